@@ -1,0 +1,362 @@
+"""Oracle (test infrastructure): observers of the reference in NumPy.
+
+Follows ``quant_transformer/quantization/observer.py``.  Statistics are fp32 (the
+reference casts the observed tensor to the dtype of its ``min_val`` buffer,
+observer.py:134), except inside the MSEFast search where scipy hands float64
+candidates to ``calculate_qparams`` (observer.py:423-428).
+"""
+import numpy as np
+
+from .fake_quant_oracle import F32, fake_quantize_per_tensor_affine
+
+EPS = F32(1e-8)  # observer.py:31
+
+
+def quant_range(bit, symmetric):
+    """observer.py:32-37."""
+    if symmetric:
+        return -2 ** (bit - 1), 2 ** (bit - 1) - 1
+    return 0, 2 ** bit - 1
+
+
+def calculate_qparams(min_val, max_val, quant_min, quant_max, symmetric):
+    """observer.py:101-119.  Works in the dtype of ``min_val`` (fp32, or fp64 inside MSEFast).
+
+    Returns (scale, zero_point); zero_point is int32 zeros when symmetric
+    (observer.py:109) and a float array otherwise (observer.py:117-118).
+    """
+    min_val = np.asarray(min_val)
+    max_val = np.asarray(max_val)
+    dt = min_val.dtype if min_val.dtype.kind == "f" else F32
+    zero = dt.type(0)
+    min_neg = np.minimum(min_val.astype(dt), zero)
+    max_pos = np.maximum(max_val.astype(dt), zero)
+    eps = EPS.astype(dt)
+    if symmetric:
+        max_pos = np.maximum(-min_neg, max_pos)
+        scale = max_pos / dt.type(float(quant_max - quant_min) / 2)
+        scale = np.maximum(scale, eps)
+        zero_point = np.zeros(min_neg.shape, dtype=np.int32)
+    else:
+        scale = (max_pos - min_neg) / dt.type(float(quant_max - quant_min))
+        scale = np.maximum(scale, eps)
+        zero_point = dt.type(quant_min) - np.round(min_neg / scale)
+        zero_point = np.clip(zero_point, dt.type(quant_min), dt.type(quant_max))
+    return scale, zero_point
+
+
+# ---------------------------------------------------------------------------
+# padding removal (observer.py:72-98)
+# ---------------------------------------------------------------------------
+
+def _tokens_first(x, seq_pos):
+    """observer.py:74-80 / 88-94: move ``seq_pos`` to axis 1 and flatten the rest -> [B, T, F]."""
+    x = np.asarray(x)
+    other = [d for d in range(x.ndim) if d != seq_pos]
+    if len(other) == 3:
+        x = np.transpose(x, (other[0], seq_pos, other[1], other[2]))
+        x = x.reshape(x.shape[0], x.shape[1], -1)
+    elif len(other) == 2:
+        x = np.transpose(x, (other[0], seq_pos, other[1]))
+    return x
+
+
+def remove_padding(x, lengths, seq_pos):
+    """observer.py:72-84: concatenate the first ``lengths[b]`` tokens of every sample -> [sum L, F].
+
+    ``zip`` (observer.py:82) stops at the shorter of (lengths, batch rows): a
+    ``[B*h, T, S]`` BART tensor with a length-B mask keeps only its first B rows.
+    """
+    xt = _tokens_first(x, seq_pos)
+    rows = [seq[: int(n)] for n, seq in zip(np.asarray(lengths).tolist(), xt)]
+    if not rows:
+        return np.zeros((0,), dtype=F32)
+    return np.concatenate(rows, axis=0).astype(F32)
+
+
+def reshape_batch_embedding(x, seq_pos):
+    """observer.py:86-98: as remove_padding with every token kept."""
+    xt = _tokens_first(x, seq_pos)
+    return xt.reshape(-1, xt.shape[-1]).astype(F32)
+
+
+# ---------------------------------------------------------------------------
+# torch.quantile (linear interpolation) restated; pinned in tests/test_oracle_pinning.py
+# ---------------------------------------------------------------------------
+
+def fma_f32(a, b, c):
+    """Correctly rounded fp32 ``a*b + c`` (single rounding), as torch's CPU lerp kernel computes.
+
+    The product of two fp32 values is exact in float64; the float64 sum may
+    round once, so the TwoSum error term is used to break an fp32 tie the way
+    the infinitely precise value would.
+    """
+    p = np.float64(F32(a)) * np.float64(F32(b))
+    c = np.float64(F32(c))
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)
+    r = F32(s)
+    if err != 0.0 and np.isfinite(r):
+        rd = np.float64(r)
+        if rd != s:
+            # s lies strictly between fp32 neighbours; a halfway case needs the sign of err
+            other = np.nextafter(r, F32(np.inf) if s > rd else F32(-np.inf))
+            mid = (rd + np.float64(other)) * 0.5
+            if s == mid:
+                toward_other = (err > 0) == (np.float64(other) > rd)
+                r = other if toward_other else r
+    return F32(r)
+
+
+def torch_quantile_linear(values, q):
+    """``torch.quantile(values, q)`` for a 1-D fp32 tensor and scalar ``q`` (observer.py:51).
+
+    rank = fp32(q) * (n-1) in fp32; below/above = floor/ceil; result =
+    lerp(below, above, rank - floor(rank)) with torch's two-branch lerp
+    evaluated with one fused multiply-add per branch.
+    """
+    v = np.sort(np.asarray(values, dtype=F32).reshape(-1))
+    n = v.size
+    if np.isnan(v).any():
+        return F32(np.nan)
+    rank = F32(q) * F32(n - 1)
+    lo = int(np.floor(rank))
+    hi = int(np.ceil(rank))
+    w = F32(rank - F32(lo))
+    a, b = v[lo], v[hi]
+    diff = F32(b - a)
+    if w < F32(0.5):
+        return fma_f32(w, diff, a)
+    return fma_f32(F32(w - F32(1)), diff, b)
+
+
+def token_min_max(value):
+    """observer.py:64-65: per-token max and min over the feature axis of ``[N_tok, F]``."""
+    value = np.asarray(value, dtype=F32)
+    return value.min(axis=1), value.max(axis=1)
+
+
+def prune_thresholds(token_min, token_max, percentile):
+    """observer.py:50-59,66-67: clipping bounds picked by the token-wise percentile.
+
+    upper = quantile(|token_max|, p); lower = -quantile(|token_min|, p);
+    up = max(token_max[token_max <= upper]); lo = min(token_min[token_min >= lower]).
+    """
+    upper = torch_quantile_linear(np.abs(token_max), percentile)
+    lower = -torch_quantile_linear(np.abs(token_min), percentile)
+    up = token_max[token_max <= upper].max()
+    lo = token_min[token_min >= lower].min()
+    return F32(lo), F32(up)
+
+
+def prune_token(value, percentile, name=""):
+    """observer.py:61-70: returns the clipped ``[N_tok, F]`` tensor (unchanged for attention_probs)."""
+    value = np.asarray(value, dtype=F32)
+    if "attention_probs" in name:
+        return value
+    tmin, tmax = token_min_max(value)
+    lo, up = prune_thresholds(tmin, tmax, percentile)
+    # torch.clip(value, min=lo, max=up) == min(max(value, lo), up)
+    return np.minimum(np.maximum(value, lo), up)
+
+
+def aminmax(x):
+    x = np.asarray(x, dtype=F32)
+    return F32(x.min()), F32(x.max())
+
+
+def _to_channel_rows(x, ch_axis):
+    """observer.py:11-21 ``_transform_to_ch_axis``: swap ch_axis with axis 0 and flatten -> [C, -1]."""
+    x = np.asarray(x, dtype=F32)
+    order = list(range(x.ndim))
+    order[ch_axis], order[0] = 0, ch_axis
+    return np.transpose(x, order).reshape(x.shape[ch_axis], -1)
+
+
+# ---------------------------------------------------------------------------
+# observer state machines
+# ---------------------------------------------------------------------------
+
+class ObserverState:
+    """Plain-data stand-in for ObserverBase's buffers (observer.py:26-39)."""
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1, name=""):
+        self.bit, self.symmetric, self.ch_axis = bit, symmetric, ch_axis
+        self.quant_min, self.quant_max = quant_range(bit, symmetric)
+        self.min_val = np.asarray(F32(np.inf))
+        self.max_val = np.asarray(F32(-np.inf))
+        self.cnt = 0
+        self.percentile = None
+        self.name = name
+        self.one_side_dist = None
+
+    def qparams(self):
+        return calculate_qparams(self.min_val, self.max_val, self.quant_min, self.quant_max, self.symmetric)
+
+    # observer.py:194-202 (also 228-236, 559-567)
+    def _avg_update(self, cur_min, cur_max):
+        if self.max_val.size <= 1 and np.isinf(self.max_val).all():
+            mn, mx = np.asarray(cur_min), np.asarray(cur_max)
+        else:
+            c = F32(self.cnt) if self.max_val.dtype == F32 else np.float64(self.cnt)
+            mn = self.min_val * c + cur_min
+            mx = self.max_val * c + cur_max
+        self.cnt += 1
+        d = F32(self.cnt) if np.asarray(mn).dtype == F32 else np.float64(self.cnt)
+        self.min_val = np.asarray(mn / d)
+        self.max_val = np.asarray(mx / d)
+
+    # observer.py:143-144 (also 535-536)
+    def _running_update(self, cur_min, cur_max):
+        self.min_val = np.minimum(self.min_val, cur_min)
+        self.max_val = np.maximum(self.max_val, cur_max)
+
+
+def _prepare(x, lengths, seq_pos):
+    x = np.asarray(x, dtype=F32)
+    if lengths is not None:
+        return remove_padding(x, lengths, seq_pos)
+    return x
+
+
+def observe_minmax(st, x, lengths=None, seq_pos=-1):
+    """MinMaxObserver.forward, observer.py:130-145."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = _prepare(x, lengths, seq_pos)
+    if st.ch_axis == -1:
+        cur_min, cur_max = aminmax(x)
+    else:
+        rows = _to_channel_rows(x, st.ch_axis)
+        cur_min, cur_max = rows.min(axis=1), rows.max(axis=1)
+    st._running_update(cur_min, cur_max)
+
+
+def observe_avg_minmax(st, x, lengths=None, seq_pos=-1):
+    """AvgMinMaxObserver.forward, observer.py:184-203."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = _prepare(x, lengths, seq_pos)
+    assert st.ch_axis == -1
+    st._avg_update(*aminmax(x))
+
+
+def observe_avg_prune_minmax(st, x, lengths=None, seq_pos=-1):
+    """AvgPruneMinMaxObserver.forward, observer.py:214-237."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = np.asarray(x, dtype=F32)
+    if lengths is not None:
+        x = prune_token(remove_padding(x, lengths, seq_pos), st.percentile, st.name)
+    elif seq_pos != -1:
+        x = prune_token(reshape_batch_embedding(x, seq_pos), st.percentile, st.name)
+    assert st.ch_axis == -1
+    st._avg_update(*aminmax(x))
+
+
+# ---------------------------------------------------------------------------
+# MSEFast (observer.py:412-567)
+# ---------------------------------------------------------------------------
+
+def mse_loss(x, new_min, new_max, quant_min, quant_max, symmetric):
+    """observer.py:423-432 ``loss_fx`` + ``lp_loss`` (p=2).
+
+    ``new_min/new_max`` arrive as float64 (scipy), so qparams are float64; the
+    scale reaches the fake-quant as a Python float and is applied in fp32; the
+    zero-point is truncated with ``int()``.  Loss is the fp32 mean of squared
+    error (accumulated here in float64 and rounded once; torch's fp32 summation
+    order is not part of the reference).
+    """
+    x = np.asarray(x, dtype=F32)
+    scale, zp = calculate_qparams(np.float64(new_min), np.float64(new_max), quant_min, quant_max, symmetric)
+    _, y = fake_quantize_per_tensor_affine(x, F32(float(scale)), F32(int(zp)), quant_min, quant_max)
+    d = np.abs(y - x)
+    return F32((d * d).astype(np.float64).mean())
+
+
+def one_side_dist(x):
+    """observer.py:528-529."""
+    x = np.asarray(x)
+    return "pos" if x.min() >= 0.0 else "neg" if x.max() <= 0.0 else "no"
+
+
+def msefast_search_1d(x, x_min, x_max, st, counter=None):
+    """observer.py:441-445,483-494: bounded Brent over the clipping range, symmetric or one-sided."""
+    from scipy.optimize import minimize_scalar
+    xr = float(max(abs(float(x_min)), float(x_max)))
+
+    def loss(r):
+        if counter is not None:
+            counter[0] += 1
+        lo = 0.0 if st.one_side_dist == "pos" else -r
+        hi = 0.0 if st.one_side_dist == "neg" else r
+        return mse_loss(x, lo, hi, st.quant_min, st.quant_max, st.symmetric)
+
+    res = minimize_scalar(loss, bounds=(min(0.1, 0.01 * xr), xr), method="Bounded")
+    r = np.float64(res.x)
+    # observer.py:491-492: the one-sided zero is zeros_like(fp32 extremum); the searched side is float64
+    best_min = F32(0) if st.one_side_dist == "pos" else -r
+    best_max = F32(0) if st.one_side_dist == "neg" else r
+    return best_min, best_max
+
+
+def msefast_search_2d(x, x_min, x_max, st, counter=None):
+    """observer.py:434-481: outer Brent over range, inner Brent over shift."""
+    from scipy.optimize import minimize_scalar
+    x_min, x_max = float(x_min), float(x_max)
+    span = float(quant_max_minus_min(st))
+
+    def shift_loss(shift, xr):
+        if counter is not None:
+            counter[0] += 1
+        return mse_loss(x, max(0.0 - shift, x_min), min(xr - shift, x_max),
+                        st.quant_min, st.quant_max, st.symmetric)
+
+    def shift_bounds(xr):
+        delta = xr / span
+        return delta * st.quant_min, delta * st.quant_max
+
+    def range_loss(xr):
+        return minimize_scalar(shift_loss, args=(xr,), bounds=shift_bounds(xr), method="Bounded").fun
+
+    xr0 = float(F32(x_max) - F32(x_min))  # fp32 subtraction of the observed extrema (observer.py:459)
+    res = minimize_scalar(range_loss, bounds=(min(0.1, 0.01 * xr0), xr0), method="Bounded")
+    final_range = res.x
+    sub = minimize_scalar(shift_loss, args=(final_range,), bounds=shift_bounds(final_range), method="Bounded")
+    # observer.py:479-480: Python max/min keep the fp32 extremum's dtype when it wins
+    lo, hi = np.float64(0.0 - sub.x), np.float64(final_range - sub.x)
+    return (F32(x_min) if x_min > lo else lo), (F32(x_max) if x_max < hi else hi)
+
+
+def quant_max_minus_min(st):
+    return st.quant_max - st.quant_min
+
+
+def observe_msefast(st, x, lengths=None, seq_pos=-1, average=False, counter=None):
+    """MSEFastObserver.forward (observer.py:520-536) / AvgMSEFastObserver.forward (545-567)."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = _prepare(x, lengths, seq_pos)
+    if st.one_side_dist is None:
+        st.one_side_dist = one_side_dist(x)
+    search = msefast_search_1d if (st.one_side_dist != "no" or st.symmetric) else msefast_search_2d
+    if st.ch_axis == -1:
+        x_min, x_max = aminmax(x)
+        best_min, best_max = search(x, x_min, x_max, st, counter)
+        # per-tensor results keep the dtype the search produced (float64 from scipy, observer.py:481,494)
+        best_min, best_max = np.asarray(best_min), np.asarray(best_max)
+    else:
+        rows = _to_channel_rows(x, st.ch_axis)
+        best_min, best_max = rows.min(axis=1), rows.max(axis=1)
+        for c in range(rows.shape[0]):
+            lo, hi = search(rows[c], best_min[c], best_max[c], st, counter)
+            best_min[c], best_max[c] = lo, hi  # assignment into fp32 tensors (observer.py:504,516)
+    if average:
+        st._avg_update(best_min, best_max)
+    else:
+        st._running_update(best_min, best_max)

@@ -1,0 +1,76 @@
+"""Pin the oracle's restatements of third-party arithmetic against the installed libraries.
+
+torch.quantile (linear) and scipy's bounded minimiser are not in the reference
+tree; the oracle restates them (oracle/observer_oracle.py, oracle/brent.py).
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import minimize_scalar
+
+from oracle.observer_oracle import torch_quantile_linear, fma_f32
+from oracle.brent import BoundedBrent, minimize_bounded
+
+
+def test_quantile_matches_torch_bit_for_bit():
+    rng = np.random.default_rng(0)
+    qs = [1.0, 0.99, 0.97, 0.9967, 0.71, 0.95, 0.9, 0.85, 0.7, 1 - 0.0033 * 7, 0.5, 0.0, 0.123]
+    for trial in range(1500):
+        n = int(rng.integers(1, 6000))
+        v = (np.abs(rng.standard_normal(n)) * rng.choice([1, 20, 0.01])).astype(np.float32)
+        q = float(rng.choice(qs))
+        want = np.float32(torch.quantile(torch.from_numpy(v), q).item())
+        assert torch_quantile_linear(v, q) == want, (n, q)
+
+
+def test_fma_is_single_rounded():
+    import fractions
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        a, b, c = (np.float32(v) for v in rng.standard_normal(3) * rng.choice([1e-3, 1, 1e3]))
+        exact = fractions.Fraction(float(a)) * fractions.Fraction(float(b)) + fractions.Fraction(float(c))
+        r = fma_f32(a, b, c)
+        lo, hi = np.nextafter(r, np.float32(-np.inf)), np.nextafter(r, np.float32(np.inf))
+        err = abs(fractions.Fraction(float(r)) - exact)
+        assert err <= abs(fractions.Fraction(float(lo)) - exact) and err <= abs(fractions.Fraction(float(hi)) - exact)
+
+
+FUNCS = [
+    (lambda x: (x - 2.0) ** 2, (0.0, 5.0)),
+    (lambda x: np.sin(x) + 0.1 * x, (0.0, 10.0)),
+    (lambda x: abs(x - 0.3) + 0.01 * x * x, (-1.0, 1.0)),
+    (lambda x: np.cosh(x - 1.5), (0.1, 4.0)),
+    (lambda x: -x, (0.0, 1.0)),            # minimum at the upper bound
+    (lambda x: x, (0.25, 3.0)),            # minimum at the lower bound
+    (lambda x: np.floor(x * 7) / 7.0 + (x - 1) ** 2 * 0.05, (0.0, 2.0)),   # staircase, like a quantisation loss
+]
+
+
+@pytest.mark.parametrize("idx", range(len(FUNCS)))
+def test_bounded_brent_matches_scipy_iterates(idx):
+    f, (lo, hi) = FUNCS[idx]
+    seen = []
+
+    def wrapped(x):
+        seen.append(float(x))
+        return float(f(x))
+    res = minimize_scalar(wrapped, bounds=(lo, hi), method="Bounded")
+    mine = []
+
+    def wrapped2(x):
+        mine.append(float(x))
+        return float(f(x))
+    x, fx, nfev = minimize_bounded(wrapped2, lo, hi)
+    assert nfev == res.nfev
+    assert mine == seen            # identical iterate sequence
+    assert x == float(res.x) and fx == float(res.fun)
+
+
+def test_bounded_brent_ask_tell_and_maxiter():
+    st = BoundedBrent(0.0, 1.0, maxiter=5)
+    x = st.start()
+    n = 0
+    while x is not None:
+        n += 1
+        x = st.tell((x - 0.77) ** 2)
+    assert n == 5 and st.done

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: observer + fake-quant over BERT-base [256,128,768] activations on MI355X.
+
+One "step" = one call of an activation quantizer on one resident fp32 batch with observer and
+fake-quant both on -- AvgPruneMinMaxObserver (token-wise clipping, p = 0.95, padded tokens
+skipped) -> running average -> calculate_qparams -> LSQ+ fake-quant forward -- i.e. the
+``observer -> fake-quant in one call`` row of BASELINE.md: three HIP launches
+(token_minmax, token_range_finalize, fake_quant).  ``value`` counts ALGORITHMIC bytes:
+4 B per observed (non-padded) element + 8 B per element for the fake-quant.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; N>1 under torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPE = (256, 128, 768)          # BASELINE.json: BERT-base 256 x 128 x 768 activations
+PERCENTILE = 0.95
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+GIB = float(1 << 30)
+
+
+def make_inputs(dev, n_buffers, seed):
+    """BASELINE.md section 4 synthetic inputs: randn with 6 seeded outlier hidden dims x20; lengths randint(8,129)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    outliers = torch.randperm(SHAPE[2], generator=g)[:6]
+    lengths = torch.randint(8, 129, (SHAPE[0],), generator=g)
+    gd = torch.Generator(device=dev).manual_seed(seed)
+    xs = []
+    for _ in range(n_buffers):
+        x = torch.randn(*SHAPE, device=dev, generator=gd)
+        x[..., outliers.to(dev)] *= 20.0
+        xs.append(x)
+    return xs, lengths
+
+
+def make_quantizer(dev):
+    from types import SimpleNamespace as NS
+    from outlier_suppression_amd.quantization import Quantizer
+    cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    q = Quantizer(None, cfg).to(dev)
+    q.observer.set_name("bert.encoder.layer.0.output.LayerNorm.layernorm_post_act_fake_quantize.observer")
+    q.observer.set_percentile(PERCENTILE)
+    q.enable_observer()
+    q.enable_fake_quant()
+    return q
+
+
+def cpu_baseline(seed, budget_s=20.0):
+    """The same step through oracle/torch_eager.py (the eager op chains the reference executes) on the
+    host cores, on a bounded sample: 32 of the 256 sequences per step, repeated for ~budget_s."""
+    from oracle import torch_eager as TE
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(seed)
+    outliers = torch.randperm(SHAPE[2], generator=g)[:6]
+    lengths = torch.randint(8, 129, (SHAPE[0],), generator=g)[:32]
+    x = torch.randn(32, SHAPE[1], SHAPE[2], generator=g)
+    x[..., outliers] *= 20.0
+    bytes_step = 4 * int(lengths.sum()) * SHAPE[2] + 8 * x.numel()
+    state = [torch.tensor(float("inf")), torch.tensor(float("-inf")), 0]
+    with torch.no_grad():
+        TE.observe_prune_then_quantize(x, lengths, PERCENTILE, state)     # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            TE.observe_prune_then_quantize(x, lengths, PERCENTILE, state)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 200:
+                break
+        dt = (time.perf_counter() - t0) / reps
+    return {"value": round(bytes_step / dt / GIB, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_eager.py (stock torch CPU ops = what the reference executes), "
+                      f"32 of 256 sequences [32,128,768], {reps} reps, {dt * 1e3:.1f} ms/step, same byte accounting"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--buffers", type=int, default=4, help="distinct input tensors cycled through (4 x 96 MiB > 256 MiB Infinity Cache)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)    # "nccl" is RCCL on ROCm
+
+    from outlier_suppression_amd import _hip, calibration
+    _hip.load()
+    q = make_quantizer(dev)
+    xs, lengths = make_inputs(dev, args.buffers, seed=1234 + rank)
+    lengths = lengths.to(dev)
+    n_elem = xs[0].numel()
+    valid_elem = int(lengths.sum().item()) * SHAPE[2]
+    bytes_step = 4 * valid_elem + 8 * n_elem
+
+    def step(i):
+        return q(xs[i % len(xs)], lengths, 1)
+
+    for i in range(args.warmup):
+        step(i)
+    # per-batch statistics table for the sharded-calibration exchange (N > 1)
+    table = torch.zeros(args.steps, 1, 2, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = xs[i % len(xs)]
+        # same three launches as q(x, lengths, 1); split here only to bracket the dominant kernel with events
+        q._observe(x, lengths, 1)
+        ev[i][0].record()
+        y = q._quantize(x)
+        ev[i][1].record()
+    if world > 1:
+        # the path's one real exchange: per-batch statistics, gathered once and replayed in batch order
+        table[:, 0, 0] = q.observer.min_val
+        table[:, 0, 1] = q.observer.max_val
+        calibration.gather_batch_table(table, args.steps * world)
+    barrier()
+    dt = time.perf_counter() - t0
+    del y
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    fq_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    fq_avg_ms = sum(fq_ms) / len(fq_ms)
+    achieved = 8.0 * n_elem / (fq_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("fq_tensor_vec_kernel", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    value = bytes_step * args.steps * world / dt / GIB
+    out = {
+        "metric": "fake-quant+observer GiB/s (% HBM peak)",
+        "value": round(value, 2),
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BERT-base activation [256,128,768] fp32, AvgPruneMinMaxObserver(p=0.95, lengths randint(8,129)) "
+                               "-> running average -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]; configs[1] site shape",
+                   "launches_per_step": 3, "buffers_cycled": len(xs),
+                   "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
+                   "pct_hbm_peak": round(100.0 * value * GIB / 1e9 / (HBM_PEAK_GBS * world), 2)},
+        "roofline": {"bound": "hbm", "kernel": "fq_tensor_vec_kernel<false> (fake-quant forward, 8 B/elem)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "avg_launch_us": round(fq_avg_ms * 1e3, 2), "median_launch_us": round(fq_ms[len(fq_ms) // 2] * 1e3, 2),
+                     "algorithmic_bytes_per_launch": 8 * n_elem},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * osq_hip.h -- C ABI of the MI355X (gfx950) fake-quant / observer hot path.
+ *
+ * The reference (wimh966/outlier_suppression) has no FFI: its hot path is a chain
+ * of eager PyTorch ops inside quant_transformer/quantization/ (the .py files).  Each entry
+ * point below replaces one such chain; the comment above it cites the reference
+ * lines it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add to call them.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on
+ *     that stream and never synchronises with the host;
+ *   - scalars that the reference reads with `.item()` (scale, zero_point,
+ *     min_val, max_val) stay on the device and are passed by pointer;
+ *   - return value: 0 on success, a negative osq_status otherwise;
+ *     osq_last_error() returns a thread-local description;
+ *   - `workspace` is caller-owned device scratch of at least
+ *     osq_workspace_bytes() bytes, zero-initialised ONCE by the caller and then
+ *     reused (kernels leave it zeroed where they need it zeroed).  One
+ *     workspace per stream in flight.
+ */
+#ifndef OSQ_HIP_H
+#define OSQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* osq_stream;
+
+typedef enum osq_status {
+    OSQ_OK = 0,
+    OSQ_ERR_INVALID_ARGUMENT = -1,
+    OSQ_ERR_HIP = -2,
+    OSQ_ERR_UNSUPPORTED = -3
+} osq_status;
+
+/* zero-point storage: FixedFakeQuantize keeps int32 (fake_quant.py:105),
+ * LSQPlusFakeQuantize an fp32 Parameter (fake_quant.py:174). */
+typedef enum osq_zp_type { OSQ_ZP_INT32 = 0, OSQ_ZP_FLOAT32 = 1 } osq_zp_type;
+
+/* how the learnable variants post-process (scale, zero_point) before quantising */
+typedef enum osq_param_mode {
+    OSQ_PARAM_FIXED = 0,   /* util_quant.py:11-26   use as is                                  */
+    OSQ_PARAM_LSQ = 1,     /* util_quant.py:29-45   scale <- grad_scale(scale, g)              */
+    OSQ_PARAM_LSQPLUS = 2  /* util_quant.py:48-67   zp <- round_ste(zp); both <- grad_scale()  */
+} osq_param_mode;
+
+/* running-statistic rule applied after a batch's (min, max) is known */
+typedef enum osq_update_rule {
+    OSQ_UPDATE_NONE = 0,     /* only report the batch's (min, max)                      */
+    OSQ_UPDATE_RUNNING = 1,  /* observer.py:143-144  min_val = min(min_val, cur) ...    */
+    OSQ_UPDATE_AVERAGE = 2   /* observer.py:194-202  (m*cnt + cur) / (cnt+1)            */
+} osq_update_rule;
+
+/*
+ * Logical [batch, tokens, feat_outer, feat_inner] view of an activation, i.e. the
+ * tensor observer.py:72-80 builds with permute+reshape, described by element
+ * strides instead of being materialised.  feat_inner is the fastest feature axis.
+ *   [B,T,H]            seq_pos=1: outer=1,  inner=H
+ *   [B,h,T,d]          seq_pos=2: outer=h,  inner=d
+ *   [B,h,d,T]          seq_pos=3: outer=h,  inner=d  (strides of the view)
+ *   [B,h,T,S]          seq_pos=2: outer=h,  inner=S
+ */
+typedef struct osq_token_view {
+    int64_t batch, tokens, feat_outer, feat_inner;
+    int64_t stride_batch, stride_token, stride_outer, stride_inner;
+} osq_token_view;
+
+const char* osq_last_error(void);
+int         osq_abi_version(void);
+size_t      osq_workspace_bytes(void);
+
+/* ------------------------------------------------------------------ fake-quant forward */
+
+/* util_quant.py:11-15 fake_quantize_per_tensor_affine, as called by
+ * FixedFakeQuantize.forward fake_quant.py:123-125 (scale/zero_point stay on device
+ * instead of .item()); with mode=LSQ/LSQPLUS also util_quant.py:29-34 / 48-55 forward
+ * (LSQFakeQuantize / LSQPlusFakeQuantize.forward, fake_quant.py:159-167 / 199-208).
+ * x, y: n contiguous fp32.  x_quant (nullable): the clamped integer tensor, fp32 storage. */
+int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t n,
+                              const float* scale, const void* zero_point, int zp_type,
+                              int mode, float grad_factor, int quant_min, int quant_max,
+                              osq_stream stream);
+
+/* Same arithmetic for a non-dense tensor of up to 4 dims (e.g. hidden_states[:, 0],
+ * quant_bert.py:445): explicit sizes and element strides for input and output. */
+int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,
+                                      const int64_t sizes[4], const int64_t x_strides[4],
+                                      const int64_t y_strides[4],
+                                      const float* scale, const void* zero_point, int zp_type,
+                                      int mode, float grad_factor, int quant_min, int quant_max,
+                                      osq_stream stream);
+
+/* util_quant.py:18-26 fake_quantize_per_channel_affine (and the per-channel learnable
+ * forwards :37-45, :58-67).  x is contiguous and viewed as [outer, channels, inner]
+ * with ch_axis in the middle; scale/zero_point have `channels` entries. */
+int osq_fake_quant_per_channel(const float* x, float* y, float* x_quant,
+                               int64_t outer, int64_t channels, int64_t inner,
+                               const float* scale, const void* zero_point, int zp_type,
+                               int mode, float grad_factor, int quant_min, int quant_max,
+                               osq_stream stream);
+
+/* ------------------------------------------------------------------ LSQ / LSQ+ backward */
+
+/* What autograd produces for util_quant.py:48-55 (per-tensor): dx (elementwise, same
+ * fp32 operations as autograd), dscale[1], dzero_point[1] (nullable for LSQ).
+ * Needed by learn_scale, token_wise_clipping.py:89-107. */
+int osq_lsq_backward_per_tensor(const float* x, const float* grad_out, float* grad_x, int64_t n,
+                                const float* scale, const void* zero_point, int zp_type,
+                                int mode, float grad_factor, int quant_min, int quant_max,
+                                float* grad_scale, float* grad_zero_point,
+                                void* workspace, osq_stream stream);
+
+/* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner]. */
+int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,
+                                 int64_t outer, int64_t channels, int64_t inner,
+                                 const float* scale, const void* zero_point, int zp_type,
+                                 int mode, float grad_factor, int quant_min, int quant_max,
+                                 float* grad_scale, float* grad_zero_point,
+                                 osq_stream stream);
+
+/* fake_quant.py:152-153 / 188-191: what LSQFakeQuantize / LSQPlusFakeQuantize do to their
+ * parameters on every forward while the observer is off:
+ *   scale.abs_(); scale.clamp_(min=eps); zero_point.clamp_(quant_min, quant_max)  (fp32 zp only)
+ * n entries, in place, one launch.  zero_point may be NULL (LSQ keeps an int32 buffer). */
+int osq_lsq_sanitize(float* scale, float* zero_point, int64_t n, float eps,
+                     int quant_min, int quant_max, osq_stream stream);
+
+/* ------------------------------------------------------------------ observers */
+
+/* observer.py:101-119 ObserverBase.calculate_qparams over n entries.
+ * zero_point_out is int32 or fp32 storage according to zp_type. */
+int osq_calculate_qparams(const float* min_val, const float* max_val, int64_t n,
+                          int quant_min, int quant_max, int symmetric,
+                          float* scale_out, void* zero_point_out, int zp_type,
+                          osq_stream stream);
+
+/* observer.py:139 torch._aminmax(x) over n contiguous values, followed by the
+ * running-statistic rule of the observer (MinMaxObserver :143-144, Avg* :194-202)
+ * and, when scale_out != NULL, calculate_qparams (:101-119) -- what
+ * QuantizeBase.forward does after observer(...) at fake_quant.py:108-116.
+ * cur_minmax (nullable): the batch's own (min, max), 2 floats.  `cnt` is the
+ * observer's batch counter BEFORE this call (host int, observer.py:198). */
+int osq_observe_flat(const float* x, int64_t n,
+                     int update_rule, int64_t cnt, float* min_val, float* max_val,
+                     float* cur_minmax,
+                     int quant_min, int quant_max, int symmetric,
+                     float* scale_out, void* zero_point_out, int zp_type,
+                     void* workspace, osq_stream stream);
+
+/* observer.py:141-144 per-channel min/max: _transform_to_ch_axis + _aminmax(y, 1) +
+ * running min/max, x contiguous viewed as [outer, channels, inner]; optional
+ * qparams per channel.  min_val/max_val hold `channels` entries. */
+int osq_observe_channels(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                         int update_rule, int64_t cnt, float* min_val, float* max_val,
+                         int quant_min, int quant_max, int symmetric,
+                         float* scale_out, void* zero_point_out, int zp_type,
+                         osq_stream stream);
+
+/* observer.py:64-65 after observer.py:72-84: per-token min and max over the feature
+ * axes, for the tokens t < lengths[b] only (lengths == NULL: every token,
+ * observer.py:86-98).  token_min/token_max have batch*tokens slots, slot b*T+t;
+ * slots of padded tokens are left untouched. */
+int osq_token_minmax(const float* x, const osq_token_view* view, const int64_t* lengths,
+                     float* token_min, float* token_max, osq_stream stream);
+
+/* Everything after the per-token extrema in AvgPruneMinMaxObserver.forward /
+ * AvgMinMaxObserver.forward / MinMaxObserver.forward with a mask:
+ *   prune != 0: cac_thres + prune_token (observer.py:50-70) with `percentile`;
+ *   prune == 0: plain min/max over the valid tokens (observer.py:193), also used
+ *               when 'attention_probs' is in the observer's name (observer.py:62-63);
+ * then the update rule (observer.py:194-202 or 143-144) and optional qparams.
+ * One launch, one workgroup. */
+int osq_token_range_finalize(const float* token_min, const float* token_max,
+                             int64_t batch, int64_t tokens, const int64_t* lengths,
+                             int prune, double percentile,
+                             int update_rule, int64_t cnt, float* min_val, float* max_val,
+                             float* cur_minmax,
+                             int quant_min, int quant_max, int symmetric,
+                             float* scale_out, void* zero_point_out, int zp_type,
+                             osq_stream stream);
+
+/* Running statistic for a batch (min, max) that is already known -- the replay step
+ * of sharded calibration (gathered per-batch statistics applied in global batch
+ * order, observer.py:194-202).  cur_min/cur_max: n entries. */
+int osq_observer_update(const float* cur_min, const float* cur_max, int64_t n,
+                        int update_rule, int64_t cnt, float* min_val, float* max_val,
+                        osq_stream stream);
+
+/* ------------------------------------------------------------------ gamma migration */
+
+/* gamma_migration.py:70-71  w.weight.data *= gamma  (gamma broadcast over columns). */
+int osq_gamma_fold(float* weight, const float* gamma, int64_t rows, int64_t cols,
+                   osq_stream stream);
+
+/* util_layernorm.py:27  bias <- beta / gamma. */
+int osq_gamma_split_bias(const float* beta, const float* gamma, float* bias_out, int64_t n,
+                         osq_stream stream);
+
+/* util_layernorm.py:49-52 GammaResidual.forward: out = input * gamma + hidden
+ * (gamma == NULL: input + hidden).  rows x cols contiguous. */
+int osq_gamma_residual(const float* input, const float* hidden, const float* gamma,
+                       float* out, int64_t rows, int64_t cols, osq_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSQ_HIP_H */

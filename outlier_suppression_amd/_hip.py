@@ -1,0 +1,121 @@
+"""ctypes binding of ``libosq_hip.so`` (the C ABI declared in ``include/osq_hip.h``).
+
+There is no CPU fallback anywhere in this package: if the library is missing, or a
+tensor is not on a HIP device, the call raises.  PyTorch is used only for device
+memory, streams and ``torch.distributed``.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libosq_hip.so")
+
+# zero-point storage / parameter mode / update rule (mirrors include/osq_hip.h)
+ZP_INT32, ZP_FLOAT32 = 0, 1
+PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
+UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+_D = ctypes.c_double
+
+
+class TokenView(ctypes.Structure):
+    """``osq_token_view``: logical [batch, tokens, feat_outer, feat_inner] with element strides."""
+    _fields_ = [(n, _L) for n in ("batch", "tokens", "feat_outer", "feat_inner",
+                                  "stride_batch", "stride_token", "stride_outer", "stride_inner")]
+
+
+# name -> (restype, argtypes); one entry per symbol declared in include/osq_hip.h
+SIGNATURES = {
+    "osq_last_error": (ctypes.c_char_p, []),
+    "osq_abi_version": (_I, []),
+    "osq_workspace_bytes": (ctypes.c_size_t, []),
+    "osq_fake_quant_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
+                                               _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_fake_quant_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_lsq_backward_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P]),
+    "osq_lsq_backward_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
+    "osq_lsq_sanitize": (_I, [_P, _P, _L, _F, _I, _I, _P]),
+    "osq_calculate_qparams": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P]),
+    "osq_observe_flat": (_I, [_P, _L, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "osq_observe_channels": (_I, [_P, _L, _L, _L, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "osq_token_minmax": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
+    "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
+    "osq_gamma_fold": (_I, [_P, _P, _L, _L, _P]),
+    "osq_gamma_split_bias": (_I, [_P, _P, _P, _L, _P]),
+    "osq_gamma_residual": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.join(_HERE, 'csrc')}`.  outlier_suppression_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)   # torch is already imported: its libamdhip64.so.7 satisfies the dependency
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().osq_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"osq_hip {what} failed (status {rc}): {msg}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("outlier_suppression_amd: tensors must live on a HIP device "
+                               f"(got device={t.device}); there is no CPU path.")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_workspaces = {}
+
+
+def workspace(device):
+    """Zero-initialised scratch for (device, current stream); kernels leave their counters zeroed."""
+    s = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), s.cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = int(load().osq_workspace_bytes())
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,470 @@
+// Fake-quant forward and LSQ/LSQ+ backward for gfx950 (MI355X).
+//
+// Replaces the eager op chains of quant_transformer/quantization/util_quant.py:
+// one HBM read and one HBM write per element (8 B/elem) instead of eight
+// elementwise passes.  Bandwidth-bound: 16-byte global loads/stores per lane,
+// four independent 16-byte loads in flight per lane before any arithmetic,
+// grid sized to a few waves per SIMD and grid-strided above that.
+#include "osq_device.h"
+#include "osq_host.h"
+
+namespace osq {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;   // float4 loads in flight per lane
+
+template <bool WRITE_Q>
+__device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float s, float z, float qmin, float qmax) {
+    q.x = quantize_value(v.x, s, z, qmin, qmax);
+    q.y = quantize_value(v.y, s, z, qmin, qmax);
+    q.z = quantize_value(v.z, s, z, qmin, qmax);
+    q.w = quantize_value(v.w, s, z, qmin, qmax);
+    y.x = dequantize_value(q.x, s, z);
+    y.y = dequantize_value(q.y, s, z);
+    y.z = dequantize_value(q.z, s, z);
+    y.w = dequantize_value(q.w, s, z);
+}
+
+// ---------------------------------------------------------------- per-tensor, dense
+
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
+    const float4* __restrict__ x, float4* __restrict__ y, float4* __restrict__ xq, int64_t n4,
+    const float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ xqt, int tail,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const float s = p.scale, z = p.zp;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    // main body: kUnroll independent 16-byte loads, then arithmetic, then stores
+    for (; i + (kUnroll - 1) * stride < n4; i += kUnroll * stride) {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_stream(&x[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            float4 o, q;
+            fq4<WRITE_Q>(v[u], o, q, s, z, qmin, qmax);
+            store_stream(&y[i + u * stride], o);
+            if (WRITE_Q) store_stream(&xq[i + u * stride], q);
+        }
+    }
+    for (; i < n4; i += stride) {
+        float4 o, q;
+        fq4<WRITE_Q>(x[i], o, q, s, z, qmin, qmax);
+        y[i] = o;
+        if (WRITE_Q) xq[i] = q;
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) {
+        const float q = quantize_value(xt[threadIdx.x], s, z, qmin, qmax);
+        yt[threadIdx.x] = dequantize_value(q, s, z);
+        if (WRITE_Q) xqt[threadIdx.x] = q;
+    }
+}
+
+// scalar fallback for buffers that are not 16-byte aligned
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kThreads) void fq_tensor_scalar_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, int64_t n,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float q = quantize_value(x[i], p.scale, p.zp, qmin, qmax);
+        y[i] = dequantize_value(q, p.scale, p.zp);
+        if (WRITE_Q) xq[i] = q;
+    }
+}
+
+struct Strided4 {
+    int64_t size[4];
+    int64_t xs[4];
+    int64_t ys[4];
+};
+
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kThreads) void fq_tensor_strided_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, Strided4 d, int64_t n,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        int64_t r = i, xo = 0, yo = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const int64_t c = r % d.size[k];
+            r /= d.size[k];
+            xo += c * d.xs[k];
+            yo += c * d.ys[k];
+        }
+        const float q = quantize_value(x[xo], p.scale, p.zp, qmin, qmax);
+        y[yo] = dequantize_value(q, p.scale, p.zp);
+        if (WRITE_Q) xq[yo] = q;
+    }
+}
+
+// ---------------------------------------------------------------- per-channel
+
+// [rows = outer*channels, inner] with inner % 4 == 0: one wave walks whole rows, the
+// row's (scale, zero_point) is wave-uniform.  Weights [C_out, C_in], ch_axis = 0.
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kThreads) void fq_channel_rows_kernel(
+    const float4* __restrict__ x, float4* __restrict__ y, float4* __restrict__ xq,
+    int64_t rows, int64_t channels, int inner4,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kThreads / OSQ_WAVE);
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const int64_t c = r % channels;
+        const QParams p = effective_params(scale_p[c], load_zp(zp_p, zp_type, c), mode, g);
+        const float4* xr = x + r * inner4;
+        float4* yr = y + r * inner4;
+        float4* qr = WRITE_Q ? xq + r * inner4 : nullptr;
+        int j = lane;
+        for (; j + (kUnroll - 1) * OSQ_WAVE < inner4; j += kUnroll * OSQ_WAVE) {
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = xr[j + u * OSQ_WAVE];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                float4 o, q;
+                fq4<WRITE_Q>(v[u], o, q, p.scale, p.zp, qmin, qmax);
+                yr[j + u * OSQ_WAVE] = o;
+                if (WRITE_Q) qr[j + u * OSQ_WAVE] = q;
+            }
+        }
+        for (; j < inner4; j += OSQ_WAVE) {
+            float4 o, q;
+            fq4<WRITE_Q>(xr[j], o, q, p.scale, p.zp, qmin, qmax);
+            yr[j] = o;
+            if (WRITE_Q) qr[j] = q;
+        }
+    }
+}
+
+// generic [outer, channels, inner]: channel = (i / inner) % channels per element
+template <bool WRITE_Q>
+__global__ __launch_bounds__(kThreads) void fq_channel_generic_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, int64_t n,
+    int64_t channels, int64_t inner,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const int64_t c = (i / inner) % channels;
+        const QParams p = effective_params(scale_p[c], load_zp(zp_p, zp_type, c), mode, g);
+        const float q = quantize_value(x[i], p.scale, p.zp, qmin, qmax);
+        y[i] = dequantize_value(q, p.scale, p.zp);
+        if (WRITE_Q) xq[i] = q;
+    }
+}
+
+// ---------------------------------------------------------------- LSQ / LSQ+ backward
+
+// Per element (autograd of util_quant.py:48-55, see oracle/fake_quant_oracle.py):
+//   g_mul = gy * s ; g_in = inside ? g_mul : 0 ; dx = g_in / s
+//   ds  += gy * (xq - z)  +  (-g_in) * ((x / s) / s)
+//   dzp += g_in - g_mul
+// Sums: fp32 per lane over a short run, then double across lanes / blocks; block
+// partials are combined in block order by the last block (deterministic).
+struct BwdAcc {
+    float ds_mul, ds_div, dz;
+};
+
+__device__ __forceinline__ float bwd_elem(float x, float gy, float s, float z, float qmin, float qmax, BwdAcc& a) {
+    float x_int;
+    const float q = quantize_value(x, s, z, qmin, qmax, &x_int);
+    const bool inside = (x_int >= qmin) && (x_int <= qmax);
+    const float g_mul = gy * s;
+    const float g_in = inside ? g_mul : 0.0f;
+    a.ds_mul += gy * (q - z);
+    a.ds_div += (-g_in) * ((x / s) / s);
+    a.dz += g_in - g_mul;
+    return g_in / s;
+}
+
+__global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
+    const float4* __restrict__ x, const float4* __restrict__ gy, float4* __restrict__ dx, int64_t n4,
+    const float* __restrict__ xt, const float* __restrict__ gyt, float* __restrict__ dxt, int tail,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp,
+    double* __restrict__ partials, unsigned int* __restrict__ counter) {
+    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const float s = p.scale, z = p.zp;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    double t_ds = 0.0, t_dz = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += 2 * stride) {
+        const bool two = (i + stride) < n4;
+        const float4 a0 = load_stream(&x[i]);
+        const float4 b0 = load_stream(&gy[i]);
+        float4 a1 = a0, b1 = b0;
+        if (two) {
+            a1 = load_stream(&x[i + stride]);
+            b1 = load_stream(&gy[i + stride]);
+        }
+        BwdAcc acc = {0.f, 0.f, 0.f};
+        float4 o;
+        o.x = bwd_elem(a0.x, b0.x, s, z, qmin, qmax, acc);
+        o.y = bwd_elem(a0.y, b0.y, s, z, qmin, qmax, acc);
+        o.z = bwd_elem(a0.z, b0.z, s, z, qmin, qmax, acc);
+        o.w = bwd_elem(a0.w, b0.w, s, z, qmin, qmax, acc);
+        store_stream(&dx[i], o);
+        if (two) {
+            o.x = bwd_elem(a1.x, b1.x, s, z, qmin, qmax, acc);
+            o.y = bwd_elem(a1.y, b1.y, s, z, qmin, qmax, acc);
+            o.z = bwd_elem(a1.z, b1.z, s, z, qmin, qmax, acc);
+            o.w = bwd_elem(a1.w, b1.w, s, z, qmin, qmax, acc);
+            store_stream(&dx[i + stride], o);
+        }
+        t_ds += static_cast<double>(acc.ds_mul) + static_cast<double>(acc.ds_div);
+        t_dz += static_cast<double>(acc.dz);
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) {
+        BwdAcc acc = {0.f, 0.f, 0.f};
+        dxt[threadIdx.x] = bwd_elem(xt[threadIdx.x], gyt[threadIdx.x], s, z, qmin, qmax, acc);
+        t_ds += static_cast<double>(acc.ds_mul) + static_cast<double>(acc.ds_div);
+        t_dz += static_cast<double>(acc.dz);
+    }
+    __shared__ double sh[2][kThreads / OSQ_WAVE];
+    t_ds = wave_sum(t_ds);
+    t_dz = wave_sum(t_dz);
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
+    if (lane == 0) { sh[0][w] = t_ds; sh[1][w] = t_dz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < kThreads / OSQ_WAVE; ++k) { a += sh[0][k]; b += sh[1][k]; }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+    if (grid_last_block(counter, gridDim.x)) {
+        double a = 0.0, b = 0.0;
+        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) { a += partials[2 * k]; b += partials[2 * k + 1]; }
+        // fixed combination order: lane-strided partial sums, then wave tree, then waves in order
+        a = wave_sum(a);
+        b = wave_sum(b);
+        __syncthreads();
+        if (lane == 0) { sh[0][w] = a; sh[1][w] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double sa = 0.0, sb = 0.0;
+            for (int k = 0; k < kThreads / OSQ_WAVE; ++k) { sa += sh[0][k]; sb += sh[1][k]; }
+            // grad_scale backward: d(t*g)/dt = g  (util_quant.py:70-71)
+            const double gs = (mode == OSQ_PARAM_FIXED) ? 1.0 : static_cast<double>(g);
+            if (dscale) dscale[0] = static_cast<float>(sa * gs);
+            if (dzp) dzp[0] = static_cast<float>(sb * ((mode == OSQ_PARAM_LSQPLUS) ? static_cast<double>(g) : 1.0));
+            *counter = 0u;
+        }
+    }
+}
+
+// per-channel backward on [rows = outer*channels, inner]: one workgroup per channel,
+// no cross-workgroup reduction needed.
+__global__ __launch_bounds__(kThreads) void lsq_bwd_channel_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx,
+    int64_t outer, int64_t channels, int64_t inner,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp) {
+    const int64_t c = blockIdx.x;
+    const QParams p = effective_params(scale_p[c], load_zp(zp_p, zp_type, c), mode, g);
+    double t_ds = 0.0, t_dz = 0.0;
+    for (int64_t o = 0; o < outer; ++o) {
+        const int64_t base = (o * channels + c) * inner;
+        for (int64_t j = threadIdx.x; j < inner; j += kThreads) {
+            BwdAcc acc = {0.f, 0.f, 0.f};
+            dx[base + j] = bwd_elem(x[base + j], gy[base + j], p.scale, p.zp, qmin, qmax, acc);
+            t_ds += static_cast<double>(acc.ds_mul) + static_cast<double>(acc.ds_div);
+            t_dz += static_cast<double>(acc.dz);
+        }
+    }
+    __shared__ double sh[2][kThreads / OSQ_WAVE];
+    t_ds = wave_sum(t_ds);
+    t_dz = wave_sum(t_dz);
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
+    if (lane == 0) { sh[0][w] = t_ds; sh[1][w] = t_dz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < kThreads / OSQ_WAVE; ++k) { a += sh[0][k]; b += sh[1][k]; }
+        const double gs = (mode == OSQ_PARAM_FIXED) ? 1.0 : static_cast<double>(g);
+        if (dscale) dscale[c] = static_cast<float>(a * gs);
+        if (dzp) dzp[c] = static_cast<float>(b * ((mode == OSQ_PARAM_LSQPLUS) ? static_cast<double>(g) : 1.0));
+    }
+}
+
+__global__ void lsq_sanitize_kernel(float* __restrict__ scale, float* __restrict__ zp, int64_t n, float eps, float qmin,
+                                    float qmax) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = fabsf(scale[i]);
+    scale[i] = (s < eps) ? eps : s;                 // clamp_(min=eps) keeps NaN
+    if (zp) {
+        float z = zp[i];
+        z = (z < qmin) ? qmin : z;
+        z = (z > qmax) ? qmax : z;
+        zp[i] = z;
+    }
+}
+
+static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return static_cast<int>(b);
+}
+
+}  // namespace osq
+
+using namespace osq;
+
+extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t n,
+                                         const float* scale, const void* zero_point, int zp_type,
+                                         int mode, float grad_factor, int quant_min, int quant_max,
+                                         osq_stream stream) {
+    OSQ_REQUIRE(n >= 0 && (n == 0 || (x && y)) && scale && zero_point, "fake_quant_per_tensor: null pointer or n < 0");
+    OSQ_REQUIRE(mode >= OSQ_PARAM_FIXED && mode <= OSQ_PARAM_LSQPLUS, "fake_quant_per_tensor: bad mode");
+    if (n == 0) return OSQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
+    const bool aligned = aligned16(x) && aligned16(y) && (!x_quant || aligned16(x_quant));
+    if (aligned) {
+        const int64_t n4 = n / 4;
+        const int tail = static_cast<int>(n - n4 * 4);
+        const int grid = grid_for(n4, kThreads * kUnroll, kMaxBlocks);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        float4* q4 = reinterpret_cast<float4*>(x_quant);
+        if (x_quant)
+            hipLaunchKernelGGL(fq_tensor_vec_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, n4, x + n4 * 4,
+                               y + n4 * 4, x_quant + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        else
+            hipLaunchKernelGGL(fq_tensor_vec_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, n4, x + n4 * 4,
+                               y + n4 * 4, nullptr, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    } else {
+        const int grid = grid_for(n, kThreads, kMaxBlocks);
+        if (x_quant)
+            hipLaunchKernelGGL(fq_tensor_scalar_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, n, scale,
+                               zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        else
+            hipLaunchKernelGGL(fq_tensor_scalar_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, n, scale,
+                               zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    }
+    return check_launch("fake_quant_per_tensor");
+}
+
+extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,
+                                                 const int64_t sizes[4], const int64_t x_strides[4],
+                                                 const int64_t y_strides[4],
+                                                 const float* scale, const void* zero_point, int zp_type,
+                                                 int mode, float grad_factor, int quant_min, int quant_max,
+                                                 osq_stream stream) {
+    OSQ_REQUIRE(sizes && x_strides && y_strides && scale && zero_point, "fake_quant_per_tensor_strided: null pointer");
+    Strided4 d;
+    int64_t n = 1;
+    for (int k = 0; k < 4; ++k) {
+        OSQ_REQUIRE(sizes[k] >= 0, "fake_quant_per_tensor_strided: negative size");
+        d.size[k] = sizes[k]; d.xs[k] = x_strides[k]; d.ys[k] = y_strides[k];
+        n *= sizes[k];
+    }
+    if (n == 0) return OSQ_OK;
+    OSQ_REQUIRE(x && y, "fake_quant_per_tensor_strided: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
+    const int grid = grid_for(n, kThreads, kMaxBlocks);
+    if (x_quant)
+        hipLaunchKernelGGL(fq_tensor_strided_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, d, n, scale,
+                           zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    else
+        hipLaunchKernelGGL(fq_tensor_strided_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, d, n, scale,
+                           zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    return check_launch("fake_quant_per_tensor_strided");
+}
+
+extern "C" int osq_fake_quant_per_channel(const float* x, float* y, float* x_quant,
+                                          int64_t outer, int64_t channels, int64_t inner,
+                                          const float* scale, const void* zero_point, int zp_type,
+                                          int mode, float grad_factor, int quant_min, int quant_max,
+                                          osq_stream stream) {
+    OSQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0 && scale && zero_point, "fake_quant_per_channel: bad argument");
+    const int64_t n = outer * channels * inner;
+    if (n == 0) return OSQ_OK;
+    OSQ_REQUIRE(x && y, "fake_quant_per_channel: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
+    const bool aligned = aligned16(x) && aligned16(y) && (!x_quant || aligned16(x_quant));
+    if (aligned && inner % 4 == 0 && inner >= 64 && inner / 4 < (1 << 30)) {
+        const int64_t rows = outer * channels;
+        const int grid = grid_for(rows, kThreads / OSQ_WAVE, kMaxBlocks * 2);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        float4* q4 = reinterpret_cast<float4*>(x_quant);
+        if (x_quant)
+            hipLaunchKernelGGL(fq_channel_rows_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, rows, channels,
+                               static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        else
+            hipLaunchKernelGGL(fq_channel_rows_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, rows, channels,
+                               static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    } else {
+        const int grid = grid_for(n, kThreads, kMaxBlocks);
+        if (x_quant)
+            hipLaunchKernelGGL(fq_channel_generic_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, n, channels,
+                               inner, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        else
+            hipLaunchKernelGGL(fq_channel_generic_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, n, channels,
+                               inner, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+    }
+    return check_launch("fake_quant_per_channel");
+}
+
+extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out, float* grad_x, int64_t n,
+                                           const float* scale, const void* zero_point, int zp_type,
+                                           int mode, float grad_factor, int quant_min, int quant_max,
+                                           float* grad_scale, float* grad_zero_point,
+                                           void* workspace, osq_stream stream) {
+    OSQ_REQUIRE(n >= 0 && scale && zero_point && workspace, "lsq_backward_per_tensor: null pointer or n < 0");
+    OSQ_REQUIRE(n == 0 || (x && grad_out && grad_x), "lsq_backward_per_tensor: null tensor");
+    OSQ_REQUIRE(aligned16(x) && aligned16(grad_out) && aligned16(grad_x), "lsq_backward_per_tensor: tensors must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
+    const int64_t n4 = n / 4;
+    const int tail = static_cast<int>(n - n4 * 4);
+    const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
+    Workspace ws(workspace);
+    hipLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
+                       grad_out + n4 * 4, grad_x + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax,
+                       grad_scale, grad_zero_point, ws.doubles(), ws.counter(0));
+    return check_launch("lsq_backward_per_tensor");
+}
+
+extern "C" int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,
+                                            int64_t outer, int64_t channels, int64_t inner,
+                                            const float* scale, const void* zero_point, int zp_type,
+                                            int mode, float grad_factor, int quant_min, int quant_max,
+                                            float* grad_scale, float* grad_zero_point,
+                                            osq_stream stream) {
+    OSQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0 && scale && zero_point, "lsq_backward_per_channel: bad argument");
+    if (outer * channels * inner == 0) return OSQ_OK;
+    OSQ_REQUIRE(x && grad_out && grad_x, "lsq_backward_per_channel: null tensor");
+    OSQ_REQUIRE(channels < (1ll << 31), "lsq_backward_per_channel: too many channels");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lsq_bwd_channel_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads), 0, st, x, grad_out,
+                       grad_x, outer, channels, inner, scale, zero_point, zp_type, mode, grad_factor,
+                       static_cast<float>(quant_min), static_cast<float>(quant_max), grad_scale, grad_zero_point);
+    return check_launch("lsq_backward_per_channel");
+}
+
+extern "C" int osq_lsq_sanitize(float* scale, float* zero_point, int64_t n, float eps, int quant_min, int quant_max,
+                                osq_stream stream) {
+    OSQ_REQUIRE(n >= 0 && (n == 0 || scale), "lsq_sanitize: null scale or n < 0");
+    if (n == 0) return OSQ_OK;
+    hipLaunchKernelGGL(lsq_sanitize_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), scale, zero_point, n, eps, static_cast<float>(quant_min),
+                       static_cast<float>(quant_max));
+    return check_launch("lsq_sanitize");
+}

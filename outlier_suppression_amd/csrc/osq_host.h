@@ -1,0 +1,46 @@
+// Host-side helpers of the C ABI: argument checks, error text, launch checks,
+// workspace carving.  No torch types anywhere below the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/osq_hip.h"
+
+namespace osq {
+
+constexpr int kMaxBlocks = 2048;          // 256 CUs x 8 workgroups of 256 threads
+constexpr size_t kWsHeaderBytes = 256;    // 64 x uint32 tickets/counters
+constexpr size_t kWsScratchBytes = 64 * 1024;
+
+void set_error(const char* fmt, ...);
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define OSQ_REQUIRE(cond, msg)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            ::osq::set_error("%s", msg);             \
+            return OSQ_ERR_INVALID_ARGUMENT;         \
+        }                                            \
+    } while (0)
+
+static inline int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return OSQ_ERR_HIP;
+    }
+    return OSQ_OK;
+}
+
+// Caller-owned scratch: [64 counters][64 KiB scratch].  Counters are zero between
+// launches (each kernel's last workgroup resets the one it used).
+struct Workspace {
+    char* base;
+    explicit Workspace(void* p) : base(static_cast<char*>(p)) {}
+    unsigned int* counter(int k) const { return reinterpret_cast<unsigned int*>(base) + k; }
+    double* doubles() const { return reinterpret_cast<double*>(base + kWsHeaderBytes); }
+    float* floats() const { return reinterpret_cast<float*>(base + kWsHeaderBytes); }
+};
+
+}  // namespace osq

@@ -1,0 +1,393 @@
+"""Tensor-level entry points: torch tensors in, C-ABI kernel launches out.
+
+Everything here runs on the current HIP stream and never synchronises with the
+host.  No arithmetic on tensor data happens in Python; torch only allocates.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import (PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, UPDATE_AVERAGE, UPDATE_NONE, UPDATE_RUNNING,  # noqa: F401
+                   ZP_FLOAT32, ZP_INT32)
+
+
+def _zp_type(zero_point):
+    if zero_point.dtype == torch.int32:
+        return ZP_INT32
+    if zero_point.dtype == torch.float32:
+        return ZP_FLOAT32
+    raise TypeError(f"zero_point must be int32 or float32, got {zero_point.dtype}")
+
+
+def _check_f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"outlier_suppression_amd kernels compute in float32, got {t.dtype}")
+
+
+def is_dense(x):
+    """True if x's elements occupy one gap-free block of memory (any dim order)."""
+    if x.is_contiguous():
+        return True
+    expected = 1
+    for size, stride in sorted(zip(x.shape, x.stride()), key=lambda p: (p[1], p[0])):
+        if size == 1:
+            continue
+        if stride != expected:
+            return False
+        expected *= size
+    return True
+
+
+def _i64x4(vals):
+    vals = list(vals)
+    vals = [1] * (4 - len(vals)) + vals if len(vals) <= 4 else None
+    if vals is None:
+        raise NotImplementedError("strided fake-quant supports at most 4 dims")
+    return (ctypes.c_int64 * 4)(*vals)
+
+
+def _pad4_strides(x):
+    st = list(x.stride())
+    return (ctypes.c_int64 * 4)(*([0] * (4 - len(st)) + st))
+
+
+# ---------------------------------------------------------------------------------------
+# fake-quant forward
+# ---------------------------------------------------------------------------------------
+
+def fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode=PARAM_FIXED, grad_factor=1.0,
+                          return_quantized=False):
+    """(x_dequant[, x_quant]) of util_quant.py:11-15 / 29-34 / 48-55 (forward).  scale/zero_point: 1-element device tensors."""
+    lib = _hip.load()
+    _hip.require_device(x, scale, zero_point)
+    _check_f32(x, scale)
+    st = _hip.stream_ptr(x.device)
+    if is_dense(x):
+        y = torch.empty_like(x)
+        xq = torch.empty_like(x) if return_quantized else None
+        _hip.check(lib.osq_fake_quant_per_tensor(_hip.ptr(x), _hip.ptr(y), _hip.ptr(xq), x.numel(), _hip.ptr(scale),
+                                                 _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                                                 int(quant_min), int(quant_max), st), "fake_quant_per_tensor")
+    else:
+        if x.dim() > 4:
+            x = x.contiguous()
+            return fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode, grad_factor, return_quantized)
+        y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        xq = torch.empty_like(y) if return_quantized else None
+        _hip.check(lib.osq_fake_quant_per_tensor_strided(
+            _hip.ptr(x), _hip.ptr(y), _hip.ptr(xq), _i64x4(x.shape), _pad4_strides(x), _pad4_strides(y),
+            _hip.ptr(scale), _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+            int(quant_min), int(quant_max), st), "fake_quant_per_tensor_strided")
+    return (y, xq) if return_quantized else y
+
+
+def _channel_split(x, ch_axis):
+    ch_axis = ch_axis % x.dim()
+    outer = 1
+    for s in x.shape[:ch_axis]:
+        outer *= s
+    inner = 1
+    for s in x.shape[ch_axis + 1:]:
+        inner *= s
+    return outer, x.shape[ch_axis], inner
+
+
+def fake_quant_per_channel(x, scale, zero_point, ch_axis, quant_min, quant_max, mode=PARAM_FIXED, grad_factor=1.0,
+                           return_quantized=False):
+    """util_quant.py:18-26 / 37-45 / 58-67 (forward)."""
+    lib = _hip.load()
+    _hip.require_device(x, scale, zero_point)
+    _check_f32(x, scale)
+    x = x.contiguous()
+    outer, channels, inner = _channel_split(x, ch_axis)
+    if scale.numel() != channels or zero_point.numel() != channels:
+        raise ValueError(f"per-channel fake-quant: {channels} channels but scale/zero_point have "
+                         f"{scale.numel()}/{zero_point.numel()} entries")
+    y = torch.empty_like(x)
+    xq = torch.empty_like(x) if return_quantized else None
+    _hip.check(lib.osq_fake_quant_per_channel(_hip.ptr(x), _hip.ptr(y), _hip.ptr(xq), outer, channels, inner,
+                                              _hip.ptr(scale), _hip.ptr(zero_point), _zp_type(zero_point), mode,
+                                              float(grad_factor), int(quant_min), int(quant_max),
+                                              _hip.stream_ptr(x.device)), "fake_quant_per_channel")
+    return (y, xq) if return_quantized else y
+
+
+# ---------------------------------------------------------------------------------------
+# backward (STE for x; LSQ/LSQ+ for scale / zero_point)
+# ---------------------------------------------------------------------------------------
+
+def _like_layout(g, x):
+    """grad_out arranged in memory exactly like x (x is dense)."""
+    if g.stride() == x.stride() and g.is_cuda:
+        return g
+    out = torch.empty_like(x)
+    out.copy_(g)
+    return out
+
+
+def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max, mode, grad_factor,
+                            need_scale=True, need_zp=True):
+    lib = _hip.load()
+    _hip.require_device(x, grad_out, scale, zero_point)
+    _check_f32(x, grad_out, scale)
+    if not is_dense(x):
+        x = x.contiguous()
+    g = _like_layout(grad_out, x)
+    dx = torch.empty_like(x)
+    ds = torch.empty(1, dtype=torch.float32, device=x.device) if need_scale else None
+    dz = torch.empty(1, dtype=torch.float32, device=x.device) if need_zp else None
+    ws = _hip.workspace(x.device)
+    _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
+                                               _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                                               int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
+                                               _hip.stream_ptr(x.device)), "lsq_backward_per_tensor")
+    return dx, ds, dz
+
+
+def lsq_backward_per_channel(x, grad_out, scale, zero_point, ch_axis, quant_min, quant_max, mode, grad_factor,
+                             need_scale=True, need_zp=True):
+    lib = _hip.load()
+    _hip.require_device(x, grad_out, scale, zero_point)
+    _check_f32(x, grad_out, scale)
+    x = x.contiguous()
+    g = grad_out.contiguous()
+    outer, channels, inner = _channel_split(x, ch_axis)
+    dx = torch.empty_like(x)
+    ds = torch.empty(channels, dtype=torch.float32, device=x.device) if need_scale else None
+    dz = torch.empty(channels, dtype=torch.float32, device=x.device) if need_zp else None
+    _hip.check(lib.osq_lsq_backward_per_channel(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), outer, channels, inner,
+                                                _hip.ptr(scale), _hip.ptr(zero_point), _zp_type(zero_point), mode,
+                                                float(grad_factor), int(quant_min), int(quant_max), _hip.ptr(ds),
+                                                _hip.ptr(dz), _hip.stream_ptr(x.device)), "lsq_backward_per_channel")
+    return dx, ds, dz
+
+
+def lsq_sanitize_(scale, zero_point, eps, quant_min, quant_max):
+    """In place: scale <- max(|scale|, eps); fp32 zero_point <- clamp(zero_point, qmin, qmax).  One launch."""
+    lib = _hip.load()
+    _hip.require_device(scale, zero_point)
+    _check_f32(scale, zero_point)
+    _hip.check(lib.osq_lsq_sanitize(_hip.ptr(scale), _hip.ptr(zero_point), scale.numel(), float(eps), int(quant_min),
+                                    int(quant_max), _hip.stream_ptr(scale.device)), "lsq_sanitize")
+
+
+class _FakeQuantFn(torch.autograd.Function):
+    """Differentiable fake-quant: forward = one HIP launch, backward = one HIP launch."""
+
+    @staticmethod
+    def forward(ctx, x, scale, zero_point, ch_axis, quant_min, quant_max, mode, grad_factor):
+        ctx.cfg = (ch_axis, quant_min, quant_max, mode, grad_factor)
+        ctx.save_for_backward(x, scale, zero_point)
+        if ch_axis == -1:
+            return fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode, grad_factor)
+        return fake_quant_per_channel(x, scale, zero_point, ch_axis, quant_min, quant_max, mode, grad_factor)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, scale, zero_point = ctx.saved_tensors
+        ch_axis, quant_min, quant_max, mode, grad_factor = ctx.cfg
+        need_s = ctx.needs_input_grad[1]
+        need_z = ctx.needs_input_grad[2] and zero_point.dtype == torch.float32
+        if ch_axis == -1:
+            dx, ds, dz = lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max, mode, grad_factor,
+                                                 need_s, need_z)
+        else:
+            dx, ds, dz = lsq_backward_per_channel(x, grad_out, scale, zero_point, ch_axis, quant_min, quant_max, mode,
+                                                  grad_factor, need_s, need_z)
+        if ds is not None:
+            ds = ds.reshape(scale.shape)
+        if dz is not None:
+            dz = dz.reshape(zero_point.shape)
+        return (dx if ctx.needs_input_grad[0] else None), ds, dz, None, None, None, None, None
+
+
+def fake_quant(x, scale, zero_point, ch_axis, quant_min, quant_max, mode=PARAM_FIXED, grad_factor=1.0):
+    """Fake-quant with autograd when any input needs a gradient, a bare launch otherwise."""
+    needs = torch.is_grad_enabled() and (x.requires_grad or scale.requires_grad or
+                                         (zero_point.is_floating_point() and zero_point.requires_grad))
+    if needs:
+        return _FakeQuantFn.apply(x, scale, zero_point, ch_axis, quant_min, quant_max, mode, grad_factor)
+    sd, zd = scale.detach(), zero_point.detach()
+    if ch_axis == -1:
+        return fake_quant_per_tensor(x, sd, zd, quant_min, quant_max, mode, grad_factor)
+    return fake_quant_per_channel(x, sd, zd, ch_axis, quant_min, quant_max, mode, grad_factor)
+
+
+# ---------------------------------------------------------------------------------------
+# observers
+# ---------------------------------------------------------------------------------------
+
+def calculate_qparams(min_val, max_val, quant_min, quant_max, symmetric, scale_out=None, zero_point_out=None,
+                      zp_dtype=None):
+    """observer.py:101-119 on device.  Returns (scale fp32, zero_point) with zero_point int32 when
+    symmetric and fp32 otherwise unless ``zp_dtype`` / ``zero_point_out`` says differently."""
+    lib = _hip.load()
+    _hip.require_device(min_val, max_val)
+    mn = min_val.detach().to(torch.float32).contiguous()
+    mx = max_val.detach().to(torch.float32).contiguous()
+    if scale_out is None:
+        scale_out = torch.empty(mn.shape, dtype=torch.float32, device=mn.device)
+    if zero_point_out is None:
+        dt = zp_dtype if zp_dtype is not None else (torch.int32 if symmetric else torch.float32)
+        zero_point_out = torch.empty(mn.shape, dtype=dt, device=mn.device)
+    _hip.check(lib.osq_calculate_qparams(_hip.ptr(mn), _hip.ptr(mx), mn.numel(), int(quant_min), int(quant_max),
+                                         int(bool(symmetric)), _hip.ptr(scale_out), _hip.ptr(zero_point_out),
+                                         _zp_type(zero_point_out), _hip.stream_ptr(mn.device)), "calculate_qparams")
+    return scale_out, zero_point_out
+
+
+class QParamSink:
+    """Where a fused observer launch should write scale / zero_point (None = do not compute)."""
+    __slots__ = ("scale", "zero_point")
+
+    def __init__(self, scale=None, zero_point=None):
+        self.scale, self.zero_point = scale, zero_point
+
+    def args(self):
+        if self.scale is None:
+            return None, None, ZP_INT32
+        return _hip.ptr(self.scale), _hip.ptr(self.zero_point), _zp_type(self.zero_point)
+
+
+def observe_flat(x, rule, cnt, min_val, max_val, quant_min, quant_max, symmetric, sink=None, cur=None):
+    """Global min/max of a dense tensor + running statistic (+ qparams): ONE launch."""
+    lib = _hip.load()
+    _hip.require_device(x, min_val, max_val)
+    _check_f32(x, min_val, max_val)
+    if not is_dense(x):
+        x = x.contiguous()
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    ws = _hip.workspace(x.device)
+    _hip.check(lib.osq_observe_flat(_hip.ptr(x), x.numel(), rule, int(cnt), _hip.ptr(min_val), _hip.ptr(max_val),
+                                    _hip.ptr(cur), int(quant_min), int(quant_max), int(bool(symmetric)), s_ptr, z_ptr,
+                                    z_type, _hip.ptr(ws), _hip.stream_ptr(x.device)), "observe_flat")
+
+
+def observe_channels(x, ch_axis, rule, cnt, min_val, max_val, quant_min, quant_max, symmetric, sink=None):
+    """Per-channel min/max + running statistic (+ qparams): ONE launch."""
+    lib = _hip.load()
+    _hip.require_device(x, min_val, max_val)
+    _check_f32(x, min_val, max_val)
+    x = x.contiguous()
+    outer, channels, inner = _channel_split(x, ch_axis)
+    if min_val.numel() != channels or max_val.numel() != channels:
+        raise ValueError("observe_channels: statistic buffers must have one entry per channel")
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    _hip.check(lib.osq_observe_channels(_hip.ptr(x), outer, channels, inner, rule, int(cnt), _hip.ptr(min_val),
+                                        _hip.ptr(max_val), int(quant_min), int(quant_max), int(bool(symmetric)), s_ptr,
+                                        z_ptr, z_type, _hip.stream_ptr(x.device)), "observe_channels")
+
+
+def token_view(x, seq_pos, n_lengths=None):
+    """Describe x as [batch, tokens, feat_outer, feat_inner] the way observer.py:72-80 permutes it.
+
+    With a length-B mask on a tensor whose dim 0 is larger (BART's [B*h, T, S] attention
+    probabilities) ``zip`` in observer.py:82 only visits the first B rows: ``n_lengths`` trims batch.
+    """
+    if x.dim() not in (3, 4):
+        raise NotImplementedError("masked observers support 3-D and 4-D activations (observer.py:76-79)")
+    seq_pos = seq_pos % x.dim()
+    if seq_pos == 0:
+        raise ValueError("seq_pos must not be the batch axis")
+    others = [d for d in range(x.dim()) if d != seq_pos]
+    sz, st = x.shape, x.stride()
+    batch = sz[0] if n_lengths is None else min(sz[0], n_lengths)
+    if len(others) == 3:
+        fo, fi = others[1], others[2]
+        outer, inner, s_outer, s_inner = sz[fo], sz[fi], st[fo], st[fi]
+    else:
+        fi = others[1]
+        outer, inner, s_outer, s_inner = 1, sz[fi], 0, st[fi]
+    return _hip.TokenView(batch, sz[seq_pos], outer, inner, st[0], st[seq_pos], s_outer, s_inner)
+
+
+_token_scratch = {}
+
+
+def _scratch(device, n):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _token_scratch.get(key)
+    if buf is None or buf.numel() < 2 * n:
+        buf = torch.empty(2 * max(n, 4096), dtype=torch.float32, device=device)
+        _token_scratch[key] = buf
+    return buf[:n], buf[n:2 * n]
+
+
+def token_minmax(x, seq_pos, lengths=None, out=None):
+    """Per-token (min, max) over features for tokens t < lengths[b]; padded slots untouched."""
+    lib = _hip.load()
+    _hip.require_device(x, lengths)
+    _check_f32(x)
+    if lengths is not None and lengths.dtype != torch.int64:
+        lengths = lengths.to(torch.int64)
+    view = token_view(x, seq_pos, None if lengths is None else lengths.numel())
+    n = view.batch * view.tokens
+    tmin, tmax = out if out is not None else _scratch(x.device, n)
+    _hip.check(lib.osq_token_minmax(_hip.ptr(x), ctypes.byref(view), _hip.ptr(lengths), _hip.ptr(tmin), _hip.ptr(tmax),
+                                    _hip.stream_ptr(x.device)), "token_minmax")
+    return tmin, tmax, view.batch, view.tokens, lengths
+
+
+def token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, percentile, rule, cnt, min_val, max_val,
+                         quant_min, quant_max, symmetric, sink=None, cur=None):
+    """Percentile pruning / plain extrema over valid tokens + running statistic (+ qparams): ONE launch."""
+    lib = _hip.load()
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    _hip.check(lib.osq_token_range_finalize(_hip.ptr(tmin), _hip.ptr(tmax), batch, tokens, _hip.ptr(lengths),
+                                            int(bool(prune)), float(percentile if prune else 1.0), rule, int(cnt),
+                                            _hip.ptr(min_val), _hip.ptr(max_val), _hip.ptr(cur), int(quant_min),
+                                            int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
+                                            _hip.stream_ptr(tmin.device)), "token_range_finalize")
+
+
+def observer_update(cur_min, cur_max, rule, cnt, min_val, max_val):
+    lib = _hip.load()
+    _hip.require_device(cur_min, cur_max, min_val, max_val)
+    _check_f32(cur_min, cur_max, min_val, max_val)
+    _hip.check(lib.osq_observer_update(_hip.ptr(cur_min), _hip.ptr(cur_max), cur_min.numel(), rule, int(cnt),
+                                       _hip.ptr(min_val), _hip.ptr(max_val), _hip.stream_ptr(min_val.device)),
+               "observer_update")
+
+
+# ---------------------------------------------------------------------------------------
+# gamma migration
+# ---------------------------------------------------------------------------------------
+
+def gamma_fold_(weight, gamma):
+    """In place W[:, j] *= gamma[j] (gamma_migration.py:70-71)."""
+    lib = _hip.load()
+    _hip.require_device(weight, gamma)
+    _check_f32(weight, gamma)
+    if not weight.is_contiguous():
+        raise ValueError("gamma_fold_: weight must be contiguous")
+    cols = weight.shape[-1]
+    if gamma.numel() != cols:
+        raise ValueError("gamma_fold_: gamma must have one entry per input feature")
+    _hip.check(lib.osq_gamma_fold(_hip.ptr(weight), _hip.ptr(gamma.contiguous()), weight.numel() // cols, cols,
+                                  _hip.stream_ptr(weight.device)), "gamma_fold")
+    return weight
+
+
+def gamma_split_bias(beta, gamma):
+    lib = _hip.load()
+    _hip.require_device(beta, gamma)
+    _check_f32(beta, gamma)
+    out = torch.empty_like(beta, memory_format=torch.contiguous_format)
+    _hip.check(lib.osq_gamma_split_bias(_hip.ptr(beta.contiguous()), _hip.ptr(gamma.contiguous()), _hip.ptr(out),
+                                        beta.numel(), _hip.stream_ptr(beta.device)), "gamma_split_bias")
+    return out
+
+
+def gamma_residual(inp, hidden, gamma=None):
+    """input * gamma + hidden (util_layernorm.py:49-52), inference path (no autograd)."""
+    lib = _hip.load()
+    _hip.require_device(inp, hidden, gamma)
+    _check_f32(inp, hidden, gamma)
+    a, h = inp.contiguous(), hidden.contiguous()
+    cols = a.shape[-1]
+    out = torch.empty_like(a)
+    _hip.check(lib.osq_gamma_residual(_hip.ptr(a), _hip.ptr(h), _hip.ptr(gamma), _hip.ptr(out), a.numel() // cols, cols,
+                                      _hip.stream_ptr(a.device)), "gamma_residual")
+    return out

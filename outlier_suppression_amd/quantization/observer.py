@@ -1,0 +1,168 @@
+"""Observers with the reference's class names and buffers, computed by gfx950 HIP kernels.
+
+Reference: quant_transformer/quantization/observer.py.  State kept exactly as there:
+buffers ``min_val`` / ``max_val`` (fp32, start at +inf / -inf), Python attributes
+``cnt``, ``percentile``, ``name``; state-dict keys ``observer.min_val`` /
+``observer.max_val``.
+
+Differences in mechanism, not in results:
+  * padding is never removed with ``cat`` (observer.py:72-84); kernels skip padded tokens;
+  * per-token extrema, the two quantiles, the thresholded extrema, the running average
+    and calculate_qparams run on the device without a host sync;
+  * a whole observation is 1 launch (flat / per-channel) or 2 launches (masked).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import UPDATE_AVERAGE, UPDATE_RUNNING, QParamSink
+
+
+def _quant_range(bit, symmetric):
+    if symmetric:
+        return -(1 << (bit - 1)), (1 << (bit - 1)) - 1
+    return 0, (1 << bit) - 1
+
+
+class ObserverBase(nn.Module):
+    """observer.py:24-119."""
+
+    update_rule = UPDATE_RUNNING
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__()
+        self.bit, self.symmetric, self.ch_axis = bit, symmetric, ch_axis
+        self.eps = torch.tensor(1e-8, dtype=torch.float32)
+        self.quant_min, self.quant_max = _quant_range(bit, symmetric)
+        self.register_buffer("min_val", torch.tensor(float("inf")))
+        self.register_buffer("max_val", torch.tensor(float("-inf")))
+        self._capture = None   # sharded calibration: 2-float device slot that receives this batch's (min, max)
+
+    # -- attributes the solver code sets (state.py:65-69, token_wise_clipping.py:16-17)
+    def set_name(self, name):
+        self.name = name
+
+    def set_batch(self, batch):
+        self.batch = batch
+
+    def set_percentile(self, percentile):
+        self.percentile = percentile
+
+    @torch.jit.export
+    def calculate_qparams(self, min_val, max_val):
+        """observer.py:101-119 on the device: (scale fp32, zero_point int32 if symmetric else fp32)."""
+        return ops.calculate_qparams(min_val, max_val, self.quant_min, self.quant_max, self.symmetric)
+
+    # -- helpers -----------------------------------------------------------------------
+    def _home(self, device, channels=None):
+        """Statistic buffers on x's device (the reference mixes a CPU 0-dim buffer with CUDA
+        values freely); per-channel observers grow from the scalar start value to [C]."""
+        if self.min_val.device != device:
+            self.min_val = self.min_val.to(device)
+            self.max_val = self.max_val.to(device)
+        if channels is not None and self.min_val.numel() != channels:
+            self.min_val = self.min_val.reshape(-1)[:1].expand(channels).contiguous()
+            self.max_val = self.max_val.reshape(-1)[:1].expand(channels).contiguous()
+
+    def _counter(self):
+        return getattr(self, "cnt", 0)
+
+    def _bump(self):
+        if hasattr(self, "cnt") and self._capture is None:
+            self.cnt += 1
+
+    def _observe_tokens(self, x, lengths, seq_pos, prune, sink):
+        tmin, tmax, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths)
+        self._home(x.device)
+        rule, cur = self.update_rule, None
+        if self._capture is not None:      # record this batch only; calibration.replay() applies the rule later
+            rule, cur, sink = ops.UPDATE_NONE, self._capture, None
+        ops.token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, getattr(self, "percentile", 1.0),
+                                 rule, self._counter(), self.min_val, self.max_val,
+                                 self.quant_min, self.quant_max, self.symmetric, sink, cur)
+
+    def _observe_flat(self, x, sink):
+        self._home(x.device)
+        rule, cur = self.update_rule, None
+        if self._capture is not None:
+            rule, cur, sink = ops.UPDATE_NONE, self._capture, None
+        ops.observe_flat(x, rule, self._counter(), self.min_val, self.max_val,
+                         self.quant_min, self.quant_max, self.symmetric, sink, cur)
+
+    def _observe_channels(self, x, sink):
+        self._home(x.device, x.shape[self.ch_axis])
+        ops.observe_channels(x, self.ch_axis, self.update_rule, self._counter(), self.min_val, self.max_val,
+                             self.quant_min, self.quant_max, self.symmetric, sink)
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        """Observe ``x`` and, if ``sink`` is given, also write calculate_qparams(min_val, max_val)
+        into it in the same launch (what fake_quant.py:108-116 does in three steps)."""
+        raise NotImplementedError
+
+    def forward(self, x_orig, observation_mask=None, seq_pos=-1):
+        if x_orig.numel() == 0:
+            return x_orig
+        self.observe_into(x_orig.detach(), observation_mask, seq_pos, None)
+        return x_orig
+
+
+class MinMaxObserver(ObserverBase):
+    """observer.py:122-145: running min / max over the calibration set; per-tensor or per-channel."""
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        if observation_mask is not None:
+            assert self.ch_axis == -1
+            self._observe_tokens(x, observation_mask, seq_pos, False, sink)
+        elif self.ch_axis == -1:
+            self._observe_flat(x, sink)
+        else:
+            self._observe_channels(x, sink)
+
+
+class AvgMinMaxObserver(ObserverBase):
+    """observer.py:176-203: average of the per-batch min / max."""
+
+    update_rule = UPDATE_AVERAGE
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.cnt = 0
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        assert self.ch_axis == -1
+        if observation_mask is not None:
+            self._observe_tokens(x, observation_mask, seq_pos, False, sink)
+        else:
+            self._observe_flat(x, sink)
+        self._bump()
+
+
+class AvgPruneMinMaxObserver(ObserverBase):
+    """observer.py:206-237: token-wise clipping -- per-token extrema, percentile over tokens,
+    clip range = extrema of the tokens inside the percentile; averaged over batches."""
+
+    update_rule = UPDATE_AVERAGE
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.cnt = 0
+
+    def _prunes(self):
+        # observer.py:62-63: attention probabilities are never pruned; the name is set by
+        # state.set_observer_name and must be present, as in the reference
+        if "attention_probs" in self.name:
+            return False
+        if getattr(self, "percentile", None) is None:
+            raise AttributeError("AvgPruneMinMaxObserver: call set_percentile() before observing "
+                                 "(token_wise_clipping.set_ratio does)")
+        return True
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        assert self.ch_axis == -1
+        if observation_mask is not None:
+            self._observe_tokens(x, observation_mask, seq_pos, self._prunes(), sink)
+        elif seq_pos != -1:
+            self._observe_tokens(x, None, seq_pos, self._prunes(), sink)
+        else:
+            self._observe_flat(x, sink)   # pooler / classifier inputs: observer.py:220-226
+        self._bump()

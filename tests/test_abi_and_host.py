@@ -1,0 +1,194 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/osq_hip.h declares;
+host-side logic (factory, flags, name-substring togglers, state-dict keys, fail-loudly rules)."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "osq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(osq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from outlier_suppression_amd import _hip
+    lib = _hip.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/osq_hip.h but not exported"
+        assert name in _hip.SIGNATURES, f"{name} has no ctypes signature"
+    assert sorted(_hip.SIGNATURES) == declared
+    assert lib.osq_abi_version() >= 1
+    assert lib.osq_workspace_bytes() >= 4096
+
+
+def test_argument_validation_without_gpu():
+    """Invalid arguments are rejected before any launch, so this is safe on a CPU box."""
+    from outlier_suppression_amd import _hip
+    lib = _hip.load()
+    rc = lib.osq_fake_quant_per_tensor(None, None, None, 16, None, None, 0, 0, 1.0, 0, 63, None)
+    assert rc == -1 and b"null" in lib.osq_last_error()
+    rc = lib.osq_calculate_qparams(None, None, 4, 0, 63, 0, None, None, 0, None)
+    assert rc == -1
+    rc = lib.osq_token_range_finalize(ctypes.c_void_p(16), ctypes.c_void_p(16), 2, 2, None, 1, 1.5, 0, 0, None, None, None,
+                                      0, 63, 0, None, None, 0, None)
+    assert rc == -1 and b"percentile" in lib.osq_last_error()
+
+
+def test_no_cpu_fallback():
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import Quantizer
+    cfg = NS(quantizer="FixedFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    q = Quantizer(None, cfg)
+    x = torch.randn(2, 4, 8)
+    assert q(x) is x                      # both switches off: identity, no compute
+    q.enable_observer()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        q(x)
+    q.disable_observer()
+    q.enable_fake_quant()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        q(x)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.calculate_qparams(torch.zeros(3), torch.ones(3), 0, 63, False)
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import outlier_suppression_amd.quantization, "
+            "outlier_suppression_amd.ops, outlier_suppression_amd.gamma_migration, outlier_suppression_amd.calibration; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "outlier_suppression_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_factory_and_state_dict_keys(golden):
+    from outlier_suppression_amd.quantization import Quantizer
+    from outlier_suppression_amd.quantization.fake_quant import (FixedFakeQuantize, LSQFakeQuantize,
+                                                                 LSQPlusFakeQuantize, QuantizeBase)
+    from outlier_suppression_amd.quantization.quantized_module import (QLinear, QEmbedding, QConv2d, ObserverDict,
+                                                                       FakeQuantizeDict)
+    g = golden("modules")
+    for k in range(int(g["n"])):
+        quantizer, observer, bit, sym, ch_axis, kind, sdt, zdt = (str(v) for v in g[f"c{k}_info"])
+        cfg = NS(quantizer=quantizer, observer=observer, bit=int(bit), symmetric=bool(int(sym)), ch_axis=int(ch_axis))
+        q = Quantizer(None, cfg)
+        assert isinstance(q, QuantizeBase) and type(q).__name__ == quantizer and type(q.observer).__name__ == observer
+        assert sorted(q.state_dict().keys()) == [str(s) for s in g[f"c{k}_sdkeys"]]
+        assert str(q.scale.dtype) == sdt and str(q.zero_point.dtype) == zdt
+        assert (q.observer_enabled, q.fake_quant_enabled) == (0, 0)
+    wcfg = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    lin = torch.nn.Linear(8, 5)
+    ql = Quantizer(lin, wcfg)
+    assert isinstance(ql, QLinear) and torch.equal(ql.weight, lin.weight) and ql.weight is not lin.weight
+    assert isinstance(ql.weight_fake_quant, FixedFakeQuantize) and (ql.quant_min if hasattr(ql, "quant_min") else True)
+    assert ql.weight_fake_quant.quant_min == -32 and ql.weight_fake_quant.quant_max == 31
+    emb = Quantizer(torch.nn.Embedding(11, 4, padding_idx=0), wcfg)
+    assert isinstance(emb, QEmbedding) and emb.padding_idx == 0
+    conv = Quantizer(torch.nn.Conv2d(3, 4, 3, padding=1), wcfg)
+    assert isinstance(conv, QConv2d)
+    ln = torch.nn.LayerNorm(4)
+    assert Quantizer(ln, wcfg) is ln
+    assert {"MinMaxObserver", "AvgMinMaxObserver", "AvgPruneMinMaxObserver"} <= set(ObserverDict)
+    assert set(FakeQuantizeDict) == {"FixedFakeQuantize", "LSQFakeQuantize", "LSQPlusFakeQuantize"}
+    assert issubclass(LSQPlusFakeQuantize, QuantizeBase) and issubclass(LSQFakeQuantize, QuantizeBase)
+    # with both switches off a Q-operator is the plain operator
+    x = torch.randn(2, 8)
+    assert torch.equal(ql(x), lin(x))
+
+
+class _Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from outlier_suppression_amd.quantization import Quantizer
+        a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+        w = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+        self.dense = Quantizer(torch.nn.Linear(4, 4), w)
+        self.attention_probs_post_act_fake_quantize = Quantizer(None, a)
+        self.out_post_act_fake_quantize = Quantizer(None, NS(**{**vars(a), "quantizer": "FixedFakeQuantize"}))
+
+
+def _flags(m):
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    return {n: (q.observer_enabled, q.fake_quant_enabled) for n, q in m.named_modules() if isinstance(q, QuantizeBase)}
+
+
+def test_state_togglers_follow_reference_rules():
+    from outlier_suppression_amd.quantization import (enable_calibration_woquantization, enable_calibration_quantization,
+                                                      enable_quantization, disable_all)
+    from outlier_suppression_amd.quantization.state import set_observer_name
+    m = _Toy()
+    W, A1, A2 = "dense.weight_fake_quant", "attention_probs_post_act_fake_quantize", "out_post_act_fake_quantize"
+    enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
+    assert _flags(m) == {W: (1, 0), A1: (0, 0), A2: (0, 0)}
+    enable_calibration_woquantization(m, quantizer_type="act_fake_quant")
+    assert _flags(m) == {W: (0, 0), A1: (1, 0), A2: (1, 0)}
+    enable_calibration_quantization(m, quantizer_type="fake_quant")      # learnable ones keep the observer off
+    assert _flags(m) == {W: (1, 1), A1: (0, 1), A2: (1, 1)}
+    enable_quantization(m, except_quantizer=[A2])
+    assert _flags(m) == {W: (0, 1), A1: (0, 1), A2: (0, 0)}
+    disable_all(m)
+    assert set(_flags(m).values()) == {(0, 0)}
+    set_observer_name(m)
+    assert m.attention_probs_post_act_fake_quantize.observer.name == A1 + ".observer"
+    assert m.dense.weight_fake_quant.observer.name == W + ".observer"
+
+
+def test_state_dict_round_trip_with_grown_buffers():
+    """fake_quant.py:66-97: per-channel scale / zero_point change size after the first observation;
+    loading must accept the stored shapes."""
+    from outlier_suppression_amd.quantization import Quantizer
+    w = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    src = Quantizer(torch.nn.Linear(4, 6), w)
+    fq = src.weight_fake_quant
+    fq.scale = torch.rand(6)
+    fq.zero_point = torch.zeros(6, dtype=torch.int32)
+    fq.observer.min_val = -torch.rand(6)
+    fq.observer.max_val = torch.rand(6)
+    sd = src.state_dict()
+    dst = Quantizer(torch.nn.Linear(4, 6), w)
+    dst.load_state_dict(sd)
+    assert torch.equal(dst.weight_fake_quant.scale, fq.scale)
+    assert torch.equal(dst.weight_fake_quant.observer.max_val, fq.observer.max_val)
+    a = NS(quantizer="LSQPlusFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    q1, q2 = Quantizer(None, a), Quantizer(None, a)
+    q1.scale.data.fill_(0.37)
+    q1.zero_point.data.fill_(12.0)
+    q2.load_state_dict(q1.state_dict())
+    assert q2.scale.item() == pytest.approx(0.37) and q2.zero_point.item() == 12.0
+
+
+def test_token_view_matches_reference_permutation():
+    """ops.token_view describes the tensor observer.py:72-80 would build by permute+reshape."""
+    from outlier_suppression_amd import ops
+    from oracle.observer_oracle import _tokens_first
+    rng = np.random.default_rng(0)
+    cases = [((3, 5, 8), 1), ((3, 8, 5), 2), ((2, 3, 5, 4), 2), ((2, 3, 4, 5), 3), ((2, 5, 3, 4), 1)]
+    for shape, sp in cases:
+        x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        for xv in (x, x.transpose(-1, -2).contiguous().transpose(-1, -2)):
+            v = ops.token_view(xv, sp)
+            want = _tokens_first(xv.numpy(), sp)
+            flat = xv.contiguous().view(-1) if xv.is_contiguous() else None
+            base = xv.numpy()
+            storage = np.lib.stride_tricks.as_strided(base, shape=(v.batch, v.tokens, v.feat_outer, v.feat_inner),
+                                                      strides=[4 * s for s in (v.stride_batch, v.stride_token,
+                                                                               v.stride_outer, v.stride_inner)])
+            assert np.array_equal(storage.reshape(v.batch, v.tokens, -1), want)
+    # BART quirk: [B*h, T, S] with a length-B mask only covers the first B rows (observer.py:82)
+    v = ops.token_view(torch.zeros(8, 5, 5), 1, n_lengths=2)
+    assert v.batch == 2

@@ -184,3 +184,31 @@ def test_gamma_migration_pieces(golden, eq32):
     assert eq32(GM.split_bias(g["beta"], g["gamma"]), g["split_bias"])
     assert eq32(GM.gamma_residual(g["x"], g["hidden"]), g["res_before"])
     assert eq32(GM.gamma_residual(g["x"], g["hidden"], g["gamma"]), g["res_after"])
+
+
+def test_torch_eager_restatement_matches_golden(golden, eq32):
+    """oracle/torch_eager.py (the op chains the reference executes; bench.py's cpu_baseline) on the same vectors."""
+    import torch
+    from oracle import torch_eager as TE
+    g = golden("fake_quant")
+    for k in range(int(g["n_per_tensor"])):
+        scale, zp, qmin, qmax = g[f"pt{k}_meta"][:4]
+        y = TE.fake_quant_chain(torch.from_numpy(g[f"pt{k}_x"]), float(scale), int(zp), int(qmin), int(qmax))
+        assert eq32(y.numpy(), g[f"pt{k}_y"])
+    g = golden("observers")
+    checked = 0
+    for k in range(int(g["n"])):
+        obs_name, lay, seq_pos, masked, name, p = (str(v) for v in g[f"c{k}_info"])
+        if obs_name != "AvgPruneMinMaxObserver" or lay != "bth" or not int(masked) or not p:
+            continue
+        state = [torch.tensor(float("inf")), torch.tensor(float("-inf")), 0]
+        for it in range(g[f"c{k}_x"].shape[0]):
+            x = torch.from_numpy(g[f"c{k}_x"][it])
+            y, scale, zp = TE.observe_prune_then_quantize(x, torch.from_numpy(g[f"c{k}_len"][it]), float(p), state)
+            assert eq32(state[0].numpy(), g[f"c{k}_min"][it]) and eq32(state[1].numpy(), g[f"c{k}_max"][it])
+        assert eq32(scale.numpy(), g[f"c{k}_scale"]) and eq32(zp.numpy(), g[f"c{k}_zp"])
+        _, y_np = FQ.fake_quantize_learnableplus_per_tensor(x.numpy(), scale.numpy(), zp.numpy(), 0, 63,
+                                                            FQ.lsqplus_grad_factor(x.numel(), 63))
+        assert eq32(y.numpy(), y_np)
+        checked += 1
+    assert checked >= 5

@@ -239,12 +239,15 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0;
         for (int k = 0; k < kThreads / OSQ_WAVE; ++k) { a += sh[0][k]; b += sh[1][k]; }
-        partials[2 * blockIdx.x] = a;
-        partials[2 * blockIdx.x + 1] = b;
+        publish_f64(&partials[2 * blockIdx.x], a);
+        publish_f64(&partials[2 * blockIdx.x + 1], b);
     }
     if (grid_last_block(counter, gridDim.x)) {
         double a = 0.0, b = 0.0;
-        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) { a += partials[2 * k]; b += partials[2 * k + 1]; }
+        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) {
+            a += consume_f64(&partials[2 * k]);
+            b += consume_f64(&partials[2 * k + 1]);
+        }
         // fixed combination order: lane-strided partial sums, then wave tree, then waves in order
         a = wave_sum(a);
         b = wave_sum(b);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
             const double gs = (mode == OSQ_PARAM_FIXED) ? 1.0 : static_cast<double>(g);
             if (dscale) dscale[0] = static_cast<float>(sa * gs);
             if (dzp) dzp[0] = static_cast<float>(sb * ((mode == OSQ_PARAM_LSQPLUS) ? static_cast<double>(g) : 1.0));
-            *counter = 0u;
+            grid_reset(counter, gridDim.x);
         }
     }
 }

@@ -121,23 +121,23 @@ __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc.add(xt[threadIdx.x]);
     acc = block_reduce(acc);
     if (threadIdx.x == 0) {
-        partials[3 * blockIdx.x] = acc.mn;
-        partials[3 * blockIdx.x + 1] = acc.mx;
-        partials[3 * blockIdx.x + 2] = acc.bad ? 1.0f : 0.0f;
+        publish_f32(&partials[3 * blockIdx.x], acc.mn);
+        publish_f32(&partials[3 * blockIdx.x + 1], acc.mx);
+        publish_f32(&partials[3 * blockIdx.x + 2], acc.bad ? 1.0f : 0.0f);
     }
     if (grid_last_block(counter, gridDim.x)) {
         MinMax t;
         t.init();
         for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) {
-            t.mn = fminf(t.mn, partials[3 * k]);
-            t.mx = fmaxf(t.mx, partials[3 * k + 1]);
-            t.bad |= partials[3 * k + 2] != 0.0f;
+            t.mn = fminf(t.mn, consume_f32(&partials[3 * k]));
+            t.mx = fmaxf(t.mx, consume_f32(&partials[3 * k + 1]));
+            t.bad |= consume_f32(&partials[3 * k + 2]) != 0.0f;
         }
         t = block_reduce(t);
         if (threadIdx.x == 0) {
             t.poison();
             finish_entry(fin, 0, t.mn, t.mx);
-            *counter = 0u;
+            grid_reset(counter, gridDim.x);
         }
     }
 }
@@ -187,56 +187,76 @@ __global__ __launch_bounds__(kThreads) void observe_channels_kernel(const float*
 
 // ---------------------------------------------------------------- per-token min/max (K6/K7)
 
+constexpr int kTokPerWave = 4;                                  // tokens a wave keeps in flight together
+constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;      // consecutive tokens of ONE sample per workgroup
+
 // Fast path: feat_inner contiguous (stride 1), everything 16-byte aligned.
-// One wave per token.  The wave is split into 64/G lane groups of G lanes; group g
-// walks feature segments g, g + 64/G, ...; inside a segment a lane reads 16 bytes at
-// a time.  G = 64 when a segment has >= 64 float4 (e.g. [B,T,768]); G = 16 for
-// head_dim 64 ([B,h,T,64] and its views), so that no lane idles on short segments.
+// Workgroup = 16 consecutive tokens of one sample (blockIdx.y = sample); a workgroup that
+// starts beyond the sample's valid length exits at once, so padding is never read.
+// Each wave owns 4 tokens and issues all their 16-byte loads before reducing any.
+// Lane layout inside a token: the wave is split into 64/G groups of G lanes; group g walks
+// feature segments g, g + 64/G, ...; G = 64 for one long segment ([B,T,768]), G = 16 for
+// head_dim 64 ([B,h,T,64] and its views) so that no lane idles on short segments.
+template <bool SINGLE_SEGMENT>
 __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float* __restrict__ x, osq_token_view v,
                                                                     const int64_t* __restrict__ lengths,
                                                                     float* __restrict__ tok_min,
                                                                     float* __restrict__ tok_max, int lgG, int inner4) {
-    const int lane = threadIdx.x & (OSQ_WAVE - 1);
-    const int G = 1 << lgG;
-    const int grp = lane >> lgG, li = lane & (G - 1), ngrp = OSQ_WAVE >> lgG;
-    const int64_t ntok = v.batch * v.tokens;
-    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
-    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-    for (int64_t tok = wave0; tok < ntok; tok += nwaves) {
-        const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
-        if (lengths && t >= lengths[b]) continue;   // padded token: never read
-        const float* base = x + b * v.stride_batch + t * v.stride_token;
-        MinMax acc;
-        acc.init();
-        if (v.feat_outer == 1) {
-            const float4* p = reinterpret_cast<const float4*>(base);
-            int j = lane;
-            for (; j + 3 * OSQ_WAVE < inner4; j += 4 * OSQ_WAVE) {
-                const float4 a = p[j], bb = p[j + OSQ_WAVE], c = p[j + 2 * OSQ_WAVE], d = p[j + 3 * OSQ_WAVE];
-                acc.add4(a); acc.add4(bb); acc.add4(c); acc.add4(d);
+    const int64_t b = blockIdx.y;
+    int64_t len = v.tokens;
+    if (lengths) {
+        const int64_t l = lengths[b];
+        len = l < len ? l : len;
+    }
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kTokPerBlock + w * kTokPerWave;
+    if (t0 >= len) return;
+    const int ntok = (len - t0) < kTokPerWave ? static_cast<int>(len - t0) : kTokPerWave;
+    const float* base = x + b * v.stride_batch + t0 * v.stride_token;
+    MinMax acc[kTokPerWave];
+#pragma unroll
+    for (int k = 0; k < kTokPerWave; ++k) acc[k].init();
+    if (SINGLE_SEGMENT) {
+        for (int j = lane; j < inner4; j += OSQ_WAVE) {
+            float4 val[kTokPerWave];
+#pragma unroll
+            for (int k = 0; k < kTokPerWave; ++k) {
+                const int kk = k < ntok ? k : 0;                 // short tail: re-read token 0, result unused
+                val[k] = reinterpret_cast<const float4*>(base + kk * v.stride_token)[j];
             }
-            for (; j < inner4; j += OSQ_WAVE) acc.add4(p[j]);
-        } else {
-            int64_t o = grp;
-            for (; o + ngrp < v.feat_outer; o += 2 * ngrp) {      // two segments in flight
-                const float4* p0 = reinterpret_cast<const float4*>(base + o * v.stride_outer);
-                const float4* p1 = reinterpret_cast<const float4*>(base + (o + ngrp) * v.stride_outer);
-                for (int j = li; j < inner4; j += G) {
-                    const float4 a = p0[j], bb = p1[j];
-                    acc.add4(a); acc.add4(bb);
+#pragma unroll
+            for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
+        }
+    } else {
+        const int G = 1 << lgG;
+        const int grp = lane >> lgG, li = lane & (G - 1), ngrp = OSQ_WAVE >> lgG;
+        for (int64_t o = grp; o < v.feat_outer; o += ngrp) {
+            const float* seg = base + o * v.stride_outer;
+            for (int j = li; j < inner4; j += G) {
+                float4 val[kTokPerWave];
+#pragma unroll
+                for (int k = 0; k < kTokPerWave; ++k) {
+                    const int kk = k < ntok ? k : 0;
+                    val[k] = reinterpret_cast<const float4*>(seg + kk * v.stride_token)[j];
                 }
-            }
-            for (; o < v.feat_outer; o += ngrp) {
-                const float4* p0 = reinterpret_cast<const float4*>(base + o * v.stride_outer);
-                for (int j = li; j < inner4; j += G) acc.add4(p0[j]);
+#pragma unroll
+                for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
             }
         }
-        acc.wave_reduce();
-        if (lane == 0) {
-            acc.poison();
-            tok_min[tok] = acc.mn;
-            tok_max[tok] = acc.mx;
-        }
+    }
+#pragma unroll
+    for (int k = 0; k < kTokPerWave; ++k) {
+        acc[k].wave_reduce();
+        acc[k].poison();
+    }
+    if (lane < ntok) {
+        float mn = acc[0].mn, mx = acc[0].mx;
+#pragma unroll
+        for (int k = 1; k < kTokPerWave; ++k)
+            if (lane == k) { mn = acc[k].mn; mx = acc[k].mx; }
+        const int64_t slot = b * v.tokens + t0 + lane;
+        tok_min[slot] = mn;
+        tok_max[slot] = mx;
     }
 }
 
@@ -271,164 +291,269 @@ __global__ __launch_bounds__(kThreads) void token_minmax_generic_kernel(const fl
 
 // ---------------------------------------------------------------- token range finaliser (K7b + K8 + K9)
 
-// Single workgroup.  Valid slots: b*T + t with t < lengths[b] (all if lengths == NULL).
+// Single workgroup of 1024 threads.  Valid slots: b*T + t with t < lengths[b] (all if
+// lengths == NULL).  Up to 32 slots per thread are loaded ONCE into registers (covers
+// batch*tokens <= 32768, e.g. the [256,128,768] benchmark tensor); larger inputs re-read
+// the L2-resident arrays in every pass.
 //
 // prune: torch.quantile(|token_max|, p) needs the order statistics floor(rank) and
-// ceil(rank), rank = fp32(p) * fp32(N-1).  They are found by a 4-pass, 8-bit radix
-// select on the fp32 bit patterns of the absolute values (non-negative floats order
-// like their bit patterns); the value at ceil(rank) is the same value when duplicates
-// cover it and otherwise the smallest value above.  Interpolation is torch's lerp
+// ceil(rank), rank = fp32(p) * fp32(N-1).  Selection works on the fp32 bit patterns of the
+// absolute values (non-negative floats order like their bit patterns) with a range
+// histogram: 2048 bins spread linearly (power-of-two bin width) over the CURRENT key range
+// [lo, lo + width); the bin holding the wanted rank becomes the next range.  Starting from
+// the observed [min key, max key] each level strips 11 bits, so three levels give the exact
+// key; bins follow the data range, so the per-bin LDS atomics do not pile up on one exponent
+// bin the way a digit-wise radix pass would.  The value at ceil(rank) is the same value when
+// duplicates cover it and otherwise the smallest key above.  Interpolation is torch's lerp
 // (one fused multiply-add per branch, pinned in tests/test_oracle_pinning.py).
-struct Select {
-    unsigned int prefix;     // bits fixed so far (high to low)
-    unsigned int below;      // how many keys are smaller than every key matching the prefix
-};
+constexpr int kSelBins = 2048;
+constexpr int kSelBits = 11;
+constexpr int kCacheSlots = 32;
 
-__device__ __forceinline__ bool slot_valid(int64_t slot, int64_t T, const int64_t* lengths, int64_t* b_cache,
-                                           int64_t* len_cache) {
-    if (!lengths) return true;
-    const int64_t b = slot / T, t = slot - b * T;
-    if (b != *b_cache) { *b_cache = b; *len_cache = lengths[b]; }
-    return t < *len_cache;
-}
+struct SelState {
+    unsigned int lo;       // first key of the current range; the selected key once done
+    unsigned int width;    // number of key values in the range (0 once done: nothing matches any more)
+    unsigned int rank;     // wanted rank among the keys inside the range
+    unsigned int shift;    // log2(bin width) of the level being histogrammed
+    unsigned int le;       // keys below the range so far; once done: keys <= the selected key
+    unsigned int done;
+};
 
 __device__ __forceinline__ unsigned int abs_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
+__device__ __forceinline__ unsigned int level_shift(unsigned int width) {
+    const unsigned int bits = width <= 1u ? 0u : 32u - __builtin_clz(width - 1u);
+    return bits > kSelBits ? bits - kSelBits : 0u;
+}
+
+template <bool CACHED>
 __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const float* __restrict__ tok_min,
                                                                        const float* __restrict__ tok_max, int64_t B,
                                                                        int64_t T, const int64_t* __restrict__ lengths,
                                                                        int prune, float q, Finish fin) {
-    __shared__ unsigned int hist[2][256];
-    __shared__ Select sel[2];
-    __shared__ unsigned int s_count[2];        // keys <= selected value
-    __shared__ unsigned int s_next[2];         // smallest key above the selected value
-    __shared__ long long s_n;
-    __shared__ int s_nan;
-    __shared__ float s_res[2];
+    __shared__ unsigned int hist[2][kSelBins];
+    __shared__ SelState sel[2];
+    __shared__ unsigned int s_n, s_bad, s_next[2], s_kmin[2], s_kmax[2], s_omin, s_omax;
+    __shared__ unsigned int s_wtot[2][kFinalThreads / OSQ_WAVE];
 
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    constexpr int kWaves = kFinalThreads / OSQ_WAVE;
     const int64_t slots = B * T;
-    const int tid = threadIdx.x;
 
-    // ---- pass 0: N (valid tokens), NaN check, plain extrema
-    MinMax plain;
-    plain.init();
-    long long my_n = 0;
-    {
-        int64_t bc = -1, lc = 0;
-        for (int64_t s = tid; s < slots; s += kFinalThreads) {
-            if (!slot_valid(s, T, lengths, &bc, &lc)) continue;
-            ++my_n;
-            const float a = tok_min[s], b = tok_max[s];
-            plain.mn = fminf(plain.mn, a);
-            plain.mx = fmaxf(plain.mx, b);
-            plain.bad |= (a != a) || (b != b);
+    // ---- register cache (CACHED): slot = tid + i*1024
+    float r_mn[kCacheSlots], r_mx[kCacheSlots];
+    unsigned int vmask = 0u;
+    if (CACHED) {
+        // every load is unconditional (index clamped) and independent, so all of them are in
+        // flight together; validity is decided afterwards from the lengths
+        const unsigned int Tu = static_cast<unsigned int>(T), last = static_cast<unsigned int>(slots) - 1u;
+        {
+            int len_i[kCacheSlots];
+#pragma unroll
+            for (int i = 0; i < kCacheSlots; ++i) {
+                const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
+                const unsigned int sc = s < last ? s : last;
+                int64_t l = T;
+                if (lengths) l = lengths[sc / Tu];
+                len_i[i] = l > T ? static_cast<int>(T) : (l < 0 ? 0 : static_cast<int>(l));
+            }
+#pragma unroll
+            for (int i = 0; i < kCacheSlots; ++i) {
+                const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
+                const unsigned int sc = s < last ? s : last;
+                const unsigned int t = sc - (sc / Tu) * Tu;
+                if (s <= last && static_cast<int>(t) < len_i[i]) vmask |= (1u << i);
+            }
+        }
+        asm volatile("" : "+v"(vmask));   // lengths are dead before the value loads start
+#pragma unroll
+        for (int i = 0; i < kCacheSlots; ++i) {
+            const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
+            const unsigned int sc = s < last ? s : last;
+            r_mn[i] = tok_min[sc];
+            r_mx[i] = tok_max[sc];
         }
     }
-    if (tid == 0) { s_n = 0; s_nan = 0; }
-    __syncthreads();
-    {
-        long long wn = my_n;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wn += __shfl_xor(wn, o, OSQ_WAVE);
-        if ((tid & (OSQ_WAVE - 1)) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&s_n), static_cast<unsigned long long>(wn));
+// run `body` for every valid slot with vmn / vmx bound to its token minimum / maximum
+#define OSQ_FOR_EACH_VALID(...)                                                                    \
+    if (CACHED) {                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < kCacheSlots; ++i_) {                               \
+            if ((vmask >> i_) & 1u) {                                                              \
+                float vmn = r_mn[i_], vmx = r_mx[i_];                                              \
+                /* opaque copies: values derived from them are recomputed per pass, not kept live */ \
+                asm volatile("" : "+v"(vmn), "+v"(vmx));                                           \
+                __VA_ARGS__                                                                        \
+            }                                                                                      \
+        }                                                                                          \
+    } else {                                                                                       \
+        for (int64_t b_ = wv; b_ < B; b_ += kWaves) {                                              \
+            int64_t len_ = T;                                                                      \
+            if (lengths) { const int64_t l_ = lengths[b_]; len_ = l_ < len_ ? l_ : len_; }         \
+            const float* pmn_ = tok_min + b_ * T;                                                  \
+            const float* pmx_ = tok_max + b_ * T;                                                  \
+            for (int64_t t_ = lane; t_ < len_; t_ += OSQ_WAVE) {                                   \
+                const float vmn = pmn_[t_], vmx = pmx_[t_];                                        \
+                __VA_ARGS__                                                                        \
+            }                                                                                      \
+        }                                                                                          \
     }
-    plain = block_reduce(plain);
-    if (tid == 0) { s_nan = plain.bad; s_res[0] = plain.mn; s_res[1] = plain.mx; }
-    __syncthreads();
-    const long long N = s_n;
-    float cur_min = s_res[0], cur_max = s_res[1];
 
-    if (N > 0 && prune && !s_nan) {
-        const float rank = q * static_cast<float>(N - 1);
+    if (tid == 0) {
+        s_n = 0u; s_bad = 0u; s_omin = 0xffffffffu; s_omax = 0u;
+        s_kmin[0] = s_kmin[1] = 0xffffffffu;
+        s_kmax[0] = s_kmax[1] = 0u;
+        s_next[0] = s_next[1] = 0xffffffffu;
+    }
+    __syncthreads();
+
+    // ---- pass 0: N, NaN flag, plain extrema, key ranges
+    {
+        unsigned int n = 0u, kmin0 = 0xffffffffu, kmax0 = 0u, kmin1 = 0xffffffffu, kmax1 = 0u;
+        MinMax plain;
+        plain.init();
+        OSQ_FOR_EACH_VALID({
+            ++n;
+            plain.mn = fminf(plain.mn, vmn);
+            plain.mx = fmaxf(plain.mx, vmx);
+            plain.bad |= (vmn != vmn) || (vmx != vmx);
+            const unsigned int k0 = abs_key(vmx), k1 = abs_key(vmn);
+            kmin0 = min(kmin0, k0); kmax0 = max(kmax0, k0);
+            kmin1 = min(kmin1, k1); kmax1 = max(kmax1, k1);
+        })
+        plain.wave_reduce();
+        kmin0 = wave_min_u32(kmin0); kmax0 = wave_max_u32(kmax0);
+        kmin1 = wave_min_u32(kmin1); kmax1 = wave_max_u32(kmax1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(static_cast<int>(n), o, OSQ_WAVE);
+        if (lane == 0) {
+            atomicAdd(&s_n, n);
+            if (plain.bad) atomicOr(&s_bad, 1u);
+            atomicMin(&s_omin, ordered_bits(plain.mn));
+            atomicMax(&s_omax, ordered_bits(plain.mx));
+            atomicMin(&s_kmin[0], kmin0); atomicMax(&s_kmax[0], kmax0);
+            atomicMin(&s_kmin[1], kmin1); atomicMax(&s_kmax[1], kmax1);
+        }
+    }
+    __syncthreads();
+    const unsigned int N = s_n;
+    const bool bad = s_bad != 0u;
+    float cur_min = from_ordered_bits(s_omin), cur_max = from_ordered_bits(s_omax);
+
+    if (N > 0u && prune && !bad) {
+        const float rank = q * static_cast<float>(N - 1u);
         const float rlo = floorf(rank);
         const unsigned int k_lo = static_cast<unsigned int>(rlo);
         const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
         const float w = rank - rlo;
 
-        if (tid < 2) { sel[tid].prefix = 0u; sel[tid].below = 0u; }
-        // ---- 4 radix passes, both arrays at once: [0] = |token_max|, [1] = |token_min|
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int k = tid; k < 512; k += kFinalThreads) hist[k >> 8][k & 255] = 0u;
+        if (tid < 2) {
+            sel[tid].lo = s_kmin[tid];
+            sel[tid].width = s_kmax[tid] - s_kmin[tid] + 1u;
+            sel[tid].rank = k_lo;
+            sel[tid].shift = level_shift(sel[tid].width);
+            sel[tid].le = 0u;
+            sel[tid].done = 0u;
+        }
+        __syncthreads();
+        // ---- at most three range-histogram levels, both arrays at once: [0] = |token_max|, [1] = |token_min|
+        for (int level = 0; level < 3; ++level) {
+            if (sel[0].done && sel[1].done) break;          // uniform: sel is only written between barriers
+            for (int k = tid; k < 2 * kSelBins; k += kFinalThreads) (&hist[0][0])[k] = 0u;
             __syncthreads();
-            const unsigned int p0 = sel[0].prefix, p1 = sel[1].prefix;
-            int64_t bc = -1, lc = 0;
-            for (int64_t s = tid; s < slots; s += kFinalThreads) {
-                if (!slot_valid(s, T, lengths, &bc, &lc)) continue;
-                const unsigned int k0 = abs_key(tok_max[s]), k1 = abs_key(tok_min[s]);
-                if ((k0 & himask) == p0) atomicAdd(&hist[0][(k0 >> shift) & 255u], 1u);
-                if ((k1 & himask) == p1) atomicAdd(&hist[1][(k1 >> shift) & 255u], 1u);
-            }
+            const unsigned int lo0 = sel[0].lo, w0 = sel[0].width, sh0 = sel[0].shift;
+            const unsigned int lo1 = sel[1].lo, w1 = sel[1].width, sh1 = sel[1].shift;
+            OSQ_FOR_EACH_VALID({
+                const unsigned int d0 = abs_key(vmx) - lo0, d1 = abs_key(vmn) - lo1;
+                if (d0 < w0) atomicAdd(&hist[0][d0 >> sh0], 1u);
+                if (d1 < w1) atomicAdd(&hist[1][d1 >> sh1], 1u);
+            })
             __syncthreads();
-            if (tid < 2) {
-                unsigned int below = sel[tid].below;
-                unsigned int bin = 0;
-                for (; bin < 256; ++bin) {
-                    const unsigned int c = hist[tid][bin];
-                    if (below + c > k_lo) break;
-                    below += c;
+            // block-wide exclusive scan over the 2048 bins of each array (2 bins per thread),
+            // then the one thread whose bins straddle the wanted rank narrows the range
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const unsigned int h0 = hist[a][2 * tid], h1 = hist[a][2 * tid + 1];
+                const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
+                if (lane == OSQ_WAVE - 1) s_wtot[a][wv] = incl_w;
+                __syncthreads();
+                unsigned int base = 0u;
+#pragma unroll
+                for (int k = 0; k < kWaves; ++k) base += (k < wv) ? s_wtot[a][k] : 0u;
+                const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
+                const unsigned int want = sel[a].rank;
+                const bool active = !sel[a].done;
+                __syncthreads();                              // everyone has read sel[a] / s_wtot[a]
+                if (active && want >= excl && want < incl) {  // exactly one thread
+                    const bool second = want >= excl + h0;
+                    const unsigned int below = second ? excl + h0 : excl;
+                    const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
+                    const unsigned int sh = sel[a].shift, off = bin << sh;
+                    sel[a].lo += off;
+                    if (sh == 0u) {                           // bins are single keys: found
+                        sel[a].le += below + cnt;
+                        sel[a].width = 0u;
+                        sel[a].done = 1u;
+                    } else {
+                        const unsigned int rest = sel[a].width - off, cap = 1u << sh;
+                        sel[a].le += below;
+                        sel[a].rank = want - below;
+                        sel[a].width = rest < cap ? rest : cap;
+                        sel[a].shift = level_shift(sel[a].width);
+                    }
                 }
-                sel[tid].below = below;
-                sel[tid].prefix |= (bin << shift);
             }
             __syncthreads();
         }
-        // ---- neighbour above the selected key, and how many keys are <= it
-        if (tid < 2) { s_count[tid] = 0u; s_next[tid] = 0xffffffffu; }
-        __syncthreads();
-        const unsigned int v0 = sel[0].prefix, v1 = sel[1].prefix;
-        {
-            unsigned int c0 = 0, c1 = 0, n0 = 0xffffffffu, n1 = 0xffffffffu;
-            int64_t bc = -1, lc = 0;
-            for (int64_t s = tid; s < slots; s += kFinalThreads) {
-                if (!slot_valid(s, T, lengths, &bc, &lc)) continue;
-                const unsigned int k0 = abs_key(tok_max[s]), k1 = abs_key(tok_min[s]);
-                if (k0 <= v0) ++c0; else n0 = min(n0, k0);
-                if (k1 <= v1) ++c1; else n1 = min(n1, k1);
-            }
-            atomicAdd(&s_count[0], c0);
-            atomicAdd(&s_count[1], c1);
-            atomicMin(&s_next[0], n0);
-            atomicMin(&s_next[1], n1);
+        // (all levels done: sel[a].lo is the key at rank k_lo, sel[a].le the number of keys <= it)
+        const unsigned int v0 = sel[0].lo, v1 = sel[1].lo;
+        if (k_hi != k_lo) {   // need the key at k_lo + 1: smallest key above when duplicates do not cover it
+            unsigned int n0 = 0xffffffffu, n1 = 0xffffffffu;
+            OSQ_FOR_EACH_VALID({
+                const unsigned int k0 = abs_key(vmx), k1 = abs_key(vmn);
+                if (k0 > v0) n0 = min(n0, k0);
+                if (k1 > v1) n1 = min(n1, k1);
+            })
+            n0 = wave_min_u32(n0);
+            n1 = wave_min_u32(n1);
+            if (lane == 0) { atomicMin(&s_next[0], n0); atomicMin(&s_next[1], n1); }
+            __syncthreads();
         }
-        __syncthreads();
         float thr[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const unsigned int vk = a == 0 ? v0 : v1;
-            const float lo_v = __uint_as_float(vk);
-            const float hi_v = (k_hi == k_lo || s_count[a] > k_hi) ? lo_v : __uint_as_float(s_next[a]);
+            const float lo_v = __uint_as_float(a == 0 ? v0 : v1);
+            const float hi_v = (k_hi == k_lo || sel[a].le > k_hi) ? lo_v : __uint_as_float(s_next[a]);
             const float diff = hi_v - lo_v;
             thr[a] = (w < 0.5f) ? __builtin_fmaf(w, diff, lo_v) : __builtin_fmaf(w - 1.0f, diff, hi_v);
         }
         const float upper = thr[0], lower = -thr[1];
         // ---- up = max(token_max[token_max <= upper]) ; lo = min(token_min[token_min >= lower])
+        __syncthreads();
+        if (tid == 0) { s_omin = 0xffffffffu; s_omax = 0u; }
+        __syncthreads();
         MinMax pr;
         pr.init();
-        {
-            int64_t bc = -1, lc = 0;
-            for (int64_t s = tid; s < slots; s += kFinalThreads) {
-                if (!slot_valid(s, T, lengths, &bc, &lc)) continue;
-                const float a = tok_min[s], b = tok_max[s];
-                if (a >= lower) pr.mn = fminf(pr.mn, a);
-                if (b <= upper) pr.mx = fmaxf(pr.mx, b);
-            }
-        }
-        pr = block_reduce(pr);
-        if (tid == 0) {
-            // aminmax(clip(value, lo, up)) (observer.py:68,227): (lo, up), or (up, up) if lo > up
-            s_res[0] = (pr.mn > pr.mx) ? pr.mx : pr.mn;
-            s_res[1] = pr.mx;
+        OSQ_FOR_EACH_VALID({
+            if (vmn >= lower) pr.mn = fminf(pr.mn, vmn);
+            if (vmx <= upper) pr.mx = fmaxf(pr.mx, vmx);
+        })
+        pr.mn = wave_min(pr.mn);
+        pr.mx = wave_max(pr.mx);
+        if (lane == 0) {
+            atomicMin(&s_omin, ordered_bits(pr.mn));
+            atomicMax(&s_omax, ordered_bits(pr.mx));
         }
         __syncthreads();
-        cur_min = s_res[0];
-        cur_max = s_res[1];
+        const float lo_sel = from_ordered_bits(s_omin), up_sel = from_ordered_bits(s_omax);
+        // aminmax(clip(value, lo, up)) (observer.py:68,227): (lo, up), or (up, up) if lo > up
+        cur_min = (lo_sel > up_sel) ? up_sel : lo_sel;
+        cur_max = up_sel;
     }
-    if (tid == 0 && N > 0) {
-        if (s_nan) { cur_min = __builtin_nanf(""); cur_max = __builtin_nanf(""); }
+    if (tid == 0 && N > 0u) {
+        if (bad) { cur_min = __builtin_nanf(""); cur_max = __builtin_nanf(""); }
         finish_entry(fin, 0, cur_min, cur_max);
     }
+#undef OSQ_FOR_EACH_VALID
 }
 
 static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
@@ -541,8 +666,14 @@ extern "C" int osq_token_minmax(const float* x, const osq_token_view* view, cons
             lgG = 0;
             while ((1 << lgG) < inner4 && lgG < 6) ++lgG;
         }
-        hipLaunchKernelGGL(token_minmax_vec_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, token_min, token_max,
-                           lgG, inner4);
+        OSQ_REQUIRE(v.batch <= 65535, "token_minmax: batch exceeds grid.y");
+        const dim3 tgrid(static_cast<unsigned>((v.tokens + kTokPerBlock - 1) / kTokPerBlock), static_cast<unsigned>(v.batch));
+        if (v.feat_outer == 1)
+            hipLaunchKernelGGL(token_minmax_vec_kernel<true>, tgrid, dim3(kThreads), 0, st, x, v, lengths, token_min,
+                               token_max, lgG, inner4);
+        else
+            hipLaunchKernelGGL(token_minmax_vec_kernel<false>, tgrid, dim3(kThreads), 0, st, x, v, lengths, token_min,
+                               token_max, lgG, inner4);
     } else {
         hipLaunchKernelGGL(token_minmax_generic_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, token_min,
                            token_max);
@@ -564,7 +695,12 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     OSQ_REQUIRE(check_finish_args(update_rule, min_val, max_val, &why), why);
     const Finish fin{update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric, scale_out,
                      zero_point_out, zp_type};
-    hipLaunchKernelGGL(token_finalize_kernel, dim3(1), dim3(kFinalThreads), 0, static_cast<hipStream_t>(stream), token_min,
-                       token_max, batch, tokens, lengths, prune, static_cast<float>(percentile), fin);
+    OSQ_REQUIRE(batch * tokens < (1ll << 31), "token_range_finalize: more than 2^31 token slots");
+    if (batch * tokens <= static_cast<int64_t>(kCacheSlots) * kFinalThreads)
+        hipLaunchKernelGGL(token_finalize_kernel<true>, dim3(1), dim3(kFinalThreads), 0, static_cast<hipStream_t>(stream),
+                           token_min, token_max, batch, tokens, lengths, prune, static_cast<float>(percentile), fin);
+    else
+        hipLaunchKernelGGL(token_finalize_kernel<false>, dim3(1), dim3(kFinalThreads), 0, static_cast<hipStream_t>(stream),
+                           token_min, token_max, batch, tokens, lengths, prune, static_cast<float>(percentile), fin);
     return check_launch("token_range_finalize");
 }

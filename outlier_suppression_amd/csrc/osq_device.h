@@ -123,15 +123,69 @@ __device__ __forceinline__ void store_stream(float4* p, const float4& o) {
 
 // ---- wave64 / block reductions -------------------------------------------------------
 
+// DPP cross-lane moves run at VALU rate (no LDS crossbar round trip like ds_bpermute).
+// For an idempotent, commutative op (min / max) four DPP steps leave every lane of a
+// 16-lane row holding the row's result; the four row results are then read with
+// v_readlane and combined, giving a wave-uniform value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, OSQ_WAVE));
-    return v;
+    v = fminf(v, dpp_move<kDppQuadXor1>(v));
+    v = fminf(v, dpp_move<kDppQuadXor2>(v));
+    v = fminf(v, dpp_move<kDppRowHalfMirror>(v));
+    v = fminf(v, dpp_move<kDppRowMirror>(v));
+    return fminf(fminf(lane_value(v, 0), lane_value(v, 16)), fminf(lane_value(v, 32), lane_value(v, 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_move<kDppQuadXor1>(v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2>(v));
+    v = fmaxf(v, dpp_move<kDppRowHalfMirror>(v));
+    v = fmaxf(v, dpp_move<kDppRowMirror>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, OSQ_WAVE));
+    for (int o = 32; o > 0; o >>= 1) v = min(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o, OSQ_WAVE)));
     return v;
+}
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o, OSQ_WAVE)));
+    return v;
+}
+// wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, then row_bcast15 / row_bcast31 into the
+// following rows): six VALU-rate steps, no LDS traffic.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_add_step(unsigned int v) {
+    return v + static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ unsigned int wave_inclusive_scan_u32(unsigned int v) {
+    v = dpp_add_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+    v = dpp_add_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// order-preserving map fp32 -> u32 (for LDS atomicMin/atomicMax on floats; NaN handled separately)
+__device__ __forceinline__ unsigned int ordered_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -140,25 +194,64 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
-// Release this workgroup's global stores to the whole device, take a ticket, and tell
-// the caller whether it is the last workgroup of the grid.  The last one has acquired
-// every other workgroup's stores when this returns (cdna_hip_programming.md G16).
-// *counter must be 0 at launch; the caller resets it when it is the last block.
-__device__ __forceinline__ bool grid_last_block(unsigned int* counter, unsigned int nblocks) {
-    __shared__ unsigned int s_ticket;
-    __syncthreads();                      // every wave's partial stores are issued
+// ---- last-workgroup-finishes pattern, without release fences ---------------------------
+// A release fence at agent scope is `buffer_wbl2` = write back the whole XCD L2; issued by
+// every workgroup of a 2048-block grid it serialises (measured: 108 us for a 96 MiB min/max
+// that streams in 17 us).  Instead (cdna_hip_programming.md G16, "atomics both sides"): each
+// workgroup publishes its partial with agent-scope relaxed atomic STORES (write-through, sc1),
+// drains them (s_waitcnt vmcnt(0)), then takes a ticket with an agent-scope atomic; the last
+// workgroup reads all partials with agent-scope atomic LOADS (served by L2/fabric, never a
+// stale L1 line).  No fence, no L2 write-back.  *counter is 0 at launch and reset by the last
+// workgroup.
+__device__ __forceinline__ void publish_f32(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float consume_f32(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void publish_f64(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double consume_f64(const double* p) {
+    return __longlong_as_double(static_cast<long long>(
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+// Arrival tickets are sharded: one device-scope counter sustains only ~80 arrivals/us
+// (MI355X_MICROARCH.md "fanin": 11-13 ns per atomic), so 2048 workgroups finishing together
+// would queue for ~25 us on a single word.  32 shard counters (different cache lines would be
+// better still; different words already spread over L2 channels by address hash) take the
+// arrivals in parallel; the last arriver of a shard takes a ticket on the top counter.
+// counters[0] = top, counters[1 + s] = shard s; all zero at launch, reset by the last workgroup.
+constexpr unsigned int kTicketShards = 32;
+constexpr unsigned int kTicketStride = 16;   // one 64-byte line per counter
+
+// Call from thread 0 AFTER it has published the workgroup's partial; every thread gets the answer.
+__device__ __forceinline__ bool grid_last_block(unsigned int* counters, unsigned int nblocks) {
+    __shared__ unsigned int s_last;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the published partial has left this CU
+        const unsigned int shards = nblocks < kTicketShards ? nblocks : kTicketShards;
+        const unsigned int shard = blockIdx.x % shards;
+        const unsigned int members = (nblocks - shard + shards - 1) / shards;
+        unsigned int last = 0u;
+        const unsigned int t = __hip_atomic_fetch_add(&counters[(1 + shard) * kTicketStride], 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+        if (t == members - 1) {
+            const unsigned int top = __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (top == shards - 1) ? 1u : 0u;
+        }
+        s_last = last;
     }
     __syncthreads();
-    const bool last = (s_ticket == nblocks - 1);
-    if (last) {
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-    }
-    return last;
+    return s_last != 0u;
+}
+// thread 0 of the last workgroup
+__device__ __forceinline__ void grid_reset(unsigned int* counters, unsigned int nblocks) {
+    const unsigned int shards = nblocks < kTicketShards ? nblocks : kTicketShards;
+    __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned int s = 0; s < shards; ++s)
+        __hip_atomic_store(&counters[(1 + s) * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace osq

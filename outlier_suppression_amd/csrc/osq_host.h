@@ -9,7 +9,7 @@
 namespace osq {
 
 constexpr int kMaxBlocks = 2048;          // 256 CUs x 8 workgroups of 256 threads
-constexpr size_t kWsHeaderBytes = 256;    // 64 x uint32 tickets/counters
+constexpr size_t kWsHeaderBytes = 4096;   // ticket counters, one 64-byte line each (33 used)
 constexpr size_t kWsScratchBytes = 64 * 1024;
 
 void set_error(const char* fmt, ...);
@@ -33,12 +33,12 @@ static inline int check_launch(const char* what) {
     return OSQ_OK;
 }
 
-// Caller-owned scratch: [64 counters][64 KiB scratch].  Counters are zero between
+// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
     explicit Workspace(void* p) : base(static_cast<char*>(p)) {}
-    unsigned int* counter(int k) const { return reinterpret_cast<unsigned int*>(base) + k; }
+    unsigned int* counter(int) const { return reinterpret_cast<unsigned int*>(base); }
     double* doubles() const { return reinterpret_cast<double*>(base + kWsHeaderBytes); }
     float* floats() const { return reinterpret_cast<float*>(base + kWsHeaderBytes); }
 };

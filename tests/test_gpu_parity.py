@@ -303,10 +303,12 @@ def test_module_traces_golden(golden, eq32, dev):
         y.backward(T(g[f"c{k}_gy"], dev))
         assert eq32(N(y), g[f"c{k}_y"]), (k, quantizer)
         assert eq32(N(xt.grad), g[f"c{k}_dx"]), (k, quantizer)
+        # float sums: the reference accumulates in fp32 (its own rounding is ~1e-6 absolute on
+        # per-channel sums that cancel), the kernel in float64
         if f"c{k}_ds" in g.files:
-            np.testing.assert_allclose(N(q.scale.grad), g[f"c{k}_ds"], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(N(q.scale.grad), g[f"c{k}_ds"], rtol=2e-5, atol=2e-6)
         if f"c{k}_dzp" in g.files:
-            np.testing.assert_allclose(N(q.zero_point.grad), g[f"c{k}_dzp"], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(N(q.zero_point.grad), g[f"c{k}_dzp"], rtol=2e-5, atol=2e-6)
 
 
 def test_learnable_sanitize(dev):

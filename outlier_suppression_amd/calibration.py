@@ -34,8 +34,9 @@ def gather_batch_table(local, n_batches, group=None):
     rows = (n_batches + world - 1) // world
     if local.shape[0] != rows:
         raise ValueError(f"gather_batch_table: expected {rows} local rows, got {local.shape[0]}")
-    gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    flat = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, local.contiguous(), group=group)     # rank-major concatenation
+    gathered = flat.view((world, rows) + tuple(local.shape[1:]))
     # gathered[r, j] is batch j*W + r  ->  transpose to [j, r] and flatten = global order
     ordered = gathered.transpose(0, 1).reshape((rows * world,) + tuple(local.shape[1:]))
     return ordered[:n_batches].contiguous()

@@ -292,23 +292,29 @@ __global__ __launch_bounds__(kThreads) void token_minmax_generic_kernel(const fl
 // ---------------------------------------------------------------- token range finaliser (K7b + K8 + K9)
 
 // Single workgroup of 1024 threads.  Valid slots: b*T + t with t < lengths[b] (all if
-// lengths == NULL).  Up to 32 slots per thread are loaded ONCE into registers (covers
-// batch*tokens <= 32768, e.g. the [256,128,768] benchmark tensor); larger inputs re-read
-// the L2-resident arrays in every pass.
+// lengths == NULL).  Up to SLOTS slots per thread are loaded ONCE into registers (SLOTS = 4,
+// 8, 16 or 32 covers batch*tokens <= 4096 ... 32768, e.g. the [256,128,768] benchmark
+// tensor); larger inputs (SLOTS = 0) re-read the L2-resident arrays in every pass.
 //
 // prune: torch.quantile(|token_max|, p) needs the order statistics floor(rank) and
 // ceil(rank), rank = fp32(p) * fp32(N-1).  Selection works on the fp32 bit patterns of the
-// absolute values (non-negative floats order like their bit patterns) with a range
-// histogram: 2048 bins spread linearly (power-of-two bin width) over the CURRENT key range
-// [lo, lo + width); the bin holding the wanted rank becomes the next range.  Starting from
-// the observed [min key, max key] each level strips 11 bits, so three levels give the exact
-// key; bins follow the data range, so the per-bin LDS atomics do not pile up on one exponent
-// bin the way a digit-wise radix pass would.  The value at ceil(rank) is the same value when
-// duplicates cover it and otherwise the smallest key above.  Interpolation is torch's lerp
-// (one fused multiply-add per branch, pinned in tests/test_oracle_pinning.py).
+// absolute values (non-negative floats order like their bit patterns):
+//   pass 0  N, NaN flag, plain extrema, [min key, max key] of both arrays
+//   pass 1  range histogram: 2048 bins spread linearly (power-of-two bin width) over the
+//           observed key range -- bins follow the data, so the LDS atomics do not pile up on
+//           one exponent bin the way a digit-wise radix pass would; a block-wide DPP scan
+//           finds the bin that holds the wanted rank
+//   pass 2  the (few) keys of that bin are compacted into an LDS list, together with the
+//           smallest key above the bin; the list is ranked by counting, which yields the keys
+//           at floor(rank) and ceil(rank) exactly
+//           (if a bin holds more than 1024 keys -- massive duplicates -- fall back to two more
+//           histogram levels of 11 bits each plus a neighbour pass)
+//   pass 3  up = max(token_max[token_max <= upper]), lo = min(token_min[token_min >= lower])
+// Interpolation is torch's lerp (one fused multiply-add per branch, pinned in
+// tests/test_oracle_pinning.py).
 constexpr int kSelBins = 2048;
 constexpr int kSelBits = 11;
-constexpr int kCacheSlots = 32;
+constexpr int kListCap = 1024;
 
 struct SelState {
     unsigned int lo;       // first key of the current range; the selected key once done
@@ -317,67 +323,86 @@ struct SelState {
     unsigned int shift;    // log2(bin width) of the level being histogrammed
     unsigned int le;       // keys below the range so far; once done: keys <= the selected key
     unsigned int done;
+    unsigned int count;    // keys inside the current range
 };
 
 __device__ __forceinline__ unsigned int abs_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned int uniform(unsigned int v) {
+    return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
 
 __device__ __forceinline__ unsigned int level_shift(unsigned int width) {
     const unsigned int bits = width <= 1u ? 0u : 32u - __builtin_clz(width - 1u);
     return bits > kSelBits ? bits - kSelBits : 0u;
 }
 
-template <bool CACHED>
+// development aid: -DOSQ_FINAL_TIMING makes thread 0 write s_memtime stamps after cur_minmax[0..1]
+#ifdef OSQ_FINAL_TIMING
+#define OSQ_STAMP(k) do { if (threadIdx.x == 0 && fin.cur) reinterpret_cast<long long*>(fin.cur + 2)[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define OSQ_STAMP(k) do { } while (0)
+#endif
+
+template <int SLOTS>
 __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const float* __restrict__ tok_min,
                                                                        const float* __restrict__ tok_max, int64_t B,
                                                                        int64_t T, const int64_t* __restrict__ lengths,
                                                                        int prune, float q, Finish fin) {
+    constexpr bool CACHED = SLOTS > 0;
+    constexpr int R = CACHED ? SLOTS : 1;
+    constexpr int kWaves = kFinalThreads / OSQ_WAVE;
     __shared__ unsigned int hist[2][kSelBins];
+    __shared__ unsigned int list[2][kListCap];
     __shared__ SelState sel[2];
-    __shared__ unsigned int s_n, s_bad, s_next[2], s_kmin[2], s_kmax[2], s_omin, s_omax;
-    __shared__ unsigned int s_wtot[2][kFinalThreads / OSQ_WAVE];
+    __shared__ unsigned int s_n, s_bad, s_next[2], s_kmin[2], s_kmax[2], s_omin, s_omax, s_fill[2], s_found[2][2];
+    __shared__ unsigned int s_wtot[2][kWaves];
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
-    constexpr int kWaves = kFinalThreads / OSQ_WAVE;
     const int64_t slots = B * T;
 
-    // ---- register cache (CACHED): slot = tid + i*1024
-    float r_mn[kCacheSlots], r_mx[kCacheSlots];
+    // ---- register cache: slot = tid + i*1024.  Every load is unconditional (index clamped) and
+    // independent, so all of them are in flight together; validity comes from the lengths.
+    float r_mn[R], r_mx[R];
     unsigned int vmask = 0u;
+    OSQ_STAMP(0);
     if (CACHED) {
-        // every load is unconditional (index clamped) and independent, so all of them are in
-        // flight together; validity is decided afterwards from the lengths
         const unsigned int Tu = static_cast<unsigned int>(T), last = static_cast<unsigned int>(slots) - 1u;
         {
-            int len_i[kCacheSlots];
+            // (b, t) of slot tid + i*1024 by stepping, one division per thread instead of one per slot
+            const unsigned int step_b = kFinalThreads / Tu, step_t = kFinalThreads - step_b * Tu;
+            const unsigned int Bm1 = static_cast<unsigned int>(B) - 1u;
+            unsigned int bb = static_cast<unsigned int>(tid) / Tu, tt = static_cast<unsigned int>(tid) - bb * Tu;
+            int len_i[R];
+            unsigned int t_i[R];
 #pragma unroll
-            for (int i = 0; i < kCacheSlots; ++i) {
-                const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
-                const unsigned int sc = s < last ? s : last;
+            for (int i = 0; i < R; ++i) {
                 int64_t l = T;
-                if (lengths) l = lengths[sc / Tu];
+                if (lengths) l = lengths[bb < Bm1 ? bb : Bm1];
                 len_i[i] = l > T ? static_cast<int>(T) : (l < 0 ? 0 : static_cast<int>(l));
+                t_i[i] = tt;
+                bb += step_b;
+                tt += step_t;
+                if (tt >= Tu) { tt -= Tu; ++bb; }
             }
 #pragma unroll
-            for (int i = 0; i < kCacheSlots; ++i) {
+            for (int i = 0; i < R; ++i) {
                 const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
-                const unsigned int sc = s < last ? s : last;
-                const unsigned int t = sc - (sc / Tu) * Tu;
-                if (s <= last && static_cast<int>(t) < len_i[i]) vmask |= (1u << i);
+                if (s <= last && static_cast<int>(t_i[i]) < len_i[i]) vmask |= (1u << i);
             }
         }
         asm volatile("" : "+v"(vmask));   // lengths are dead before the value loads start
 #pragma unroll
-        for (int i = 0; i < kCacheSlots; ++i) {
+        for (int i = 0; i < R; ++i) {
             const unsigned int s = static_cast<unsigned int>(tid) + static_cast<unsigned int>(i) * kFinalThreads;
             const unsigned int sc = s < last ? s : last;
             r_mn[i] = tok_min[sc];
             r_mx[i] = tok_max[sc];
         }
     }
-// run `body` for every valid slot with vmn / vmx bound to its token minimum / maximum
+// run the statements for every valid slot with vmn / vmx bound to its token minimum / maximum
 #define OSQ_FOR_EACH_VALID(...)                                                                    \
     if (CACHED) {                                                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < kCacheSlots; ++i_) {                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < R; ++i_) {                                         \
             if ((vmask >> i_) & 1u) {                                                              \
                 float vmn = r_mn[i_], vmx = r_mx[i_];                                              \
                 /* opaque copies: values derived from them are recomputed per pass, not kept live */ \
@@ -398,11 +423,13 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         }                                                                                          \
     }
 
+    OSQ_STAMP(1);
     if (tid == 0) {
         s_n = 0u; s_bad = 0u; s_omin = 0xffffffffu; s_omax = 0u;
         s_kmin[0] = s_kmin[1] = 0xffffffffu;
         s_kmax[0] = s_kmax[1] = 0u;
         s_next[0] = s_next[1] = 0xffffffffu;
+        s_fill[0] = s_fill[1] = 0u;
     }
     __syncthreads();
 
@@ -423,10 +450,9 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         plain.wave_reduce();
         kmin0 = wave_min_u32(kmin0); kmax0 = wave_max_u32(kmax0);
         kmin1 = wave_min_u32(kmin1); kmax1 = wave_max_u32(kmax1);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(static_cast<int>(n), o, OSQ_WAVE);
+        n = wave_inclusive_scan_u32(n);      // lane 63 holds the wave total
+        if (lane == OSQ_WAVE - 1) atomicAdd(&s_n, n);
         if (lane == 0) {
-            atomicAdd(&s_n, n);
             if (plain.bad) atomicOr(&s_bad, 1u);
             atomicMin(&s_omin, ordered_bits(plain.mn));
             atomicMax(&s_omax, ordered_bits(plain.mx));
@@ -435,6 +461,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         }
     }
     __syncthreads();
+    OSQ_STAMP(2);
     const unsigned int N = s_n;
     const bool bad = s_bad != 0u;
     float cur_min = from_ordered_bits(s_omin), cur_max = from_ordered_bits(s_omax);
@@ -453,15 +480,23 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
             sel[tid].shift = level_shift(sel[tid].width);
             sel[tid].le = 0u;
             sel[tid].done = 0u;
+            sel[tid].count = N;
         }
         __syncthreads();
-        // ---- at most three range-histogram levels, both arrays at once: [0] = |token_max|, [1] = |token_min|
+        // ---- histogram levels, both arrays at once: [0] = |token_max|, [1] = |token_min|.
+        // Level 0 always runs; levels 1-2 only when a bin is too crowded for the list.
+        bool listed = false;
         for (int level = 0; level < 3; ++level) {
             if (sel[0].done && sel[1].done) break;          // uniform: sel is only written between barriers
+            if (level > 0 && (sel[0].done || sel[0].count <= kListCap) && (sel[1].done || sel[1].count <= kListCap)) {
+                listed = true;
+                break;
+            }
             for (int k = tid; k < 2 * kSelBins; k += kFinalThreads) (&hist[0][0])[k] = 0u;
             __syncthreads();
-            const unsigned int lo0 = sel[0].lo, w0 = sel[0].width, sh0 = sel[0].shift;
-            const unsigned int lo1 = sel[1].lo, w1 = sel[1].width, sh1 = sel[1].shift;
+            // block-uniform values go to SGPRs: no LDS-read dependency inside the per-slot code
+            const unsigned int lo0 = uniform(sel[0].lo), w0 = uniform(sel[0].width), sh0 = uniform(sel[0].shift);
+            const unsigned int lo1 = uniform(sel[1].lo), w1 = uniform(sel[1].width), sh1 = uniform(sel[1].shift);
             OSQ_FOR_EACH_VALID({
                 const unsigned int d0 = abs_key(vmx) - lo0, d1 = abs_key(vmn) - lo1;
                 if (d0 < w0) atomicAdd(&hist[0][d0 >> sh0], 1u);
@@ -489,6 +524,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
                     const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
                     const unsigned int sh = sel[a].shift, off = bin << sh;
                     sel[a].lo += off;
+                    sel[a].count = cnt;
                     if (sh == 0u) {                           // bins are single keys: found
                         sel[a].le += below + cnt;
                         sel[a].width = 0u;
@@ -504,30 +540,80 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
             }
             __syncthreads();
         }
-        // (all levels done: sel[a].lo is the key at rank k_lo, sel[a].le the number of keys <= it)
-        const unsigned int v0 = sel[0].lo, v1 = sel[1].lo;
-        if (k_hi != k_lo) {   // need the key at k_lo + 1: smallest key above when duplicates do not cover it
+        OSQ_STAMP(3);
+        unsigned int v0, v1, hi0, hi1;      // keys at floor(rank) / ceil(rank) of |token_max|, |token_min|
+        if (listed) {
+            // ---- pass 2: compact the keys of the chosen bins; remember the smallest key above each bin
+            const unsigned int lo0 = uniform(sel[0].lo), w0 = uniform(sel[0].width), d0ne = uniform(sel[0].done);
+            const unsigned int lo1 = uniform(sel[1].lo), w1 = uniform(sel[1].width), d1ne = uniform(sel[1].done);
             unsigned int n0 = 0xffffffffu, n1 = 0xffffffffu;
             OSQ_FOR_EACH_VALID({
                 const unsigned int k0 = abs_key(vmx), k1 = abs_key(vmn);
-                if (k0 > v0) n0 = min(n0, k0);
-                if (k1 > v1) n1 = min(n1, k1);
+                const unsigned int e0 = k0 - lo0, e1 = k1 - lo1;
+                if (d0ne) { if (k0 > lo0) n0 = min(n0, k0); }
+                else if (e0 < w0) list[0][atomicAdd(&s_fill[0], 1u)] = k0;
+                else if (k0 >= lo0) n0 = min(n0, k0);
+                if (d1ne) { if (k1 > lo1) n1 = min(n1, k1); }
+                else if (e1 < w1) list[1][atomicAdd(&s_fill[1], 1u)] = k1;
+                else if (k1 >= lo1) n1 = min(n1, k1);
             })
             n0 = wave_min_u32(n0);
             n1 = wave_min_u32(n1);
             if (lane == 0) { atomicMin(&s_next[0], n0); atomicMin(&s_next[1], n1); }
+            if (tid < 4) s_found[tid >> 1][tid & 1] = 0xffffffffu;
             __syncthreads();
+            // rank every list entry by counting (ties broken by position): entries at rank and rank+1
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const unsigned int cnt = sel[a].done ? 0u : s_fill[a];
+                if (static_cast<unsigned int>(tid) < cnt) {
+                    const unsigned int mine = list[a][tid];
+                    unsigned int r = 0u;
+                    for (unsigned int j = 0; j < cnt; ++j) {
+                        const unsigned int o = list[a][j];
+                        r += (o < mine || (o == mine && j < static_cast<unsigned int>(tid))) ? 1u : 0u;
+                    }
+                    if (r == sel[a].rank) s_found[a][0] = mine;
+                    if (r == sel[a].rank + 1u) s_found[a][1] = mine;
+                }
+            }
+            __syncthreads();
+            // key at ceil(rank): next list entry, else the smallest key above the bin
+            v0 = sel[0].done ? sel[0].lo : s_found[0][0];
+            v1 = sel[1].done ? sel[1].lo : s_found[1][0];
+            hi0 = sel[0].done ? (sel[0].le > k_hi ? v0 : s_next[0]) : (s_found[0][1] != 0xffffffffu ? s_found[0][1] : s_next[0]);
+            hi1 = sel[1].done ? (sel[1].le > k_hi ? v1 : s_next[1]) : (s_found[1][1] != 0xffffffffu ? s_found[1][1] : s_next[1]);
+        } else {
+            // all levels ran: sel[a].lo is the key at rank k_lo, sel[a].le the number of keys <= it
+            v0 = uniform(sel[0].lo);
+            v1 = uniform(sel[1].lo);
+            if (k_hi != k_lo) {   // smallest key above, used when duplicates do not cover rank k_lo + 1
+                unsigned int n0 = 0xffffffffu, n1 = 0xffffffffu;
+                OSQ_FOR_EACH_VALID({
+                    const unsigned int k0 = abs_key(vmx), k1 = abs_key(vmn);
+                    if (k0 > v0) n0 = min(n0, k0);
+                    if (k1 > v1) n1 = min(n1, k1);
+                })
+                n0 = wave_min_u32(n0);
+                n1 = wave_min_u32(n1);
+                if (lane == 0) { atomicMin(&s_next[0], n0); atomicMin(&s_next[1], n1); }
+                __syncthreads();
+            }
+            hi0 = sel[0].le > k_hi ? v0 : s_next[0];
+            hi1 = sel[1].le > k_hi ? v1 : s_next[1];
         }
+        OSQ_STAMP(4);
+        if (k_hi == k_lo) { hi0 = v0; hi1 = v1; }
         float thr[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const float lo_v = __uint_as_float(a == 0 ? v0 : v1);
-            const float hi_v = (k_hi == k_lo || sel[a].le > k_hi) ? lo_v : __uint_as_float(s_next[a]);
+            const float lo_v = __uint_as_float(a == 0 ? v0 : v1), hi_v = __uint_as_float(a == 0 ? hi0 : hi1);
             const float diff = hi_v - lo_v;
             thr[a] = (w < 0.5f) ? __builtin_fmaf(w, diff, lo_v) : __builtin_fmaf(w - 1.0f, diff, hi_v);
         }
-        const float upper = thr[0], lower = -thr[1];
-        // ---- up = max(token_max[token_max <= upper]) ; lo = min(token_min[token_min >= lower])
+        const float upper = __uint_as_float(uniform(__float_as_uint(thr[0])));
+        const float lower = -__uint_as_float(uniform(__float_as_uint(thr[1])));
+        // ---- pass 3: up = max(token_max[token_max <= upper]) ; lo = min(token_min[token_min >= lower])
         __syncthreads();
         if (tid == 0) { s_omin = 0xffffffffu; s_omax = 0u; }
         __syncthreads();
@@ -548,11 +634,13 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         // aminmax(clip(value, lo, up)) (observer.py:68,227): (lo, up), or (up, up) if lo > up
         cur_min = (lo_sel > up_sel) ? up_sel : lo_sel;
         cur_max = up_sel;
+        OSQ_STAMP(5);
     }
     if (tid == 0 && N > 0u) {
         if (bad) { cur_min = __builtin_nanf(""); cur_max = __builtin_nanf(""); }
         finish_entry(fin, 0, cur_min, cur_max);
     }
+    OSQ_STAMP(6);
 #undef OSQ_FOR_EACH_VALID
 }
 
@@ -696,11 +784,17 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     const Finish fin{update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric, scale_out,
                      zero_point_out, zp_type};
     OSQ_REQUIRE(batch * tokens < (1ll << 31), "token_range_finalize: more than 2^31 token slots");
-    if (batch * tokens <= static_cast<int64_t>(kCacheSlots) * kFinalThreads)
-        hipLaunchKernelGGL(token_finalize_kernel<true>, dim3(1), dim3(kFinalThreads), 0, static_cast<hipStream_t>(stream),
-                           token_min, token_max, batch, tokens, lengths, prune, static_cast<float>(percentile), fin);
-    else
-        hipLaunchKernelGGL(token_finalize_kernel<false>, dim3(1), dim3(kFinalThreads), 0, static_cast<hipStream_t>(stream),
-                           token_min, token_max, batch, tokens, lengths, prune, static_cast<float>(percentile), fin);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qf = static_cast<float>(percentile);
+    const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
+#define OSQ_LAUNCH_FINAL(S)                                                                                        \
+    hipLaunchKernelGGL(token_finalize_kernel<S>, dim3(1), dim3(kFinalThreads), 0, st, token_min, token_max, batch, \
+                       tokens, lengths, prune, qf, fin)
+    if (per_thread <= 4) OSQ_LAUNCH_FINAL(4);
+    else if (per_thread <= 8) OSQ_LAUNCH_FINAL(8);
+    else if (per_thread <= 16) OSQ_LAUNCH_FINAL(16);
+    else if (per_thread <= 32) OSQ_LAUNCH_FINAL(32);
+    else OSQ_LAUNCH_FINAL(0);
+#undef OSQ_LAUNCH_FINAL
     return check_launch("token_range_finalize");
 }

@@ -153,15 +153,26 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_move<kDppRowMirror>(v));
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_move_u32(unsigned int v) {
+    return static_cast<unsigned int>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ unsigned int lane_value_u32(unsigned int v, int lane) {
+    return static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o, OSQ_WAVE)));
-    return v;
+    v = min(v, dpp_move_u32<kDppQuadXor1>(v));
+    v = min(v, dpp_move_u32<kDppQuadXor2>(v));
+    v = min(v, dpp_move_u32<kDppRowHalfMirror>(v));
+    v = min(v, dpp_move_u32<kDppRowMirror>(v));
+    return min(min(lane_value_u32(v, 0), lane_value_u32(v, 16)), min(lane_value_u32(v, 32), lane_value_u32(v, 48)));
 }
 __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, static_cast<unsigned int>(__shfl_xor(static_cast<int>(v), o, OSQ_WAVE)));
-    return v;
+    v = max(v, dpp_move_u32<kDppQuadXor1>(v));
+    v = max(v, dpp_move_u32<kDppQuadXor2>(v));
+    v = max(v, dpp_move_u32<kDppRowHalfMirror>(v));
+    v = max(v, dpp_move_u32<kDppRowMirror>(v));
+    return max(max(lane_value_u32(v, 0), lane_value_u32(v, 16)), max(lane_value_u32(v, 32), lane_value_u32(v, 48)));
 }
 // wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, then row_bcast15 / row_bcast31 into the
 // following rows): six VALU-rate steps, no LDS traffic.  All 64 lanes must be active.

@@ -192,6 +192,43 @@ int osq_observer_update(const float* cur_min, const float* cur_max, int64_t n,
                         int update_rule, int64_t cnt, float* min_val, float* max_val,
                         osq_stream stream);
 
+/* ------------------------------------------------------------------ MSEFast (observer.py:412-567) */
+
+/* one_side: 0 = 'no', 1 = 'pos', 2 = 'neg' (observer.py:528-529, decided once by the caller on
+ * the first observed tensor); two_d: 1 for the nested range/shift search (observer.py:458-481),
+ * 0 for the 1-D search (observer.py:483-494). */
+
+/* golden_section_{1D,2D}_search with ch_axis = 0 (observer.py:496-517): one bounded-Brent
+ * search per row of w[rows, cols] -- the reference's Python loop over channels -- in ONE launch.
+ * best_min / best_max: rows fp32 entries (the values assigned at observer.py:504,516);
+ * nfev (nullable): loss evaluations spent per row. */
+int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int quant_min, int quant_max,
+                     int symmetric, int one_side, int two_d,
+                     float* best_min, float* best_max, int32_t* nfev, osq_stream stream);
+
+/* Per-tensor search (observer.py:497-499,510-512).  The Brent state machine lives in `state`
+ * (osq_msefast_state_bytes() of device memory).  begin: start from the tensor's (min, max)
+ * (2 floats on the device, e.g. cur_minmax of osq_observe_flat / osq_token_range_finalize with
+ * OSQ_UPDATE_NONE).  evals_*: enqueue n_evals loss evaluations (loss_fx, observer.py:423-432),
+ * each one launch that also advances the state machine; launches after convergence are no-ops.
+ * done: copy the converged flag to done_out (device int32).  commit: running min/max
+ * (observer.py:535-536) or running mean (observer.py:559-567) of the float64 statistics, then
+ * calculate_qparams in float64 into scale_out / zero_point_out (nullable). */
+size_t osq_msefast_state_bytes(void);
+int osq_msefast_tensor_begin(void* state, const float* cur_minmax, int quant_min, int quant_max,
+                             int symmetric, int one_side, int two_d, osq_stream stream);
+int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_t n, int n_evals,
+                                  void* workspace, osq_stream stream);
+int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token_view* view,
+                                    const int64_t* lengths, int n_evals,
+                                    void* workspace, osq_stream stream);
+int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
+int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt,
+                              double* min_val, double* max_val,
+                              int quant_min, int quant_max, int symmetric,
+                              float* scale_out, void* zero_point_out, int zp_type,
+                              int32_t* nfev, osq_stream stream);
+
 /* ------------------------------------------------------------------ gamma migration */
 
 /* gamma_migration.py:70-71  w.weight.data *= gamma  (gamma broadcast over columns). */

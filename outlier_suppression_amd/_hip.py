@@ -49,6 +49,13 @@ SIGNATURES = {
     "osq_token_minmax": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
     "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
+    "osq_msefast_rows": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "osq_msefast_state_bytes": (ctypes.c_size_t, []),
+    "osq_msefast_tensor_begin": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "osq_msefast_tensor_evals_flat": (_I, [_P, _P, _L, _I, _P, _P]),
+    "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
+    "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
+    "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_gamma_fold": (_I, [_P, _P, _L, _L, _P]),
     "osq_gamma_split_bias": (_I, [_P, _P, _P, _L, _P]),
     "osq_gamma_residual": (_I, [_P, _P, _P, _P, _L, _L, _P]),

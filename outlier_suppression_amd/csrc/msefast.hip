@@ -1,0 +1,534 @@
+// MSEFastObserver / AvgMSEFastObserver on gfx950 (MI355X).
+// Replaces quant_transformer/quantization/observer.py:412-567: a host-driven
+// scipy.optimize.minimize_scalar(method='Bounded') whose every loss evaluation is ~10 eager
+// kernels plus a .cpu() sync (and, per-channel, a Python loop over rows: ~15 evaluations per
+// row, 134 K rows for RoBERTa-base).
+//
+// Here the bounded Brent search (Forsythe/Malcolm/Moler fmin; restated and pinned against
+// scipy in oracle/brent.py + tests/test_oracle_pinning.py) is a device-side state machine:
+//   * per-channel weights: ONE launch; one wave per row, the row lives in registers, the whole
+//     search (1-D, or nested 2-D for asymmetric two-sided rows) runs inside the wave;
+//   * per-tensor activations: the search state sits in device memory; each loss evaluation is
+//     one streaming launch (4 B/elem, padded tokens skipped) whose last workgroup feeds the
+//     loss to the state machine and publishes the next candidate.  Launches are enqueued in
+//     chunks; a finished search turns the remaining launches of a chunk into no-ops.
+// Numerics follow the reference: candidates and qparams in float64 (scipy hands float64,
+// observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error and
+// its mean in fp32 (partial sums combined in float64).
+#include "osq_device.h"
+#include "osq_host.h"
+
+namespace osq {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / OSQ_WAVE;
+
+// ---------------------------------------------------------------- bounded Brent, ask/tell
+
+struct Brent {
+    double a, b, v, w, xf, d, e, fx, fv, fw, xm, tol1, tol2, pending;
+    int nfev, done, first;
+
+    __device__ double start(double lo, double hi) {
+        const double gold = 0.5 * (3.0 - 2.23606797749978969641);   // 0.5*(3 - sqrt(5))
+        a = lo; b = hi;
+        v = w = xf = a + gold * (b - a);
+        d = e = 0.0;
+        fx = fv = fw = 0.0;
+        nfev = 0; done = 0; first = 1;
+        pending = xf;
+        return xf;
+    }
+    __device__ void tolerances() {
+        const double sqrt_eps = 1.4832396974191326e-08;               // sqrt(2.2e-16)
+        xm = 0.5 * (a + b);
+        tol1 = sqrt_eps * fabs(xf) + 1e-5 / 3.0;                      // xatol = 1e-5
+        tol2 = 2.0 * tol1;
+    }
+    __device__ double propose() {
+        const double gold = 0.5 * (3.0 - 2.23606797749978969641);
+        bool golden = true;
+        if (fabs(e) > tol1) {
+            golden = false;
+            double r = (xf - w) * (fx - fv);
+            double q = (xf - v) * (fx - fw);
+            double p = (xf - v) * q - (xf - w) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = fabs(q);
+            r = e;
+            e = d;
+            if (fabs(p) < fabs(0.5 * q * r) && p > q * (a - xf) && p < q * (b - xf)) {
+                d = p / q;
+                const double x = xf + d;
+                if ((x - a) < tol2 || (b - x) < tol2) {
+                    const double sg = (xm > xf ? 1.0 : (xm < xf ? -1.0 : 0.0)) + (xm == xf ? 1.0 : 0.0);
+                    d = tol1 * sg;
+                }
+            } else {
+                golden = true;
+            }
+        }
+        if (golden) {
+            e = (xf >= xm) ? (a - xf) : (b - xf);
+            d = gold * e;
+        }
+        const double sg = (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0)) + (d == 0.0 ? 1.0 : 0.0);
+        const double ad = fabs(d);
+        return xf + sg * (ad > tol1 ? ad : tol1);
+    }
+    // returns the next abscissa; sets done when converged (the caller must not evaluate again)
+    __device__ double tell(double fu) {
+        ++nfev;
+        const double x = pending;
+        if (first) {
+            first = 0;
+            fx = fv = fw = fu;
+        } else {
+            if (fu <= fx) {
+                if (x >= xf) a = xf; else b = xf;
+                v = w; fv = fw;
+                w = xf; fw = fx;
+                xf = x; fx = fu;
+            } else {
+                if (x < xf) a = x; else b = x;
+                if (fu <= fw || w == xf) {
+                    v = w; fv = fw;
+                    w = x; fw = fu;
+                } else if (fu <= fv || v == xf || v == w) {
+                    v = x; fv = fu;
+                }
+            }
+            if (nfev >= 500) { done = 1; return xf; }                 // maxiter
+        }
+        tolerances();
+        if (!(fabs(xf - xm) > (tol2 - 0.5 * (b - a)))) { done = 1; return xf; }
+        pending = propose();
+        return pending;
+    }
+};
+
+// ---------------------------------------------------------------- search driver (observer.py:434-494)
+
+enum { SIDE_NO = 0, SIDE_POS = 1, SIDE_NEG = 2 };
+
+struct Search {
+    Brent outer, inner;
+    double x_min, x_max;        // observed extrema (exact fp32 values)
+    double cand_min, cand_max;  // candidate range whose loss is wanted next
+    double cur_range, best_min, best_max;
+    int quant_min, quant_max, symmetric, side, two_d, phase, done, nfev;
+
+    __device__ void shift_bounds(double r, double* lo, double* hi) const {
+        const double delta = r / static_cast<double>(quant_max - quant_min);
+        *lo = delta * quant_min;
+        *hi = delta * quant_max;
+    }
+    __device__ void candidate_1d(double r) {
+        cand_min = side == SIDE_POS ? 0.0 : -r;
+        cand_max = side == SIDE_NEG ? 0.0 : r;
+    }
+    __device__ void candidate_2d(double shift) {
+        const double lo = 0.0 - shift, hi = cur_range - shift;
+        cand_min = lo > x_min ? lo : x_min;        // max(tmp_min - shift, x_min)
+        cand_max = hi < x_max ? hi : x_max;        // min(tmp_max - shift, x_max)
+    }
+    __device__ void begin_inner(double r) {
+        cur_range = r;
+        double lo, hi;
+        shift_bounds(r, &lo, &hi);
+        candidate_2d(inner.start(lo, hi));
+    }
+    __device__ void init(float xmin_f, float xmax_f, int qmin, int qmax, int sym, int side_, int two_d_) {
+        x_min = xmin_f; x_max = xmax_f;
+        quant_min = qmin; quant_max = qmax; symmetric = sym; side = side_; two_d = two_d_;
+        phase = 0; done = 0; nfev = 0;
+        best_min = x_min; best_max = x_max;
+        if (!two_d) {
+            const float xr_f = fmaxf(fabsf(xmin_f), xmax_f);          // torch.max(x_min.abs(), x_max), fp32
+            const double xr = xr_f;
+            const double lo = 0.01 * xr < 0.1 ? 0.01 * xr : 0.1;
+            candidate_1d(outer.start(lo, xr));
+        } else {
+            const float xr_f = xmax_f - xmin_f;                        // fp32 subtraction (observer.py:459)
+            const double xr = xr_f;
+            const double lo = 0.01 * xr < 0.1 ? 0.01 * xr : 0.1;
+            begin_inner(outer.start(lo, xr));
+        }
+    }
+    __device__ void tell(float loss_f) {
+        const double f = loss_f;
+        ++nfev;
+        if (!two_d) {
+            const double r = outer.tell(f);
+            if (outer.done) {
+                const double rr = outer.xf;
+                best_min = side == SIDE_POS ? 0.0 : -rr;
+                best_max = side == SIDE_NEG ? 0.0 : rr;
+                done = 1;
+            } else {
+                candidate_1d(r);
+            }
+            return;
+        }
+        const double s = inner.tell(f);
+        if (!inner.done) { candidate_2d(s); return; }
+        if (phase == 0) {
+            const double r = outer.tell(inner.fx);                     // golden_asym_range_loss returns result.fun
+            if (outer.done) { phase = 1; begin_inner(outer.xf); }
+            else begin_inner(r);
+        } else {
+            const double shift = inner.xf, lo = 0.0 - shift, hi = cur_range - shift;
+            best_min = lo > x_min ? lo : x_min;
+            best_max = hi < x_max ? hi : x_max;
+            done = 1;
+        }
+    }
+};
+
+// observer.py:101-119 in float64, then what loss_fx hands to the fake-quant (observer.py:426-429)
+__device__ __forceinline__ void loss_qparams(double mn, double mx, int qmin, int qmax, int sym, float* scale_f, float* zp_f) {
+    const double min_neg = mn < 0.0 ? mn : 0.0, max_pos = mx > 0.0 ? mx : 0.0;
+    const double eps = static_cast<double>(1e-8f);
+    double scale, zp = 0.0;
+    if (sym) {
+        const double m = -min_neg > max_pos ? -min_neg : max_pos;
+        scale = m / (static_cast<double>(qmax - qmin) / 2.0);
+        scale = scale > eps ? scale : eps;
+    } else {
+        scale = (max_pos - min_neg) / static_cast<double>(qmax - qmin);
+        scale = scale > eps ? scale : eps;
+        zp = static_cast<double>(qmin) - rint(min_neg / scale);
+        zp = zp < qmin ? qmin : (zp > qmax ? qmax : zp);
+    }
+    *scale_f = static_cast<float>(scale);
+    *zp_f = static_cast<float>(static_cast<int>(zp));
+}
+
+__device__ __forceinline__ float sq_err(float x, float s, float z, float qmin, float qmax) {
+    const float y = dequantize_value(quantize_value(x, s, z, qmin, qmax), s, z);
+    const float d = fabsf(y - x);
+    return d * d;
+}
+
+// ---------------------------------------------------------------- per-channel: one wave per row
+
+template <int MAXV>   // cached floats per lane (row length <= 64*MAXV); MAXV == 0: re-read the row
+__global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __restrict__ w, int64_t rows, int cols,
+                                                                int quant_min, int quant_max, int symmetric, int side,
+                                                                int two_d, float* __restrict__ best_min,
+                                                                float* __restrict__ best_max, int* __restrict__ nfev_out) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t row = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    if (row >= rows) return;
+    const float* xr = w + row * cols;
+    constexpr int R = MAXV > 0 ? MAXV : 1;
+    float cache[R];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (MAXV > 0) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int j = lane + k * OSQ_WAVE;
+            cache[k] = j < cols ? xr[j] : 0.0f;
+            if (j < cols) { mn = fminf(mn, cache[k]); mx = fmaxf(mx, cache[k]); }
+        }
+    } else {
+        for (int j = lane; j < cols; j += OSQ_WAVE) { const float v = xr[j]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    Search S;                                    // every lane runs the identical state machine
+    S.init(mn, mx, quant_min, quant_max, symmetric, side, two_d);   // observer.py:500-517: the row's own extrema
+    const float qmin_f = static_cast<float>(quant_min), qmax_f = static_cast<float>(quant_max);
+    while (!S.done) {
+        float s, z;
+        loss_qparams(S.cand_min, S.cand_max, quant_min, quant_max, symmetric, &s, &z);
+        float part = 0.0f;
+        if (MAXV > 0) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int j = lane + k * OSQ_WAVE;
+                if (j < cols) part += sq_err(cache[k], s, z, qmin_f, qmax_f);
+            }
+        } else {
+            for (int j = lane; j < cols; j += OSQ_WAVE) part += sq_err(xr[j], s, z, qmin_f, qmax_f);
+        }
+        const double tot = wave_sum(static_cast<double>(part));
+        S.tell(static_cast<float>(tot / static_cast<double>(cols)));
+    }
+    if (lane == 0) {
+        best_min[row] = static_cast<float>(S.best_min);    // assignment into fp32 tensors (observer.py:504,516)
+        best_max[row] = static_cast<float>(S.best_max);
+        if (nfev_out) nfev_out[row] = S.nfev;
+    }
+}
+
+// ---------------------------------------------------------------- per-tensor: state in device memory
+
+struct TensorSearch {
+    Search S;
+    float scale, zp;          // fake-quant parameters of the pending candidate
+    int evals_launched;
+    int pad;
+};
+
+__global__ void msefast_tensor_init_kernel(TensorSearch* __restrict__ ts, const float* __restrict__ cur_minmax,
+                                           int quant_min, int quant_max, int symmetric, int side, int two_d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ts->S.init(cur_minmax[0], cur_minmax[1], quant_min, quant_max, symmetric, side, two_d);
+    loss_qparams(ts->S.cand_min, ts->S.cand_max, quant_min, quant_max, symmetric, &ts->scale, &ts->zp);
+    ts->evals_launched = 0;
+}
+
+// last workgroup: loss -> state machine -> next candidate
+__device__ __forceinline__ void tensor_search_advance(TensorSearch* ts, double total, double count) {
+    ts->S.tell(static_cast<float>(total / count));
+    if (!ts->S.done)
+        loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp);
+}
+
+__device__ __forceinline__ void block_sum_publish_finish(double part, double* partials, unsigned int* counters,
+                                                         TensorSearch* ts, double count) {
+    __shared__ double sh[kWavesPerBlock];
+    part = wave_sum(part);
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    if (lane == 0) sh[wv] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < kWavesPerBlock; ++k) a += sh[k];
+        publish_f64(&partials[blockIdx.x], a);
+    }
+    if (grid_last_block(counters, gridDim.x)) {
+        double a = 0.0;
+        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) a += consume_f64(&partials[k]);
+        a = wave_sum(a);
+        __syncthreads();
+        if (lane == 0) sh[wv] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < kWavesPerBlock; ++k) tot += sh[k];
+            tensor_search_advance(ts, tot, count);
+            grid_reset(counters, gridDim.x);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float4* __restrict__ x, int64_t n4,
+                                                                     const float* __restrict__ xt, int tail, int64_t n,
+                                                                     TensorSearch* __restrict__ ts,
+                                                                     double* __restrict__ partials,
+                                                                     unsigned int* __restrict__ counters) {
+    if (ts->S.done) return;                       // uniform: state only changes between launches
+    const float s = ts->scale, z = ts->zp;
+    const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    double acc = 0.0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += 2 * stride) {
+        const float4 a = x[i];
+        const bool two = (i + stride) < n4;
+        const float4 b = two ? x[i + stride] : a;
+        float p = sq_err(a.x, s, z, qmin, qmax) + sq_err(a.y, s, z, qmin, qmax) + sq_err(a.z, s, z, qmin, qmax) +
+                  sq_err(a.w, s, z, qmin, qmax);
+        if (two)
+            p += sq_err(b.x, s, z, qmin, qmax) + sq_err(b.y, s, z, qmin, qmax) + sq_err(b.z, s, z, qmin, qmax) +
+                 sq_err(b.w, s, z, qmin, qmax);
+        acc += static_cast<double>(p);
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc += static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax));
+    block_sum_publish_finish(acc, partials, counters, ts, static_cast<double>(n));
+}
+
+// masked / strided activations: one wave per token (valid tokens only), any strides
+__global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const float* __restrict__ x, osq_token_view v,
+                                                                      const int64_t* __restrict__ lengths, int vec,
+                                                                      TensorSearch* __restrict__ ts,
+                                                                      double* __restrict__ partials,
+                                                                      unsigned int* __restrict__ counters,
+                                                                      const double* __restrict__ valid_count) {
+    if (ts->S.done) return;
+    const float s = ts->scale, z = ts->zp;
+    const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t ntok = v.batch * v.tokens;
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+    const int64_t F = v.feat_outer * v.feat_inner;
+    double acc = 0.0;
+    for (int64_t tok = wave0; tok < ntok; tok += nwaves) {
+        const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
+        if (lengths && t >= lengths[b]) continue;
+        const float* base = x + b * v.stride_batch + t * v.stride_token;
+        float p = 0.0f;
+        if (vec) {           // feat_inner contiguous, 16-byte aligned segments
+            const int inner4 = static_cast<int>(v.feat_inner / 4);
+            const int64_t F4 = v.feat_outer * inner4;
+            for (int64_t j = lane; j < F4; j += OSQ_WAVE) {
+                const int64_t o = j / inner4, i = j - o * inner4;
+                const float4 a = reinterpret_cast<const float4*>(base + o * v.stride_outer)[i];
+                p += sq_err(a.x, s, z, qmin, qmax) + sq_err(a.y, s, z, qmin, qmax) + sq_err(a.z, s, z, qmin, qmax) +
+                     sq_err(a.w, s, z, qmin, qmax);
+            }
+        } else {
+            for (int64_t j = lane; j < F; j += OSQ_WAVE) {
+                const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
+                p += sq_err(base[o * v.stride_outer + i * v.stride_inner], s, z, qmin, qmax);
+            }
+        }
+        acc += static_cast<double>(p);
+    }
+    block_sum_publish_finish(acc, partials, counters, ts, valid_count[0]);
+}
+
+// number of observed elements = F * sum(min(len, T)) (observer.py:72-84), as a double for the mean
+__global__ void msefast_valid_count_kernel(const int64_t* __restrict__ lengths, int64_t B, int64_t T, int64_t F,
+                                           double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t tot = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        int64_t l = lengths ? lengths[b] : T;
+        l = l < 0 ? 0 : (l > T ? T : l);
+        tot += l;
+    }
+    out[0] = static_cast<double>(tot * F);
+}
+
+// commit a finished per-tensor search: running min/max (observer.py:535-536) or running mean
+// (observer.py:559-567) in float64 -- per-tensor results stay float64 in the reference
+// (torch.tensor(np.float64), observer.py:481,494) -- then qparams in float64 (observer.py:101-119).
+__global__ void msefast_commit_kernel(const TensorSearch* __restrict__ ts, int rule, int64_t cnt,
+                                      double* __restrict__ min_val, double* __restrict__ max_val, int quant_min,
+                                      int quant_max, int symmetric, float* __restrict__ scale_out,
+                                      void* __restrict__ zp_out, int zp_type, int* __restrict__ nfev_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double bmin = ts->S.best_min, bmax = ts->S.best_max;
+    double mn = min_val[0], mx = max_val[0];
+    if (rule == OSQ_UPDATE_AVERAGE) {
+        if (__builtin_isinf(mx)) { mn = bmin; mx = bmax; }
+        else { mn = mn * static_cast<double>(cnt) + bmin; mx = mx * static_cast<double>(cnt) + bmax; }
+        mn /= static_cast<double>(cnt + 1);
+        mx /= static_cast<double>(cnt + 1);
+    } else {
+        mn = bmin < mn ? bmin : mn;
+        mx = bmax > mx ? bmax : mx;
+    }
+    min_val[0] = mn;
+    max_val[0] = mx;
+    if (nfev_out) nfev_out[0] = ts->S.nfev;
+    if (scale_out) {
+        const double min_neg = mn < 0.0 ? mn : 0.0, max_pos = mx > 0.0 ? mx : 0.0;
+        const double eps = static_cast<double>(1e-8f);
+        double scale, zp = 0.0;
+        if (symmetric) {
+            const double m = -min_neg > max_pos ? -min_neg : max_pos;
+            scale = m / (static_cast<double>(quant_max - quant_min) / 2.0);
+            scale = scale > eps ? scale : eps;
+        } else {
+            scale = (max_pos - min_neg) / static_cast<double>(quant_max - quant_min);
+            scale = scale > eps ? scale : eps;
+            zp = static_cast<double>(quant_min) - rint(min_neg / scale);
+            zp = zp < quant_min ? quant_min : (zp > quant_max ? quant_max : zp);
+        }
+        scale_out[0] = static_cast<float>(scale);
+        if (zp_out) store_zp(zp_out, zp_type, 0, static_cast<float>(zp));
+    }
+}
+
+__global__ void msefast_done_kernel(const TensorSearch* __restrict__ ts, int* __restrict__ done_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) done_out[0] = ts->S.done;
+}
+
+static inline int grid_for(int64_t items, int per_block, int max_blocks) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return static_cast<int>(b);
+}
+
+}  // namespace osq
+
+using namespace osq;
+
+extern "C" size_t osq_msefast_state_bytes(void) { return sizeof(TensorSearch) + 64; }
+
+extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int quant_min, int quant_max, int symmetric,
+                                int one_side, int two_d, float* best_min, float* best_max, int32_t* nfev,
+                                osq_stream stream) {
+    OSQ_REQUIRE(w && best_min && best_max && rows > 0 && cols > 0, "msefast_rows: empty or null input");
+    OSQ_REQUIRE(cols < (1ll << 31), "msefast_rows: row too long");
+    OSQ_REQUIRE(one_side >= SIDE_NO && one_side <= SIDE_NEG, "msefast_rows: bad one_side");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = static_cast<int>((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int c = static_cast<int>(cols);
+#define OSQ_ROWS(M) hipLaunchKernelGGL(msefast_rows_kernel<M>, dim3(grid), dim3(kThreads), 0, st, w, rows, c, quant_min, \
+                                       quant_max, symmetric, one_side, two_d, best_min, best_max, nfev)
+    if (cols <= 64 * 4) OSQ_ROWS(4);
+    else if (cols <= 64 * 16) OSQ_ROWS(16);
+    else if (cols <= 64 * 48) OSQ_ROWS(48);
+    else OSQ_ROWS(0);
+#undef OSQ_ROWS
+    return check_launch("msefast_rows");
+}
+
+extern "C" int osq_msefast_tensor_begin(void* state, const float* cur_minmax, int quant_min, int quant_max,
+                                        int symmetric, int one_side, int two_d, osq_stream stream) {
+    OSQ_REQUIRE(state && cur_minmax, "msefast_tensor_begin: null pointer");
+    hipLaunchKernelGGL(msefast_tensor_init_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<TensorSearch*>(state), cur_minmax, quant_min, quant_max, symmetric, one_side, two_d);
+    return check_launch("msefast_tensor_begin");
+}
+
+extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_t n, int n_evals, void* workspace,
+                                             osq_stream stream) {
+    OSQ_REQUIRE(state && x && n > 0 && workspace && n_evals >= 0, "msefast_tensor_evals_flat: bad argument");
+    OSQ_REQUIRE(aligned16(x), "msefast_tensor_evals_flat: x must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace ws(workspace);
+    const int64_t n4 = n / 4;
+    const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
+    for (int e = 0; e < n_evals; ++e)
+        hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                           n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
+                           ws.doubles(), ws.counter(0));
+    return check_launch("msefast_tensor_evals_flat");
+}
+
+extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token_view* view,
+                                               const int64_t* lengths, int n_evals, void* workspace,
+                                               osq_stream stream) {
+    OSQ_REQUIRE(state && x && view && workspace && n_evals >= 0, "msefast_tensor_evals_tokens: bad argument");
+    const osq_token_view v = *view;
+    OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_evals_tokens: empty view");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace ws(workspace);
+    double* count = ws.doubles() + kMaxBlocks;        // behind the partials
+    hipLaunchKernelGGL(msefast_valid_count_kernel, dim3(1), dim3(64), 0, st, lengths, v.batch, v.tokens,
+                       v.feat_outer * v.feat_inner, count);
+    const int vec = v.stride_inner == 1 && v.feat_inner % 4 == 0 && aligned16(x) && v.stride_batch % 4 == 0 &&
+                    v.stride_token % 4 == 0 && (v.feat_outer == 1 || v.stride_outer % 4 == 0);
+    const int grid = grid_for(v.batch * v.tokens, kWavesPerBlock, kMaxBlocks);
+    for (int e = 0; e < n_evals; ++e)
+        hipLaunchKernelGGL(msefast_token_loss_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, vec,
+                           static_cast<TensorSearch*>(state), ws.doubles(), ws.counter(0), count);
+    return check_launch("msefast_tensor_evals_tokens");
+}
+
+extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream) {
+    OSQ_REQUIRE(state && done_out, "msefast_tensor_done: null pointer");
+    hipLaunchKernelGGL(msefast_done_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const TensorSearch*>(state), done_out);
+    return check_launch("msefast_tensor_done");
+}
+
+extern "C" int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt, double* min_val,
+                                         double* max_val, int quant_min, int quant_max, int symmetric,
+                                         float* scale_out, void* zero_point_out, int zp_type, int32_t* nfev,
+                                         osq_stream stream) {
+    OSQ_REQUIRE(state && min_val && max_val, "msefast_tensor_commit: null pointer");
+    OSQ_REQUIRE(update_rule == OSQ_UPDATE_RUNNING || update_rule == OSQ_UPDATE_AVERAGE, "msefast_tensor_commit: bad rule");
+    hipLaunchKernelGGL(msefast_commit_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const TensorSearch*>(state), update_rule, cnt, min_val, max_val, quant_min, quant_max,
+                       symmetric, scale_out, zero_point_out, zp_type, nfev);
+    return check_launch("msefast_tensor_commit");
+}

@@ -198,10 +198,27 @@ __device__ __forceinline__ unsigned int ordered_bits(float f) {
 __device__ __forceinline__ float from_ordered_bits(unsigned int u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+// double add-reduction with DPP: the xor / mirror patterns are symmetric, so after each step
+// both partners hold the same partial sum; four row results are combined through readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+__device__ __forceinline__ double lane_value_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), lane);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OSQ_WAVE);
-    return v;
+    v += dpp_move_f64<0xB1>(v);     // quad_perm:[1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);     // quad_perm:[2,3,0,1]
+    v += dpp_move_f64<0x141>(v);    // row_half_mirror
+    v += dpp_move_f64<0x140>(v);    // row_mirror
+    return (lane_value_f64(v, 0) + lane_value_f64(v, 16)) + (lane_value_f64(v, 32) + lane_value_f64(v, 48));
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 

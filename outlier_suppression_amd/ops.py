@@ -352,6 +352,90 @@ def observer_update(cur_min, cur_max, rule, cnt, min_val, max_val):
 
 
 # ---------------------------------------------------------------------------------------
+# MSEFast
+# ---------------------------------------------------------------------------------------
+
+SIDE = {"no": 0, "pos": 1, "neg": 2}
+
+
+def batch_minmax(x, observation_mask=None, seq_pos=-1):
+    """(min, max) of this tensor alone (padding excluded) as a 2-float device tensor; no state touched."""
+    cur = torch.empty(2, dtype=torch.float32, device=x.device)
+    if observation_mask is not None:
+        tmin, tmax, batch, tokens, lengths = token_minmax(x, seq_pos, observation_mask)
+        token_range_finalize(tmin, tmax, batch, tokens, lengths, False, 1.0, UPDATE_NONE, 0, None, None, 0, 1, False,
+                             None, cur)
+    else:
+        observe_flat(x, UPDATE_NONE, 0, None, None, 0, 1, False, None, cur)
+    return cur
+
+
+def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
+    """One bounded-Brent search per channel (observer.py:496-517), all rows in one launch."""
+    lib = _hip.load()
+    _hip.require_device(w)
+    _check_f32(w)
+    ch_axis = ch_axis % w.dim()
+    if ch_axis != 0:                                  # observer.py:11-21: channel axis first, rest flattened
+        order = list(range(w.dim()))
+        order[ch_axis], order[0] = 0, ch_axis
+        w = w.permute(order)
+    rows2d = w.reshape(w.shape[0], -1).contiguous()
+    rows, cols = rows2d.shape
+    bmin = torch.empty(rows, dtype=torch.float32, device=w.device)
+    bmax = torch.empty(rows, dtype=torch.float32, device=w.device)
+    nfev = torch.empty(rows, dtype=torch.int32, device=w.device)
+    _hip.check(lib.osq_msefast_rows(_hip.ptr(rows2d), rows, cols, int(quant_min), int(quant_max), int(bool(symmetric)),
+                                    SIDE[one_side], int(bool(two_d)), _hip.ptr(bmin), _hip.ptr(bmax), _hip.ptr(nfev),
+                                    _hip.stream_ptr(w.device)), "msefast_rows")
+    return bmin, bmax, nfev
+
+
+def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
+                   rule, cnt, min_val, max_val, sink=None, chunk=None):
+    """Per-tensor search (observer.py:497-499): loss launches are enqueued in chunks and the converged
+    flag is read back once per chunk (the reference syncs on every evaluation).  min_val/max_val: float64."""
+    lib = _hip.load()
+    dev = x.device
+    st = _hip.stream_ptr(dev)
+    state = torch.zeros(int(lib.osq_msefast_state_bytes()), dtype=torch.uint8, device=dev)
+    ws = _hip.workspace(dev)
+    _hip.check(lib.osq_msefast_tensor_begin(_hip.ptr(state), _hip.ptr(cur), int(quant_min), int(quant_max),
+                                            int(bool(symmetric)), SIDE[one_side], int(bool(two_d)), st), "msefast_begin")
+    if observation_mask is not None or not is_dense(x):
+        lengths = observation_mask
+        if lengths is not None and lengths.dtype != torch.int64:
+            lengths = lengths.to(torch.int64)
+        if observation_mask is None:
+            x = x.contiguous()
+            view = None
+        else:
+            view = token_view(x, seq_pos, lengths.numel())
+    else:
+        view, lengths = None, None
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    chunk = chunk or (64 if two_d else 32)
+    launched = 0
+    while True:
+        if view is None:
+            _hip.check(lib.osq_msefast_tensor_evals_flat(_hip.ptr(state), _hip.ptr(x), x.numel(), chunk, _hip.ptr(ws), st),
+                       "msefast_evals_flat")
+        else:
+            _hip.check(lib.osq_msefast_tensor_evals_tokens(_hip.ptr(state), _hip.ptr(x), ctypes.byref(view),
+                                                           _hip.ptr(lengths), chunk, _hip.ptr(ws), st), "msefast_evals_tokens")
+        launched += chunk
+        _hip.check(lib.osq_msefast_tensor_done(_hip.ptr(state), _hip.ptr(done), st), "msefast_done")
+        if int(done.item()) or launched > 500 * 500:
+            break
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    nfev = torch.empty(1, dtype=torch.int32, device=dev)
+    _hip.check(lib.osq_msefast_tensor_commit(_hip.ptr(state), rule, int(cnt), _hip.ptr(min_val), _hip.ptr(max_val),
+                                             int(quant_min), int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
+                                             _hip.ptr(nfev), st), "msefast_commit")
+    return nfev
+
+
+# ---------------------------------------------------------------------------------------
 # gamma migration
 # ---------------------------------------------------------------------------------------
 

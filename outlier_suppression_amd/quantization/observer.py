@@ -166,3 +166,67 @@ class AvgPruneMinMaxObserver(ObserverBase):
         else:
             self._observe_flat(x, sink)   # pooler / classifier inputs: observer.py:220-226
         self._bump()
+
+
+class MSEFastObserver(ObserverBase):
+    """observer.py:412-536: clipping range that minimises the quantisation MSE, found by bounded
+    Brent search (1-D for symmetric or one-sided data, nested 2-D otherwise); running min/max.
+
+    Per-tensor statistics are float64 like the reference's (scipy hands float64 results,
+    observer.py:481,494); per-channel ones fp32 (observer.py:504,516).  The data's sidedness is
+    decided on the first observed tensor (observer.py:528-529) -- one host read, once.
+    """
+
+    update_rule = UPDATE_RUNNING
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.p = 2.0
+        self.num = 100
+        self.one_side_dist = None
+        self.last_nfev = None
+
+    def _decide_side(self, cur):
+        if self.one_side_dist is None:
+            mn, mx = cur.tolist()
+            self.one_side_dist = "pos" if mn >= 0.0 else "neg" if mx <= 0.0 else "no"
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        if observation_mask is not None:
+            assert self.ch_axis == -1
+        cur = ops.batch_minmax(x, observation_mask, seq_pos)
+        self._decide_side(cur)
+        two_d = not (self.one_side_dist != "no" or self.symmetric)
+        if self.ch_axis == -1:
+            if self.min_val.dtype != torch.float64 or self.min_val.device != x.device:
+                self.min_val = self.min_val.to(device=x.device, dtype=torch.float64)
+                self.max_val = self.max_val.to(device=x.device, dtype=torch.float64)
+            self.last_nfev = ops.msefast_tensor(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
+                                                self.symmetric, self.one_side_dist, two_d, self.update_rule,
+                                                self._counter(), self.min_val, self.max_val, sink)
+        else:
+            bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
+                                                          self.symmetric, self.one_side_dist, two_d)
+            self._home(x.device, bmin.numel())
+            ops.observer_update(bmin, bmax, self.update_rule, self._counter(), self.min_val, self.max_val)
+            if sink is not None and sink.scale is not None:
+                ops.calculate_qparams(self.min_val, self.max_val, self.quant_min, self.quant_max, self.symmetric,
+                                      scale_out=sink.scale, zero_point_out=sink.zero_point)
+        self._bump()
+
+    def forward(self, x_orig, observation_mask=None, seq_pos=-1):
+        if x_orig.numel() == 0:
+            return x_orig
+        self.observe_into(x_orig.detach(), observation_mask, seq_pos, None)
+        return None     # the reference's MSEFastObserver.forward returns nothing (observer.py:520-536)
+
+
+class AvgMSEFastObserver(MSEFastObserver):
+    """observer.py:539-567: per-batch MSE-optimal range, averaged over batches; per-tensor only."""
+
+    update_rule = UPDATE_AVERAGE
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.cnt = 0
+        assert self.ch_axis == -1

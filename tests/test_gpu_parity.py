@@ -385,3 +385,80 @@ def test_empty_and_errors(dev):
         ops.fake_quant_per_tensor(torch.randn(4), s, z, 0, 63)       # CPU tensor: no fallback
     with pytest.raises(TypeError):
         ops.fake_quant_per_tensor(torch.randn(4, device=dev).half(), s, z, 0, 63)
+
+
+# ----------------------------------------------------------------------------------- MSEFast
+
+def test_msefast_golden(golden, dev):
+    """Device-side bounded Brent against the reference's scipy-driven search.  The search compares
+    fp32 losses whose summation order differs (torch CPU vs wave-parallel), so iterates part ways
+    late: ranges agree to <5e-4 relative (the NumPy oracle itself is 6e-5 from the reference),
+    evaluation counts to ~35 %."""
+    from outlier_suppression_amd.quantization.quantized_module import ObserverDict
+    g = golden("msefast")
+    for k in range(int(g["n"])):
+        cls, bit, sym, ch_axis, reps, nfev, osd = (str(v) for v in g[f"c{k}_info"])
+        bit, sym, ch_axis, reps, nfev = int(bit), bool(int(sym)), int(ch_axis), int(reps), int(nfev)
+        ob = ObserverDict[cls](bit=bit, symmetric=sym, ch_axis=ch_axis).to(dev)
+        x = g[f"c{k}_x"]
+        total = 0
+        for r in range(reps):
+            ret = ob(T(x[r] if reps > 1 else x, dev))
+            assert ret is None
+            total += int(ob.last_nfev.sum().item())
+            np.testing.assert_allclose(N(ob.min_val), g[f"c{k}_min"][r], rtol=5e-4, atol=1e-6)
+            np.testing.assert_allclose(N(ob.max_val), g[f"c{k}_max"][r], rtol=5e-4, atol=1e-6)
+        assert ob.one_side_dist == osd
+        assert ob.min_val.dtype == (torch.float64 if ch_axis == -1 else torch.float32)
+        assert abs(total - nfev) <= max(6, 0.35 * nfev), (cls, total, nfev)
+
+
+def test_msefast_loss_is_not_worse_than_oracle(dev):
+    """At the returned range the quantisation MSE must match the oracle's optimum (the quantity the
+    observer minimises), for weights of BERT-base row lengths and a masked activation."""
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver, AvgMSEFastObserver
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(8)
+    for cols, bit in ((768, 4), (3072, 4), (200, 6), (3100, 4)):
+        w = torch.randn(6, cols, generator=gen) * 0.05
+        ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
+        ob(w.to(dev))
+        st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
+        OB.observe_msefast(st, w.numpy())
+        np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=5e-4)
+        np.testing.assert_allclose(N(ob.min_val), st.min_val, rtol=5e-4)
+        for c in range(6):
+            ours = OB.mse_loss(w[c].numpy(), N(ob.min_val)[c], N(ob.max_val)[c], st.quant_min, st.quant_max, True)
+            ref = OB.mse_loss(w[c].numpy(), st.min_val[c], st.max_val[c], st.quant_min, st.quant_max, True)
+            assert ours <= ref * (1 + 2e-3)
+    x = torch.randn(8, 32, 96, generator=gen)
+    x[..., 3] *= 12
+    L = torch.randint(4, 33, (8,), generator=gen)
+    for sym in (True, False):
+        ob = AvgMSEFastObserver(bit=6, symmetric=sym).to(dev)
+        st = OB.ObserverState(bit=6, symmetric=sym)
+        for it in range(2):
+            ob(x.to(dev) * (it + 1), L.to(dev), 1)
+            OB.observe_msefast(st, x.numpy() * (it + 1), L.numpy(), 1, average=True)
+            np.testing.assert_allclose(N(ob.min_val), st.min_val, rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=1e-3, atol=1e-5)
+        assert ob.cnt == 2
+
+
+def test_msefast_through_quantizer(dev):
+    from outlier_suppression_amd.quantization import Quantizer
+    from oracle import observer_oracle as OB
+    cfg = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
+    lin = torch.nn.Linear(96, 10)
+    ql = Quantizer(lin, cfg).to(dev)
+    ql.weight_fake_quant.enable_observer()
+    ql.weight_fake_quant.enable_fake_quant()
+    x = torch.randn(3, 96, device=dev)
+    y = ql(x)
+    assert y.shape == (3, 10)
+    fq = ql.weight_fake_quant
+    st = OB.ObserverState(bit=4, symmetric=True, ch_axis=0)
+    OB.observe_msefast(st, lin.weight.detach().numpy())
+    s_o, _ = st.qparams()
+    np.testing.assert_allclose(N(fq.scale), s_o, rtol=5e-4)
+    assert fq.scale.shape == (10,) and fq.zero_point.dtype == torch.int32

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Model-level golden vectors: run the REFERENCE's quantized BERT pipeline on a tiny random BERT.
+
+Build-container only (imports /root/reference unmodified, CPU).  Mirrors the order of
+quant_transformer/solver/ptq_glue_quant.py:212-253 with the reference's own functions:
+quantize (QuantizedBertForSequenceClassification) -> prepare fp input/output -> delay_ln
+(gamma migration) -> weight calibration -> set_observer_name -> token_wise_clipping.find_ratio
+-> learn_scale -> enable_quantization -> logits.  Stores DATA ONLY: the seeded FP weights, the
+calibration batches, and what the reference produced at every stage (logits, per-ratio losses,
+every quantizer's scale / zero_point).
+
+Process-local shims (no reference file is touched): seaborn stub, identity .cuda(), and the
+transformers-4.18 names the reference imports that transformers 5.x moved or dropped
+(SURVEY.md 8c).
+"""
+import copy
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("OSQ_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def import_reference():
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    import transformers.file_utils as fu
+    import transformers.utils as tu
+    for name in ("apply_chunking_to_forward", "prune_linear_layer"):
+        if not hasattr(mu, name):
+            setattr(mu, name, getattr(pu, name))
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = lambda *a, **k: (set(), None)
+    for name in ("add_code_sample_docstrings", "add_start_docstrings", "add_start_docstrings_to_model_forward",
+                 "replace_return_docstrings", "ModelOutput"):
+        if not hasattr(fu, name):
+            setattr(fu, name, getattr(tu, name, lambda *a, **k: (lambda f: f)))
+    # transformers 4.18 semantics of the two ModuleUtilsMixin helpers the reference calls (quant_bert.py:557-564)
+    mu.ModuleUtilsMixin.get_extended_attention_mask = \
+        lambda self, attention_mask, input_shape, device=None: (1.0 - attention_mask[:, None, None, :].to(torch.float32)) * -10000.0
+    mu.ModuleUtilsMixin.get_head_mask = lambda self, head_mask, num_hidden_layers, *a, **k: [None] * num_hidden_layers
+    sys.path.insert(0, REF)
+    from quant_transformer.model import quant_bert
+    from quant_transformer.solver import gamma_migration, token_wise_clipping
+    from quant_transformer.quantization import state
+    from quant_transformer.quantization.fake_quant import QuantizeBase
+    return quant_bert, gamma_migration, token_wise_clipping, state, QuantizeBase
+
+
+def patch_hf_bert(model):
+    """Attributes the 4.18-era wrappers read from the HF modules and 5.x no longer sets."""
+    model.bert.embeddings.position_embedding_type = "absolute"
+    model.bert.encoder.gradient_checkpointing = False
+    for layer in model.bert.encoder.layer:
+        layer.attention.pruned_heads = set()
+        layer.attention.self.position_embedding_type = "absolute"
+        if not hasattr(layer, "chunk_size_feed_forward"):
+            layer.chunk_size_feed_forward = 0
+    return model
+
+
+def quantizer_table(model, QuantizeBase):
+    names, scales, zps = [], [], []
+    for n, m in model.named_modules():
+        if isinstance(m, QuantizeBase):
+            names.append(n)
+            scales.append(m.scale.detach().reshape(-1).to(torch.float64).numpy())
+            zps.append(m.zero_point.detach().reshape(-1).to(torch.float64).numpy())
+    return names, scales, zps
+
+
+def main():
+    QB, GM, TWC, ST, QuantizeBase = import_reference()
+    from transformers import BertConfig, BertForSequenceClassification
+    torch.set_num_threads(1)
+    torch.manual_seed(20240929)
+    cfg = BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                     max_position_embeddings=40, num_labels=2, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, type_vocab_size=2)
+    fp = patch_hf_bert(BertForSequenceClassification(cfg).eval())
+    with torch.no_grad():   # make LayerNorm gammas non-trivial, with outliers, as in real checkpoints (paper Fig. 1)
+        g = torch.Generator().manual_seed(7)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(torch.rand(32, generator=g) * 1.2 + 0.4)
+                m.weight[5] = 4.0
+                m.bias.copy_(torch.randn(32, generator=g) * 0.2)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0)      # livelier activations than init std 0.02 gives
+    out = {f"sd::{k}": v.numpy() for k, v in fp.state_dict().items()}
+
+    B, T, NB = 4, 16, 4
+    g = torch.Generator().manual_seed(99)
+    batches = []
+    for b in range(NB):
+        ids = torch.randint(1, 120, (B, T), generator=g)
+        L = torch.randint(3, T + 1, (B,), generator=g)
+        L[b % B] = T
+        mask = (torch.arange(T)[None, :] < L[:, None]).long()
+        ids = ids * mask
+        batches.append({"input_ids": ids, "attention_mask": mask, "token_type_ids": torch.zeros_like(ids)})
+    out["input_ids"] = np.stack([b["input_ids"].numpy() for b in batches])
+    out["attention_mask"] = np.stack([b["attention_mask"].numpy() for b in batches])
+
+    with torch.no_grad():
+        out["logits_hf_fp"] = np.stack([fp(**b).logits.numpy() for b in batches])
+
+    a_q = Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    config_quant = Cfg(a_qconfig=a_q, w_qconfig=w_q)
+    config_model = Cfg(model_type="bert", task_type="glue")
+
+    model = QB.QuantizedBertForSequenceClassification(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
+                                                      is_remove_padding=True).eval()
+    with torch.no_grad():
+        fp_output = [model(**b)[0].detach() for b in batches]          # prepare_input_output, ptq_glue_quant.py:94-107
+    out["logits_wrapped_fp"] = np.stack([o.numpy() for o in fp_output])
+
+    model = GM.delay_ln(model, config_quant, config_model)             # ptq_glue_quant.py:230-232
+    with torch.no_grad():
+        out["logits_after_gamma"] = np.stack([model(**b)[0].numpy() for b in batches])
+    out["module_names"] = np.array([n for n, _ in model.named_modules()])
+
+    ST.enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")    # :234-235
+    with torch.no_grad():
+        model(**batches[0])
+    ST.disable_all(model)                                              # :237-238
+    ST.set_observer_name(model)
+
+    # token_wise_clipping.find_ratio (token_wise_clipping.py:50-66) with a short grid
+    TWC.task_type, TWC.model_type = "glue", "bert"
+    losses = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            msg = record.getMessage()
+            if msg.startswith("the ratio is"):
+                losses.append(float(msg.split("the loss is")[1]))
+    h = Grab()
+    TWC.logger.addHandler(h)
+    TWC.logger.setLevel(logging.INFO)
+    trainer = types.SimpleNamespace(model=model)
+    iters, step = 6, 0.05
+    TWC.find_ratio(trainer, batches, fp_output, {"iters": iters, "step": step})
+    TWC.logger.removeHandler(h)
+    out["twc_losses"] = np.array(losses, dtype=np.float64)
+    out["twc_grid"] = np.array([iters, step])
+    names, scales, zps = quantizer_table(model, QuantizeBase)
+    out["q_names"] = np.array(names)
+    for i, (s, z) in enumerate(zip(scales, zps)):
+        out[f"q_after_twc_scale::{i}"], out[f"q_after_twc_zp::{i}"] = s, z
+    out["best_ratio"] = np.array([m.observer.percentile for n, m in model.named_modules()
+                                  if isinstance(m, QuantizeBase) and "act" in n][:1])
+
+    TWC.enable_quantization(model)                                     # activations quantized, weights FP
+    with torch.no_grad():
+        out["logits_act_quant"] = np.stack([model(**b)[0].numpy() for b in batches])
+
+    TWC.learn_scale(trainer, batches, fp_output, {"lr": 1e-3, "epoch": 2})   # :72-108 (larger lr so the step is visible)
+    names, scales, zps = quantizer_table(model, QuantizeBase)
+    for i, (s, z) in enumerate(zip(scales, zps)):
+        out[f"q_after_learn_scale::{i}"], out[f"q_after_learn_zp::{i}"] = s, z
+
+    ST.enable_quantization(model)                                      # ptq_glue_quant.py:251: weights + activations
+    with torch.no_grad():
+        out["logits_full_quant"] = np.stack([model(**b)[0].numpy() for b in batches])
+
+    path = os.path.join(OUT, "bert_tiny_pipeline.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(names), "quantizers; losses", losses)
+    print("logit drift gamma:", np.abs(out["logits_after_gamma"] - out["logits_wrapped_fp"]).max(),
+          "act-quant:", np.abs(out["logits_act_quant"] - out["logits_wrapped_fp"]).max(),
+          "full:", np.abs(out["logits_full_quant"] - out["logits_wrapped_fp"]).max())
+
+
+if __name__ == "__main__":
+    main()

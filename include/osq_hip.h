@@ -185,6 +185,21 @@ int osq_token_range_finalize(const float* token_min, const float* token_max,
                              float* scale_out, void* zero_point_out, int zp_type,
                              osq_stream stream);
 
+/* Grid-search form of the same step (token_wise_clipping.py:50-66 calls the observer pass once per
+ * candidate percentile although, with fake-quant off, the activations -- hence the per-token
+ * extrema -- are identical for every candidate).  The caller keeps the per-token extrema of
+ * every (quantizer, batch) pair: problem p = quantizer*n_batches + batch occupies
+ * token_min/token_max[p*problem_stride ...], all with the same batch x tokens geometry;
+ * lengths is [n_batches, batch]; prune_flags[quantizer] == 0 for 'attention_probs'
+ * quantizers.  One launch re-thresholds all pairs for `percentile` and writes each pair's
+ * (min, max) to cur_table[(batch_index*n_quantizers + quantizer)*2] -- per-batch statistics
+ * that are then replayed in batch order with osq_observer_update. */
+int osq_token_range_finalize_batched(const float* token_min, const float* token_max,
+                                     int64_t problem_stride, int n_quantizers, int n_batches,
+                                     int64_t batch, int64_t tokens, const int64_t* lengths,
+                                     const int32_t* prune_flags, double percentile,
+                                     float* cur_table, osq_stream stream);
+
 /* Running statistic for a batch (min, max) that is already known -- the replay step
  * of sharded calibration (gathered per-batch statistics applied in global batch
  * order, observer.py:194-202).  cur_min/cur_max: n entries. */

@@ -343,11 +343,29 @@ __device__ __forceinline__ unsigned int level_shift(unsigned int width) {
 #define OSQ_STAMP(k) do { } while (0)
 #endif
 
+// Batched form (token-wise-clipping grid search): workgroup p = quantizer*n_batches + batch works on
+// token arrays at p*problem_stride, lengths of its batch, prune flag of its quantizer, and writes
+// its (min, max) to cur[(batch*n_quantizers + quantizer)*2] -- the [batches, quantizers, 2] table
+// that calibration.replay() consumes.  n_batches == 0: the single-problem call.
+struct FinalBatch {
+    int64_t problem_stride;
+    int n_batches, n_quantizers;
+    const int* prune_flags;
+};
+
 template <int SLOTS>
 __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const float* __restrict__ tok_min,
                                                                        const float* __restrict__ tok_max, int64_t B,
                                                                        int64_t T, const int64_t* __restrict__ lengths,
-                                                                       int prune, float q, Finish fin) {
+                                                                       int prune, float q, Finish fin, FinalBatch fb) {
+    if (fb.n_batches > 0) {
+        const int p = blockIdx.x, qi = p / fb.n_batches, bi = p - qi * fb.n_batches;
+        tok_min += static_cast<int64_t>(p) * fb.problem_stride;
+        tok_max += static_cast<int64_t>(p) * fb.problem_stride;
+        if (lengths) lengths += static_cast<int64_t>(bi) * B;
+        prune = fb.prune_flags ? fb.prune_flags[qi] : prune;
+        fin.cur += 2 * (static_cast<int64_t>(bi) * fb.n_quantizers + qi);
+    }
     constexpr bool CACHED = SLOTS > 0;
     constexpr int R = CACHED ? SLOTS : 1;
     constexpr int kWaves = kFinalThreads / OSQ_WAVE;
@@ -787,9 +805,10 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
+    const FinalBatch fb{0, 0, 0, nullptr};
 #define OSQ_LAUNCH_FINAL(S)                                                                                        \
     hipLaunchKernelGGL(token_finalize_kernel<S>, dim3(1), dim3(kFinalThreads), 0, st, token_min, token_max, batch, \
-                       tokens, lengths, prune, qf, fin)
+                       tokens, lengths, prune, qf, fin, fb)
     if (per_thread <= 4) OSQ_LAUNCH_FINAL(4);
     else if (per_thread <= 8) OSQ_LAUNCH_FINAL(8);
     else if (per_thread <= 16) OSQ_LAUNCH_FINAL(16);
@@ -797,4 +816,30 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     else OSQ_LAUNCH_FINAL(0);
 #undef OSQ_LAUNCH_FINAL
     return check_launch("token_range_finalize");
+}
+
+extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,
+                                                int n_quantizers, int n_batches, int64_t batch, int64_t tokens,
+                                                const int64_t* lengths, const int32_t* prune_flags, double percentile,
+                                                float* cur_table, osq_stream stream) {
+    OSQ_REQUIRE(token_min && token_max && cur_table && batch > 0 && tokens > 0, "token_range_finalize_batched: empty or null input");
+    OSQ_REQUIRE(n_quantizers > 0 && n_batches > 0 && problem_stride >= batch * tokens, "token_range_finalize_batched: bad table shape");
+    OSQ_REQUIRE(percentile >= 0.0 && percentile <= 1.0, "token_range_finalize_batched: percentile outside [0, 1]");
+    OSQ_REQUIRE(batch * tokens < (1ll << 31), "token_range_finalize_batched: more than 2^31 token slots");
+    const Finish fin{OSQ_UPDATE_NONE, 0, nullptr, nullptr, cur_table, 0, 1, 0, nullptr, nullptr, 0};
+    const FinalBatch fb{problem_stride, n_batches, n_quantizers, prune_flags};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float qf = static_cast<float>(percentile);
+    const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
+    const dim3 grid(static_cast<unsigned>(n_quantizers) * static_cast<unsigned>(n_batches));
+#define OSQ_LAUNCH_FINAL(S)                                                                                     \
+    hipLaunchKernelGGL(token_finalize_kernel<S>, grid, dim3(kFinalThreads), 0, st, token_min, token_max, batch, \
+                       tokens, lengths, 1, qf, fin, fb)
+    if (per_thread <= 4) OSQ_LAUNCH_FINAL(4);
+    else if (per_thread <= 8) OSQ_LAUNCH_FINAL(8);
+    else if (per_thread <= 16) OSQ_LAUNCH_FINAL(16);
+    else if (per_thread <= 32) OSQ_LAUNCH_FINAL(32);
+    else OSQ_LAUNCH_FINAL(0);
+#undef OSQ_LAUNCH_FINAL
+    return check_launch("token_range_finalize_batched");
 }

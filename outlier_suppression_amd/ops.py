@@ -342,6 +342,20 @@ def token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, percentile, 
                                             _hip.stream_ptr(tmin.device)), "token_range_finalize")
 
 
+def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, batch, tokens, lengths, prune_flags,
+                                 percentile, cur_table):
+    """Re-threshold the cached per-token extrema of every (quantizer, batch) pair in ONE launch.
+    token_min/token_max: [n_quantizers, n_batches, batch*tokens] fp32; lengths: [n_batches, batch] int64 or None;
+    prune_flags: [n_quantizers] int32; cur_table: [n_batches, n_quantizers, 2] fp32 (written)."""
+    lib = _hip.load()
+    _hip.require_device(token_min, token_max, lengths, prune_flags, cur_table)
+    _hip.check(lib.osq_token_range_finalize_batched(_hip.ptr(token_min), _hip.ptr(token_max), token_min.stride(1),
+                                                    int(n_quantizers), int(n_batches), int(batch), int(tokens),
+                                                    _hip.ptr(lengths), _hip.ptr(prune_flags), float(percentile),
+                                                    _hip.ptr(cur_table), _hip.stream_ptr(token_min.device)),
+               "token_range_finalize_batched")
+
+
 def observer_update(cur_min, cur_max, rule, cnt, min_val, max_val):
     lib = _hip.load()
     _hip.require_device(cur_min, cur_max, min_val, max_val)

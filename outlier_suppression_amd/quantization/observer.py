@@ -37,6 +37,8 @@ class ObserverBase(nn.Module):
         self.register_buffer("min_val", torch.tensor(float("inf")))
         self.register_buffer("max_val", torch.tensor(float("-inf")))
         self._capture = None   # sharded calibration: 2-float device slot that receives this batch's (min, max)
+        self._token_cache = None   # cached grid search: (token_min, token_max) rows that receive the per-token extrema
+        self._last_site = None     # ("tokens", batch, tokens, lengths) or ("flat",) of the most recent observation
 
     # -- attributes the solver code sets (state.py:65-69, token_wise_clipping.py:16-17)
     def set_name(self, name):
@@ -68,11 +70,16 @@ class ObserverBase(nn.Module):
         return getattr(self, "cnt", 0)
 
     def _bump(self):
-        if hasattr(self, "cnt") and self._capture is None:
+        if hasattr(self, "cnt") and self._capture is None and self._token_cache is None:
             self.cnt += 1
 
     def _observe_tokens(self, x, lengths, seq_pos, prune, sink):
+        if self._token_cache is not None:     # keep the per-token extrema; thresholds are applied later, per candidate
+            _, _, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths, out=self._token_cache)
+            self._last_site = ("tokens", batch, tokens, lengths)
+            return
         tmin, tmax, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths)
+        self._last_site = ("tokens", batch, tokens, lengths)
         self._home(x.device)
         rule, cur = self.update_rule, None
         if self._capture is not None:      # record this batch only; calibration.replay() applies the rule later
@@ -82,6 +89,7 @@ class ObserverBase(nn.Module):
                                  self.quant_min, self.quant_max, self.symmetric, sink, cur)
 
     def _observe_flat(self, x, sink):
+        self._last_site = ("flat",)
         self._home(x.device)
         rule, cur = self.update_rule, None
         if self._capture is not None:

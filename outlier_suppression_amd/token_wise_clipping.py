@@ -126,3 +126,125 @@ def token_wise_clipping(trainer, fp_input, fp_output, config):
     step, iters = cac_step_iters(config.quant.a_qconfig.bit, trainer.args.per_device_eval_batch_size, config.data)
     return find_ratio(trainer, fp_input, fp_output, {"iters": getattr(config.quant, "iters", iters),
                                                      "step": getattr(config.quant, "step", step)})
+
+
+# ---------------------------------------------------------------------------------------------
+# MI355X-first coarse search: per-token extrema cached once, one re-threshold launch per candidate,
+# batches sharded over ranks with one small all-gather per candidate.
+# ---------------------------------------------------------------------------------------------
+
+def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group=None):
+    """Same result as ``find_ratio`` with half the model forwards.
+
+    In the observer pass of every candidate the fake-quantizers are off (token_wise_clipping.py:12-19),
+    so the activations -- and therefore each token's (min, max) at every quantizer -- do not depend on
+    the candidate percentile.  Phase A runs the FP model ONCE over the calibration batches and keeps
+    the per-token extrema of every (quantizer, batch) pair on the device (BERT-base, 8x32x128:
+    98 x 8 x 2 x 4096 floats = 26 MB).  Per candidate: ONE launch re-thresholds all pairs
+    (``osq_token_range_finalize_batched``), the [batches, quantizers, 2] table is replayed in batch
+    order (running mean, observer.py:194-202) and the quantized forward pass measures the loss.
+
+    Multi-GPU: ``fp_input`` / ``fp_output`` are THIS rank's batches (``calibration.shard_batches``
+    order); the statistics table and the per-batch losses are all-gathered (RCCL) and consumed in
+    global batch order on every rank, so every rank picks the same percentile and ends with
+    bit-identical scales to the single-GPU run.
+    """
+    import numpy as np
+    import torch.distributed as dist
+    from . import calibration, ops
+
+    model = trainer.model
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    n_local = len(fp_input)
+    n_batches = n_batches if n_batches is not None else n_local * world
+    rows = (n_batches + world - 1) // world
+    qs = _act_quantizers(model)
+    n_q = len(qs)
+    dev = next(model.parameters()).device
+
+    # ---- discover each site's kind with one captured forward (also yields batch 0's statistics)
+    set_ratio(model, 1.0)
+    flat_table = torch.zeros(rows, n_q, 2, dtype=torch.float32, device=dev)
+    if n_local == 0:
+        raise ValueError("find_ratio_cached: this rank has no calibration batch")
+    for i, (_, q) in enumerate(qs):
+        q.observer._capture = flat_table[0, i]
+    with torch.no_grad():
+        model(**fp_input[0])
+    sites = [q.observer._last_site for _, q in qs]
+    for _, q in qs:
+        q.observer._capture = None
+    tok_cols = [i for i, s in enumerate(sites) if s is not None and s[0] == "tokens"]
+    geoms = {(sites[i][1], sites[i][2]) for i in tok_cols}
+    if len(geoms) > 1:
+        if world > 1:
+            raise NotImplementedError("find_ratio_cached: quantizers with different token geometries are not sharded yet")
+        return find_ratio(trainer, fp_input, fp_output, param)
+    n_tok = len(tok_cols)
+    masked = n_tok > 0 and sites[tok_cols[0]][3] is not None
+    if n_tok:
+        batch, tokens = next(iter(geoms))
+        slots = batch * tokens
+        tok_min = torch.empty(n_tok, rows, slots, dtype=torch.float32, device=dev)
+        tok_max = torch.empty(n_tok, rows, slots, dtype=torch.float32, device=dev)
+        lengths = torch.zeros(rows, batch, dtype=torch.int64, device=dev) if masked else None
+        prune_flags = torch.tensor([0 if "attention_probs" in qs[i][1].observer.name else 1 for i in tok_cols],
+                                   dtype=torch.int32, device=dev)
+        col_index = torch.tensor(tok_cols, device=dev)
+        cur_tok = torch.zeros(rows, n_tok, 2, dtype=torch.float32, device=dev)
+
+    # ---- phase A: one FP pass, per-token extrema of every (quantizer, batch) kept on the device
+    with torch.no_grad():
+        for j, batch_in in enumerate(fp_input):
+            for k, i in enumerate(tok_cols):
+                qs[i][1].observer._token_cache = (tok_min[k, j], tok_max[k, j])
+            for i, (_, q) in enumerate(qs):
+                if i not in tok_cols:
+                    q.observer._capture = flat_table[j, i]
+            model(**batch_in)
+            if masked:
+                lengths[j].copy_(qs[tok_cols[0]][1].observer._last_site[3])
+    for _, q in qs:
+        q.observer._token_cache = None
+        q.observer._capture = None
+
+    def apply_ratio(ratio):
+        """Statistics of every activation quantizer for this candidate (what calibrate() leaves behind)."""
+        for _, q in qs:
+            q.observer.set_percentile(ratio)
+            q.observer.cnt = 0
+            q.observer.min_val = torch.full_like(q.observer.min_val, float("inf"))
+            q.observer.max_val = torch.full_like(q.observer.max_val, float("-inf"))
+        table = flat_table.clone()
+        if n_tok:
+            ops.token_range_finalize_batched(tok_min, tok_max, n_tok, rows, batch, tokens, lengths, prune_flags, ratio,
+                                             cur_tok)
+            table.index_copy_(1, col_index, cur_tok)
+        ordered = calibration.gather_batch_table(table, n_batches, group)
+        calibration.replay(ordered, qs)
+
+    # ---- per candidate: re-threshold (1 launch) + replay + quantized forward for the loss
+    best, best_loss = 0, 10000000
+    loss_rows = torch.zeros(rows, 1, dtype=torch.float32, device=dev)
+    for it in range(param["iters"]):
+        ratio = 1.0 - param["step"] * it
+        apply_ratio(ratio)
+        enable_quantization(model)
+        with torch.no_grad():
+            for j, batch_in in enumerate(fp_input):
+                loss_rows[j, 0] = batch_loss(model(**batch_in), batch_in, fp_output[j])
+        per_batch = calibration.gather_batch_table(loss_rows, n_batches, group).reshape(-1).cpu().numpy()
+        cur = np.float32(0)
+        for v in per_batch.astype(np.float32):      # the reference adds fp32 losses in batch order
+            cur = np.float32(cur + v)
+        cur = float(cur)
+        logger.info("the ratio is {}, the loss is {}".format(ratio, cur))
+        if best_loss > cur:
+            best_loss, best = cur, it
+    ratio = 1.0 - param["step"] * best
+    logger.info("the best percentile is {}".format(ratio))
+    apply_ratio(ratio)
+    for _, q in qs:                 # state find_ratio leaves behind: observers on, fake-quant off
+        q.disable_fake_quant()
+        q.enable_observer()
+    return ratio

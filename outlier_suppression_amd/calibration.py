@@ -34,8 +34,14 @@ def gather_batch_table(local, n_batches, group=None):
     rows = (n_batches + world - 1) // world
     if local.shape[0] != rows:
         raise ValueError(f"gather_batch_table: expected {rows} local rows, got {local.shape[0]}")
-    flat = torch.empty((world * rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(flat, local.contiguous(), group=group)     # rank-major concatenation
+    # RCCL ("nccl") gathers device tensors directly over xGMI; a gloo group (CPU tests, or several test
+    # ranks sharing one GPU) is served by staging the few KB through the host
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.detach().cpu().contiguous() if staged else local.contiguous()
+    flat = torch.empty((world * rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(flat, src, group=group)     # rank-major concatenation
+    if staged:
+        flat = flat.to(local.device)
     gathered = flat.view((world, rows) + tuple(local.shape[1:]))
     # gathered[r, j] is batch j*W + r  ->  transpose to [j, r] and flatten = global order
     ordered = gathered.transpose(0, 1).reshape((rows * world,) + tuple(local.shape[1:]))

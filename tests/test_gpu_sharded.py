@@ -1,0 +1,92 @@
+"""Sharded calibration end to end with TWO ranks sharing the one test GPU (gloo rendezvous, tables
+staged through the host): each rank observes half of the batches, the per-batch statistics and
+losses are all-gathered and replayed in global batch order -- percentile, per-candidate losses and
+every scale / zero-point must equal the single-process run bit for bit.  On the 8-GPU node the same
+code runs with backend "nccl" (RCCL) and device tensors."""
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(rank, world, port, out_dir):
+    import logging
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers import BertConfig, BertForSequenceClassification
+    from outlier_suppression_amd import calibration, token_wise_clipping as TWC
+    from outlier_suppression_amd.gamma_migration import delay_ln
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
+    from outlier_suppression_amd.quantization.state import set_observer_name
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bert_tiny_pipeline.npz"))
+    cfg = BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                     max_position_embeddings=40, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                     type_vocab_size=2)
+    fp = BertForSequenceClassification(cfg).eval()
+    fp.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}, strict=False)
+    dev = torch.device("cuda:0")
+    fp = fp.to(dev)
+    batches = [{"input_ids": torch.from_numpy(g["input_ids"][b]).to(dev),
+                "attention_mask": torch.from_numpy(g["attention_mask"][b]).to(dev),
+                "token_type_ids": torch.zeros_like(torch.from_numpy(g["input_ids"][b])).to(dev)} for b in range(4)]
+    a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    model = quantize_model(fp, w_q, a_q).to(dev)
+    with torch.no_grad():
+        fp_output = [model(**b)[0].detach() for b in batches]
+    model = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type="bert", task_type="glue"))
+    enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+    with torch.no_grad():
+        model(**batches[0])
+    disable_all(model)
+    set_observer_name(model)
+    TWC.task_type = "glue"
+    losses = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            m = record.getMessage()
+            if m.startswith("the ratio is"):
+                losses.append(float(m.split("the loss is")[1]))
+    TWC.logger.addHandler(Grab())
+    TWC.logger.setLevel(logging.INFO)
+    mine = calibration.shard_batches(len(batches), rank, world)
+    ratio = TWC.find_ratio_cached(NS(model=model), [batches[b] for b in mine], [fp_output[b] for b in mine],
+                                  {"iters": 5, "step": 0.05}, n_batches=len(batches))
+    qs = [m for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), ratio=ratio, losses=np.array(losses),
+             scale=np.stack([q.scale.detach().cpu().numpy() for q in qs]),
+             zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]),
+             mn=np.stack([q.observer.min_val.cpu().numpy() for q in qs]),
+             cnt=np.array([q.observer.cnt for q in qs]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    mp.spawn(_run, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, 29731, str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / "w1_r0.npz")
+    for r in (0, 1):
+        two = np.load(tmp_path / f"w2_r{r}.npz")
+        assert float(two["ratio"]) == float(one["ratio"])
+        assert np.array_equal(two["losses"], one["losses"])
+        assert np.array_equal(two["scale"], one["scale"]) and np.array_equal(two["zp"], one["zp"])
+        assert np.array_equal(two["mn"], one["mn"]) and np.array_equal(two["cnt"], one["cnt"])
+    assert int(one["cnt"][0]) == 4

@@ -93,6 +93,84 @@ def cpu_baseline(seed, budget_s=20.0):
                       f"thread probe ms/step: " + ", ".join(f"{c}t={probe[c] * 1e3:.1f}" for c in candidates)}
 
 
+def calibration_wall_clock(dev, rank, world, search="cached"):
+    """BASELINE configs[1]: BERT-base (random init, HF default config), CoLA-shaped calibration set
+    (256 samples = 8 batches of [32, 128], synthetic ids / lengths), twc_fine_gamma W6A6:
+    gamma migration -> weight calibration -> token-wise-clipping grid (30 candidates, step 0.01) ->
+    LSQ+ learn-scale (3 epochs, lr 1e-5).  Clock: batches resident on device -> every quantizer has
+    its final scale / zero_point.  N > 1: the grid search is sharded (batch b on rank b mod N, one
+    all-gather of statistics and one of losses per candidate); learn-scale is sequential Adam and runs
+    replicated on every rank."""
+    import logging
+    from types import SimpleNamespace as NS
+    import torch.distributed as dist
+    from transformers import BertConfig, BertForSequenceClassification
+    from outlier_suppression_amd import calibration, token_wise_clipping as TWC
+    from outlier_suppression_amd.gamma_migration import delay_ln
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
+    from outlier_suppression_amd.quantization.state import set_observer_name
+
+    logging.getLogger("transformer").setLevel(logging.WARNING)
+    torch.manual_seed(0)
+    cfg = BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    fp = BertForSequenceClassification(cfg).eval().to(dev)
+    g = torch.Generator().manual_seed(42)
+    n_batches, B, T = 8, 32, 128
+    batches = []
+    for _ in range(n_batches):
+        L = torch.randint(8, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < L[:, None]).long()
+        ids = torch.randint(1000, 30000, (B, T), generator=g) * mask
+        batches.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev),
+                        "token_type_ids": torch.zeros_like(ids).to(dev)})
+    a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    model = quantize_model(fp, w_q, a_q).to(dev)
+    TWC.task_type, TWC.model_type = "glue", "bert"
+    mine = calibration.shard_batches(n_batches, rank, world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def run(search):
+        phases = {}
+        sync()
+        t_start = t0 = time.perf_counter()
+        with torch.no_grad():
+            fp_output = [model(**b)[0].detach() for b in batches]
+        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        m = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type="bert", task_type="glue"))
+        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
+        with torch.no_grad():
+            m(**batches[0])
+        disable_all(m)
+        set_observer_name(m)
+        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        grid = {"iters": 30, "step": 0.01}       # cac_step_iters(6 bit, bs 32, T 128), token_wise_clipping.py:118-129
+        if search == "cached":
+            ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid,
+                                          n_batches=n_batches)
+        else:
+            ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
+        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        TWC.learn_scale(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
+        sync(); phases["learn_scale"] = time.perf_counter() - t0
+        return time.perf_counter() - t_start, phases, ratio
+
+    wall, phases, ratio = run(search)
+    out = {"config": "configs[1]: BERT-base CoLA twc_fine_gamma W6A6, 256 samples (8 x [32,128]), random-init weights, synthetic ids",
+           "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}, "best_percentile": ratio,
+           "twc_candidates": 30,
+           "search": ("cached per-token extrema + 1 re-threshold launch per candidate, sharded over ranks" if search == "cached"
+                      else "literal reference order: 2 model passes per candidate"),
+           "n_gpus": world}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +179,8 @@ def main():
     ap.add_argument("--buffers", type=int, default=4, help="distinct input tensors cycled through (4 x 96 MiB > 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
+    ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -199,6 +279,9 @@ def main():
                      "avg_launch_us": round(fq_avg_ms * 1e3, 2), "median_launch_us": round(fq_ms[len(fq_ms) // 2] * 1e3, 2),
                      "algorithmic_bytes_per_launch": 8 * n_elem},
     }
+    if not args.no_calib:
+        calib = calibration_wall_clock(dev, rank, world, args.calib_search)
+        out["calibration"] = calib
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
     elif rank == 0:

@@ -16,4 +16,4 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* osq_last_error(void) { return osq::g_error; }
 extern "C" int osq_abi_version(void) { return 1; }
-extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes; }
+extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes; }

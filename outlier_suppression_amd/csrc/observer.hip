@@ -662,6 +662,312 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 #undef OSQ_FOR_EACH_VALID
 }
 
+// ---------------------------------------------------------------- wide finaliser (many token slots)
+
+// One CU pulls only ~10 B/clk from the fabric, so a single workgroup needs ~10 us just to READ the
+// extrema of 32768 tokens.  Above kWideMinSlots the same selection runs as three multi-workgroup
+// launches (a kernel boundary costs ~1.5 us, a hand-rolled grid barrier more):
+//   A  coarse histogram: bin = key >> 20 (exponent + 3 mantissa bits, 2048 bins) accumulated into
+//      a global table with wave-aggregated atomics (keys of one wave share a handful of bins: one
+//      atomic per distinct bin per wave), plus N / NaN flag / plain extrema;
+//   B  every workgroup scans the 2 x 2048 table (8 KB, L2) to find the coarse bin holding
+//      rank k_lo, then appends its slots' keys of that bin to a global list (wave-aggregated
+//      reservation) and tracks the smallest key above the bin;
+//   C  every workgroup selects ranks r and r+1 inside the (small) list redundantly -- two
+//      LDS-histogram levels over the 20 remaining key bits -- forms the thresholds, reduces
+//      max(token_max <= upper) / min(token_min >= lower) over its slots; the last workgroup
+//      (sharded tickets) finishes (running statistic, qparams) and re-zeroes the global scratch.
+constexpr int64_t kWideMinSlots = 8192;
+constexpr int kWideThreads = 256;
+constexpr int kWideSlotsPerBlock = 512;
+constexpr int kCoarseShift = 20;
+
+struct WideState {            // lives in the caller's workspace; ALL-ZERO is the idle state
+    unsigned int hist[2][kSelBins];
+    unsigned int n, bad;
+    unsigned int omin_inv, omax;              // ~ordered(min) / ordered(max): both grow with atomicMax from 0
+    unsigned int fill[2], next_inv[2];        // ~(smallest key above the chosen bin)
+    unsigned int thr_omin_inv, thr_omax;
+    unsigned int pad[6];
+};
+__device__ __forceinline__ void wide_state_clear(WideState* ws) {   // scalars only; hist is cleared by all threads
+    ws->n = 0u; ws->bad = 0u; ws->omin_inv = 0u; ws->omax = 0u;
+    ws->fill[0] = ws->fill[1] = 0u;
+    ws->next_inv[0] = ws->next_inv[1] = 0u;
+    ws->thr_omin_inv = 0u; ws->thr_omax = 0u;
+}
+__device__ __forceinline__ unsigned int peek(const unsigned int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct WideArgs {
+    const float* tok_min;
+    const float* tok_max;
+    int64_t B, T;
+    const int64_t* lengths;
+    WideState* ws;
+    unsigned int* list;        // 2 x slots keys
+    unsigned int* tickets;
+    int prune;
+    float q;
+};
+
+__device__ __forceinline__ bool wide_slot(const WideArgs& a, int64_t s, float* mn, float* mx) {
+    const int64_t slots = a.B * a.T;
+    if (s >= slots) return false;
+    if (a.lengths) {
+        const unsigned int Tu = static_cast<unsigned int>(a.T), su = static_cast<unsigned int>(s);
+        const unsigned int b = su / Tu, t = su - b * Tu;
+        if (static_cast<int64_t>(t) >= a.lengths[b]) return false;
+    }
+    *mn = a.tok_min[s];
+    *mx = a.tok_max[s];
+    return true;
+}
+
+// add `ok ? 1 : 0` into table[bin] for every lane, one atomic per distinct bin of the wave
+__device__ __forceinline__ void wave_histogram_add(unsigned int* table, unsigned int bin, bool ok) {
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        const unsigned int lb = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(bin), leader));
+        const unsigned long long same = __ballot(ok && bin == lb);
+        if ((threadIdx.x & (OSQ_WAVE - 1)) == leader) atomicAdd(&table[lb], static_cast<unsigned int>(__popcll(same)));
+        todo &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(kWideThreads) void wide_hist_kernel(WideArgs a, Finish fin) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    MinMax plain;
+    plain.init();
+    unsigned int n = 0u;
+#pragma unroll
+    for (int r = 0; r < kWideSlotsPerBlock / kWideThreads; ++r) {
+        const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
+        float mn = 0.f, mx = 0.f;
+        const bool ok = wide_slot(a, s, &mn, &mx);
+        if (ok) {
+            ++n;
+            plain.mn = fminf(plain.mn, mn);
+            plain.mx = fmaxf(plain.mx, mx);
+            plain.bad |= (mn != mn) || (mx != mx);
+        }
+        if (a.prune) {
+            wave_histogram_add(a.ws->hist[0], abs_key(mx) >> kCoarseShift, ok);
+            wave_histogram_add(a.ws->hist[1], abs_key(mn) >> kCoarseShift, ok);
+        }
+    }
+    // block partial -> ONE set of global atomics from thread 0 (which then takes the ticket in order)
+    __shared__ unsigned int s_n[kWideThreads / OSQ_WAVE];
+    n = wave_inclusive_scan_u32(n);
+    if (lane == OSQ_WAVE - 1) s_n[threadIdx.x / OSQ_WAVE] = n;
+    plain = block_reduce(plain);
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0u;
+        for (int k = 0; k < kWideThreads / OSQ_WAVE; ++k) tot += s_n[k];
+        if (tot) atomicAdd(&a.ws->n, tot);
+        if (plain.bad) atomicOr(&a.ws->bad, 1u);
+        atomicMax(&a.ws->omin_inv, ~ordered_bits(plain.mn));
+        atomicMax(&a.ws->omax, ordered_bits(plain.mx));
+    }
+    if (!a.prune) {     // plain masked min/max: the last workgroup finishes right here
+        if (grid_last_block(a.tickets, gridDim.x)) {
+            if (threadIdx.x == 0) {
+                const unsigned int N = peek(&a.ws->n);
+                float cmin = from_ordered_bits(~peek(&a.ws->omin_inv));
+                float cmax = from_ordered_bits(peek(&a.ws->omax));
+                if (peek(&a.ws->bad)) { cmin = __builtin_nanf(""); cmax = cmin; }
+                if (N > 0u) finish_entry(fin, 0, cmin, cmax);
+                wide_state_clear(a.ws);
+                grid_reset(a.tickets, gridDim.x);
+            }
+        }
+    }
+}
+
+struct CoarsePick { unsigned int bin, below, count; };
+
+// block-wide: which coarse bin holds rank `want` (2048 bins, 8 per thread); result in every thread
+__device__ __forceinline__ CoarsePick pick_coarse_bin(const unsigned int* hist, unsigned int want) {
+    __shared__ unsigned int s_tot[kWideThreads / OSQ_WAVE];
+    __shared__ CoarsePick s_pick;
+    constexpr int per = kSelBins / kWideThreads;   // 8
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    unsigned int h[per], mine = 0u;
+#pragma unroll
+    for (int k = 0; k < per; ++k) { h[k] = hist[threadIdx.x * per + k]; mine += h[k]; }
+    const unsigned int incl_w = wave_inclusive_scan_u32(mine);
+    __syncthreads();
+    if (lane == OSQ_WAVE - 1) s_tot[wv] = incl_w;
+    __syncthreads();
+    unsigned int base = 0u;
+#pragma unroll
+    for (int k = 0; k < kWideThreads / OSQ_WAVE; ++k) base += (k < wv) ? s_tot[k] : 0u;
+    const unsigned int incl = base + incl_w, excl = incl - mine;
+    if (want >= excl && want < incl) {
+        unsigned int below = excl;
+#pragma unroll
+        for (int k = 0; k < per; ++k) {
+            if (below + h[k] > want) { s_pick.bin = threadIdx.x * per + k; s_pick.below = below; s_pick.count = h[k]; break; }
+            below += h[k];
+        }
+    }
+    __syncthreads();
+    return s_pick;
+}
+
+struct WideRanks {
+    unsigned int k_lo, k_hi;
+    float w;
+};
+__device__ __forceinline__ WideRanks wide_ranks(unsigned int N, float q) {
+    const float rank = q * static_cast<float>(N - 1u);
+    const float rlo = floorf(rank);
+    return {static_cast<unsigned int>(rlo), static_cast<unsigned int>(ceilf(rank)), rank - rlo};
+}
+
+__global__ __launch_bounds__(kWideThreads) void wide_collect_kernel(WideArgs a) {
+    const unsigned int N = a.ws->n;
+    if (N == 0u || a.ws->bad) return;
+    const WideRanks rk = wide_ranks(N, a.q);
+    const CoarsePick p0 = pick_coarse_bin(a.ws->hist[0], rk.k_lo);
+    const CoarsePick p1 = pick_coarse_bin(a.ws->hist[1], rk.k_lo);
+    const int64_t slots = a.B * a.T;
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    unsigned int n0 = 0xffffffffu, n1 = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < kWideSlotsPerBlock / kWideThreads; ++r) {
+        const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
+        float mn = 0.f, mx = 0.f;
+        const bool ok = wide_slot(a, s, &mn, &mx);
+        const unsigned int k0 = abs_key(mx), k1 = abs_key(mn);
+        const unsigned int c0 = k0 >> kCoarseShift, c1 = k1 >> kCoarseShift;
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+            const unsigned int key = arr ? k1 : k0, c = arr ? c1 : c0, target = arr ? p1.bin : p0.bin;
+            const bool hit = ok && c == target;
+            const unsigned long long m = __ballot(hit);
+            if (m) {                                 // wave-aggregated reservation in the global list
+                unsigned int basepos = 0u;
+                const int leader = __ffsll(static_cast<long long>(m)) - 1;
+                if (lane == leader) basepos = atomicAdd(&a.ws->fill[arr], static_cast<unsigned int>(__popcll(m)));
+                basepos = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(basepos), leader));
+                if (hit) {
+                    const unsigned int off = static_cast<unsigned int>(__popcll(m & ((1ull << lane) - 1ull)));
+                    a.list[static_cast<int64_t>(arr) * slots + basepos + off] = key;
+                }
+            }
+            if (ok && c > target) { if (arr) n1 = min(n1, key); else n0 = min(n0, key); }
+        }
+    }
+    n0 = wave_min_u32(n0);
+    n1 = wave_min_u32(n1);
+    if (lane == 0) {
+        if (n0 != 0xffffffffu) atomicMax(&a.ws->next_inv[0], ~n0);
+        if (n1 != 0xffffffffu) atomicMax(&a.ws->next_inv[1], ~n1);
+    }
+}
+
+// select the keys at ranks r and r+1 (if present) of list[0..cnt) whose top 11 bits are equal:
+// two LDS-histogram levels over bits [19:9] and [8:0]
+__device__ __forceinline__ void list_select(const unsigned int* list, unsigned int cnt, unsigned int r, unsigned int* hist,
+                                            unsigned int* key_r, unsigned int* key_r1) {
+    unsigned int found[2] = {0xffffffffu, 0xffffffffu};
+    for (int which = 0; which < 2; ++which) {
+        unsigned int want = r + which;
+        if (want >= cnt) break;
+        unsigned int prefix = 0u, mask = 0u;
+        for (int level = 0; level < 2; ++level) {
+            const int shift = level == 0 ? 9 : 0;
+            const unsigned int field = level == 0 ? 0x7ffu : 0x1ffu;
+            __syncthreads();
+            for (int k = threadIdx.x; k < kSelBins; k += kWideThreads) hist[k] = 0u;
+            __syncthreads();
+            for (unsigned int j = threadIdx.x; j < cnt; j += kWideThreads) {
+                const unsigned int key = list[j] & 0xfffffu;
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & field], 1u);
+            }
+            __syncthreads();
+            const CoarsePick p = pick_coarse_bin(hist, want);
+            prefix |= p.bin << shift;
+            mask |= field << shift;
+            want -= p.below;
+        }
+        found[which] = prefix;
+    }
+    *key_r = found[0];
+    *key_r1 = found[1];
+}
+
+__global__ __launch_bounds__(kWideThreads) void wide_select_kernel(WideArgs a, Finish fin) {
+    __shared__ unsigned int hist[kSelBins];
+    __shared__ unsigned int s_omin, s_omax;
+    const unsigned int N = a.ws->n;
+    const bool bad = a.ws->bad != 0u;
+    const int64_t slots = a.B * a.T;
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    float upper = 0.f, lower = 0.f;
+    if (N > 0u && !bad) {
+        const WideRanks rk = wide_ranks(N, a.q);
+        float thr[2];
+        for (int arr = 0; arr < 2; ++arr) {
+            const CoarsePick p = pick_coarse_bin(a.ws->hist[arr], rk.k_lo);
+            unsigned int lo20, hi20;
+            list_select(a.list + static_cast<int64_t>(arr) * slots, p.count, rk.k_lo - p.below, hist, &lo20, &hi20);
+            const unsigned int v_lo = (p.bin << kCoarseShift) | lo20;
+            unsigned int v_hi = v_lo;
+            if (rk.k_hi != rk.k_lo) v_hi = hi20 != 0xffffffffu ? ((p.bin << kCoarseShift) | hi20) : ~a.ws->next_inv[arr];
+            const float lo_v = __uint_as_float(v_lo), hi_v = __uint_as_float(v_hi), diff = hi_v - lo_v;
+            thr[arr] = (rk.w < 0.5f) ? __builtin_fmaf(rk.w, diff, lo_v) : __builtin_fmaf(rk.w - 1.0f, diff, hi_v);
+        }
+        upper = thr[0];
+        lower = -thr[1];
+        MinMax pr;
+        pr.init();
+#pragma unroll
+        for (int r = 0; r < kWideSlotsPerBlock / kWideThreads; ++r) {
+            const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
+            float mn = 0.f, mx = 0.f;
+            if (wide_slot(a, s, &mn, &mx)) {
+                if (mn >= lower) pr.mn = fminf(pr.mn, mn);
+                if (mx <= upper) pr.mx = fmaxf(pr.mx, mx);
+            }
+        }
+        pr.mn = wave_min(pr.mn);
+        pr.mx = wave_max(pr.mx);
+        if (threadIdx.x == 0) { s_omin = 0xffffffffu; s_omax = 0u; }
+        __syncthreads();
+        if (lane == 0) { atomicMin(&s_omin, ordered_bits(pr.mn)); atomicMax(&s_omax, ordered_bits(pr.mx)); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMax(&a.ws->thr_omin_inv, ~s_omin);
+            atomicMax(&a.ws->thr_omax, s_omax);
+        }
+    }
+    __syncthreads();
+    if (grid_last_block(a.tickets, gridDim.x)) {
+        if (threadIdx.x == 0 && N > 0u) {
+            float cmin, cmax;
+            if (bad) {
+                cmin = cmax = __builtin_nanf("");
+            } else {
+                const float lo_sel = from_ordered_bits(~peek(&a.ws->thr_omin_inv));
+                const float up_sel = from_ordered_bits(peek(&a.ws->thr_omax));
+                cmin = (lo_sel > up_sel) ? up_sel : lo_sel;     // aminmax(clip(value, lo, up)), observer.py:68,227
+                cmax = up_sel;
+            }
+            finish_entry(fin, 0, cmin, cmax);
+        }
+        // leave the global scratch zeroed for the next call
+        for (int k = threadIdx.x; k < 2 * kSelBins; k += kWideThreads) (&a.ws->hist[0][0])[k] = 0u;
+        if (threadIdx.x == 0) {
+            wide_state_clear(a.ws);
+            grid_reset(a.tickets, gridDim.x);
+        }
+    }
+}
+
 static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -794,7 +1100,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
                                         float* cur_minmax,
                                         int quant_min, int quant_max, int symmetric,
                                         float* scale_out, void* zero_point_out, int zp_type,
-                                        osq_stream stream) {
+                                        void* workspace, void* list_scratch, osq_stream stream) {
     const char* why = "";
     OSQ_REQUIRE(token_min && token_max && batch > 0 && tokens > 0, "token_range_finalize: empty or null input");
     OSQ_REQUIRE(!prune || (percentile >= 0.0 && percentile <= 1.0), "token_range_finalize: percentile outside [0, 1]");
@@ -805,6 +1111,18 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
+    if (batch * tokens >= kWideMinSlots && workspace && (list_scratch || !prune)) {
+        Workspace wsp(workspace);
+        WideArgs a{token_min, token_max, batch, tokens, lengths, reinterpret_cast<WideState*>(wsp.wide()),
+                   static_cast<unsigned int*>(list_scratch), wsp.counter(0), prune, qf};
+        const int grid = static_cast<int>((batch * tokens + kWideSlotsPerBlock - 1) / kWideSlotsPerBlock);
+        hipLaunchKernelGGL(wide_hist_kernel, dim3(grid), dim3(kWideThreads), 0, st, a, fin);
+        if (prune) {
+            hipLaunchKernelGGL(wide_collect_kernel, dim3(grid), dim3(kWideThreads), 0, st, a);
+            hipLaunchKernelGGL(wide_select_kernel, dim3(grid), dim3(kWideThreads), 0, st, a, fin);
+        }
+        return check_launch("token_range_finalize(wide)");
+    }
     const FinalBatch fb{0, 0, 0, nullptr};
 #define OSQ_LAUNCH_FINAL(S)                                                                                        \
     hipLaunchKernelGGL(token_finalize_kernel<S>, dim3(1), dim3(kFinalThreads), 0, st, token_min, token_max, batch, \

@@ -11,6 +11,7 @@ namespace osq {
 constexpr int kMaxBlocks = 2048;          // 256 CUs x 8 workgroups of 256 threads
 constexpr size_t kWsHeaderBytes = 4096;   // ticket counters, one 64-byte line each (33 used)
 constexpr size_t kWsScratchBytes = 64 * 1024;
+constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
 
 void set_error(const char* fmt, ...);
 
@@ -33,7 +34,7 @@ static inline int check_launch(const char* what) {
     return OSQ_OK;
 }
 
-// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch].  Counters are zero between
+// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
@@ -41,6 +42,7 @@ struct Workspace {
     unsigned int* counter(int) const { return reinterpret_cast<unsigned int*>(base); }
     double* doubles() const { return reinterpret_cast<double*>(base + kWsHeaderBytes); }
     float* floats() const { return reinterpret_cast<float*>(base + kWsHeaderBytes); }
+    void* wide() const { return base + kWsHeaderBytes + kWsScratchBytes; }
 };
 
 }  // namespace osq

@@ -307,12 +307,13 @@ _token_scratch = {}
 
 
 def _scratch(device, n):
+    """(token_min, token_max, list_scratch): per (device, stream) scratch, grown on demand."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _token_scratch.get(key)
-    if buf is None or buf.numel() < 2 * n:
-        buf = torch.empty(2 * max(n, 4096), dtype=torch.float32, device=device)
+    if buf is None or buf.numel() < 4 * n:
+        buf = torch.empty(4 * max(n, 4096), dtype=torch.float32, device=device)
         _token_scratch[key] = buf
-    return buf[:n], buf[n:2 * n]
+    return buf[:n], buf[n:2 * n], buf[2 * n:4 * n]
 
 
 def token_minmax(x, seq_pos, lengths=None, out=None):
@@ -324,7 +325,7 @@ def token_minmax(x, seq_pos, lengths=None, out=None):
         lengths = lengths.to(torch.int64)
     view = token_view(x, seq_pos, None if lengths is None else lengths.numel())
     n = view.batch * view.tokens
-    tmin, tmax = out if out is not None else _scratch(x.device, n)
+    tmin, tmax = out if out is not None else _scratch(x.device, n)[:2]
     _hip.check(lib.osq_token_minmax(_hip.ptr(x), ctypes.byref(view), _hip.ptr(lengths), _hip.ptr(tmin), _hip.ptr(tmax),
                                     _hip.stream_ptr(x.device)), "token_minmax")
     return tmin, tmax, view.batch, view.tokens, lengths
@@ -335,11 +336,14 @@ def token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, percentile, 
     """Percentile pruning / plain extrema over valid tokens + running statistic (+ qparams): ONE launch."""
     lib = _hip.load()
     s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    dev = tmin.device
+    lst = _scratch(dev, batch * tokens)[2] if batch * tokens >= 8192 else None
     _hip.check(lib.osq_token_range_finalize(_hip.ptr(tmin), _hip.ptr(tmax), batch, tokens, _hip.ptr(lengths),
                                             int(bool(prune)), float(percentile if prune else 1.0), rule, int(cnt),
                                             _hip.ptr(min_val), _hip.ptr(max_val), _hip.ptr(cur), int(quant_min),
                                             int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
-                                            _hip.stream_ptr(tmin.device)), "token_range_finalize")
+                                            _hip.ptr(_hip.workspace(dev)), _hip.ptr(lst), _hip.stream_ptr(dev)),
+               "token_range_finalize")
 
 
 def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, batch, tokens, lengths, prune_flags,

@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     rc = lib.osq_calculate_qparams(None, None, 4, 0, 63, 0, None, None, 0, None)
     assert rc == -1
     rc = lib.osq_token_range_finalize(ctypes.c_void_p(16), ctypes.c_void_p(16), 2, 2, None, 1, 1.5, 0, 0, None, None, None,
-                                      0, 63, 0, None, None, 0, None)
+                                      0, 63, 0, None, None, 0, None, None, None)
     assert rc == -1 and b"percentile" in lib.osq_last_error()
 
 

@@ -175,9 +175,10 @@ int osq_token_minmax(const float* x, const osq_token_view* view, const int64_t* 
  *   prune == 0: plain min/max over the valid tokens (observer.py:193), also used
  *               when 'attention_probs' is in the observer's name (observer.py:62-63);
  * then the update rule (observer.py:194-202 or 143-144) and optional qparams.
- * Up to 8191 token slots: one launch, one workgroup.  From 8192 slots, when `workspace` and
- * `list_scratch` (2 * batch * tokens uint32, caller-owned, contents irrelevant) are given: three
- * multi-workgroup launches (one CU cannot read 256 KB of extrema fast enough on its own). */
+ * Up to 32768 token slots: one launch, one workgroup (extrema cached in registers).  Above, when
+ * `workspace` and `list_scratch` (2 * batch * tokens uint32, caller-owned, contents irrelevant)
+ * are given: three multi-workgroup launches (one CU pulls only ~10 B/clk, so a single workgroup
+ * cannot re-read hundreds of KB per pass).  osq_set_wide_min_slots() moves the switch point. */
 int osq_token_range_finalize(const float* token_min, const float* token_max,
                              int64_t batch, int64_t tokens, const int64_t* lengths,
                              int prune, double percentile,
@@ -186,6 +187,8 @@ int osq_token_range_finalize(const float* token_min, const float* token_max,
                              int quant_min, int quant_max, int symmetric,
                              float* scale_out, void* zero_point_out, int zp_type,
                              void* workspace, void* list_scratch, osq_stream stream);
+
+int osq_set_wide_min_slots(int64_t slots);
 
 /* Grid-search form of the same step (token_wise_clipping.py:50-66 calls the observer pass once per
  * candidate percentile although, with fake-quant off, the activations -- hence the per-token

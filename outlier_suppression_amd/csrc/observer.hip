@@ -336,6 +336,15 @@ __device__ __forceinline__ unsigned int level_shift(unsigned int width) {
     return bits > kSelBits ? bits - kSelBits : 0u;
 }
 
+// development aid (-DOSQ_FINAL_TIMING): thread 0 of every workgroup stamps s_memtime into a debug buffer
+#ifdef OSQ_FINAL_TIMING
+__device__ long long* g_osq_dbg = nullptr;
+#define OSQ_WSTAMP(k) do { if (threadIdx.x == 0 && g_osq_dbg) g_osq_dbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define OSQ_DBGVAL(k, v) do { if (g_osq_dbg) g_osq_dbg[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define OSQ_WSTAMP(k) do { } while (0)
+#define OSQ_DBGVAL(k, v) do { } while (0)
+#endif
 // development aid: -DOSQ_FINAL_TIMING makes thread 0 write s_memtime stamps after cur_minmax[0..1]
 #ifdef OSQ_FINAL_TIMING
 #define OSQ_STAMP(k) do { if (threadIdx.x == 0 && fin.cur) reinterpret_cast<long long*>(fin.cur + 2)[k] = __builtin_readcyclecounter(); } while (0)
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 // ---------------------------------------------------------------- wide finaliser (many token slots)
 
 // One CU pulls only ~10 B/clk from the fabric, so a single workgroup needs ~10 us just to READ the
-// extrema of 32768 tokens.  Above kWideMinSlots the same selection runs as three multi-workgroup
+// extrema of 32768 tokens.  Above g_wide_min_slots the same selection runs as three multi-workgroup
 // launches (a kernel boundary costs ~1.5 us, a hand-rolled grid barrier more):
 //   A  coarse histogram: bin = key >> 20 (exponent + 3 mantissa bits, 2048 bins) accumulated into
 //      a global table with wave-aggregated atomics (keys of one wave share a handful of bins: one
@@ -677,7 +686,11 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 //      LDS-histogram levels over the 20 remaining key bits -- forms the thresholds, reduces
 //      max(token_max <= upper) / min(token_min >= lower) over its slots; the last workgroup
 //      (sharded tickets) finishes (running statistic, qparams) and re-zeroes the global scratch.
-constexpr int64_t kWideMinSlots = 8192;
+// Measured on MI355X at 32768 slots: single workgroup 28.5 us, the three launches 30 us (6.4 + 9.5 + 14;
+// each is dominated by launch + dependent-load latency, not work) -- so the wide path only takes over
+// above the register-cache limit of the single-workgroup kernel, where that kernel would re-read the
+// arrays from L2 in every pass (~25 us per pass at 65536 slots).  osq_set_wide_min_slots() overrides.
+static int64_t g_wide_min_slots = 32769;
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
 constexpr int kCoarseShift = 20;
@@ -712,33 +725,32 @@ struct WideArgs {
     float q;
 };
 
+// Load a slot's extrema unconditionally (index clamped) so that the loads do not wait for the length
+// lookup; validity is decided afterwards.
 __device__ __forceinline__ bool wide_slot(const WideArgs& a, int64_t s, float* mn, float* mx) {
     const int64_t slots = a.B * a.T;
-    if (s >= slots) return false;
-    if (a.lengths) {
-        const unsigned int Tu = static_cast<unsigned int>(a.T), su = static_cast<unsigned int>(s);
-        const unsigned int b = su / Tu, t = su - b * Tu;
-        if (static_cast<int64_t>(t) >= a.lengths[b]) return false;
-    }
-    *mn = a.tok_min[s];
-    *mx = a.tok_max[s];
-    return true;
+    const int64_t sc = s < slots ? s : slots - 1;
+    const unsigned int Tu = static_cast<unsigned int>(a.T), su = static_cast<unsigned int>(sc);
+    const unsigned int b = su / Tu, t = su - b * Tu;
+    int64_t len = a.T;
+    if (a.lengths) len = a.lengths[b];
+    *mn = a.tok_min[sc];
+    *mx = a.tok_max[sc];
+    return s < slots && static_cast<int64_t>(t) < len;
 }
 
-// add `ok ? 1 : 0` into table[bin] for every lane, one atomic per distinct bin of the wave
-__device__ __forceinline__ void wave_histogram_add(unsigned int* table, unsigned int bin, bool ok) {
-    unsigned long long todo = __ballot(ok);
-    while (todo) {
-        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-        const unsigned int lb = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(bin), leader));
-        const unsigned long long same = __ballot(ok && bin == lb);
-        if ((threadIdx.x & (OSQ_WAVE - 1)) == leader) atomicAdd(&table[lb], static_cast<unsigned int>(__popcll(same)));
-        todo &= ~same;
-    }
-}
+// Hot coarse bins are neighbours (same exponent, adjacent mantissa bits); in bin order they would share
+// one or two 64-byte lines and every global atomic of every workgroup would queue on them.  Entry b of
+// the global table therefore lives at perm(b): neighbours end up 128 entries (8 lines) apart.
+__device__ __forceinline__ unsigned int coarse_slot(unsigned int bin) { return ((bin & 15u) << 7) | (bin >> 4); }
 
 __global__ __launch_bounds__(kWideThreads) void wide_hist_kernel(WideArgs a, Finish fin) {
+    __shared__ unsigned int lh[2][kSelBins];
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    if (a.prune) {
+        for (int k = threadIdx.x; k < 2 * kSelBins; k += kWideThreads) (&lh[0][0])[k] = 0u;
+        __syncthreads();
+    }
     MinMax plain;
     plain.init();
     unsigned int n = 0u;
@@ -753,9 +765,16 @@ __global__ __launch_bounds__(kWideThreads) void wide_hist_kernel(WideArgs a, Fin
             plain.mx = fmaxf(plain.mx, mx);
             plain.bad |= (mn != mn) || (mx != mx);
         }
-        if (a.prune) {
-            wave_histogram_add(a.ws->hist[0], abs_key(mx) >> kCoarseShift, ok);
-            wave_histogram_add(a.ws->hist[1], abs_key(mn) >> kCoarseShift, ok);
+        if (a.prune && ok) {      // workgroup-local histogram first (LDS resolves same-bin lanes in hardware)
+            atomicAdd(&lh[0][abs_key(mx) >> kCoarseShift], 1u);
+            atomicAdd(&lh[1][abs_key(mn) >> kCoarseShift], 1u);
+        }
+    }
+    if (a.prune) {          // flush the (few) non-empty bins: one global atomic each
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2 * kSelBins; k += kWideThreads) {
+            const unsigned int c = (&lh[0][0])[k];
+            if (c) atomicAdd(&a.ws->hist[k >> 11][coarse_slot(k & (kSelBins - 1))], c);
         }
     }
     // block partial -> ONE set of global atomics from thread 0 (which then takes the ticket in order)
@@ -789,6 +808,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_hist_kernel(WideArgs a, Fin
 struct CoarsePick { unsigned int bin, below, count; };
 
 // block-wide: which coarse bin holds rank `want` (2048 bins, 8 per thread); result in every thread
+// hist: 2048 counts in bin order, in LDS or global memory
 __device__ __forceinline__ CoarsePick pick_coarse_bin(const unsigned int* hist, unsigned int want) {
     __shared__ unsigned int s_tot[kWideThreads / OSQ_WAVE];
     __shared__ CoarsePick s_pick;
@@ -817,6 +837,24 @@ __device__ __forceinline__ CoarsePick pick_coarse_bin(const unsigned int* hist, 
     return s_pick;
 }
 
+// Bring both permuted global coarse tables into LDS in bin order: coalesced 32-byte reads per thread in
+// MEMORY order, scattered to their bin position (inverse of coarse_slot).
+__device__ __forceinline__ void stage_coarse_tables(const WideState* ws, unsigned int (*lds)[kSelBins]) {
+    constexpr int per = kSelBins / kWideThreads;   // 8 consecutive memory entries per thread
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr) {
+        const uint4* src = reinterpret_cast<const uint4*>(&ws->hist[arr][threadIdx.x * per]);
+        const uint4 a = src[0], b = src[1];
+        const unsigned int v[per] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < per; ++k) {
+            const unsigned int i = threadIdx.x * per + k;          // memory index = lo*128 + hi
+            lds[arr][((i & 127u) << 4) | (i >> 7)] = v[k];          // bin = hi*16 + lo
+        }
+    }
+    __syncthreads();
+}
+
 struct WideRanks {
     unsigned int k_lo, k_hi;
     float w;
@@ -831,36 +869,57 @@ __global__ __launch_bounds__(kWideThreads) void wide_collect_kernel(WideArgs a) 
     const unsigned int N = a.ws->n;
     if (N == 0u || a.ws->bad) return;
     const WideRanks rk = wide_ranks(N, a.q);
-    const CoarsePick p0 = pick_coarse_bin(a.ws->hist[0], rk.k_lo);
-    const CoarsePick p1 = pick_coarse_bin(a.ws->hist[1], rk.k_lo);
+    constexpr int kRows = kWideSlotsPerBlock / kWideThreads;
+    // this workgroup's slots first: their loads fly while the coarse table is scanned
+    float v_mn[kRows], v_mx[kRows];
+    bool v_ok[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
+        v_ok[r] = wide_slot(a, s, &v_mn[r], &v_mx[r]);
+    }
+    __shared__ unsigned int coarse[2][kSelBins];
+    stage_coarse_tables(a.ws, coarse);
+    const CoarsePick p0 = pick_coarse_bin(coarse[0], rk.k_lo);
+    const CoarsePick p1 = pick_coarse_bin(coarse[1], rk.k_lo);
     const int64_t slots = a.B * a.T;
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    __shared__ unsigned int s_cnt[2], s_base[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     unsigned int n0 = 0xffffffffu, n1 = 0xffffffffu;
+    unsigned int keys[kRows][2], pos[kRows][2];
+    bool hits[kRows][2];
 #pragma unroll
-    for (int r = 0; r < kWideSlotsPerBlock / kWideThreads; ++r) {
-        const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
-        float mn = 0.f, mx = 0.f;
-        const bool ok = wide_slot(a, s, &mn, &mx);
-        const unsigned int k0 = abs_key(mx), k1 = abs_key(mn);
-        const unsigned int c0 = k0 >> kCoarseShift, c1 = k1 >> kCoarseShift;
+    for (int r = 0; r < kRows; ++r) {
+        const float mn = v_mn[r], mx = v_mx[r];
+        const bool ok = v_ok[r];
 #pragma unroll
         for (int arr = 0; arr < 2; ++arr) {
-            const unsigned int key = arr ? k1 : k0, c = arr ? c1 : c0, target = arr ? p1.bin : p0.bin;
+            const unsigned int key = abs_key(arr ? mn : mx), c = key >> kCoarseShift, target = arr ? p1.bin : p0.bin;
             const bool hit = ok && c == target;
+            keys[r][arr] = key;
+            hits[r][arr] = hit;
+            pos[r][arr] = 0u;
             const unsigned long long m = __ballot(hit);
-            if (m) {                                 // wave-aggregated reservation in the global list
-                unsigned int basepos = 0u;
+            if (m) {                                 // position inside the workgroup: one LDS atomic per wave
+                unsigned int wbase = 0u;
                 const int leader = __ffsll(static_cast<long long>(m)) - 1;
-                if (lane == leader) basepos = atomicAdd(&a.ws->fill[arr], static_cast<unsigned int>(__popcll(m)));
-                basepos = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(basepos), leader));
-                if (hit) {
-                    const unsigned int off = static_cast<unsigned int>(__popcll(m & ((1ull << lane) - 1ull)));
-                    a.list[static_cast<int64_t>(arr) * slots + basepos + off] = key;
-                }
+                if (lane == leader) wbase = atomicAdd(&s_cnt[arr], static_cast<unsigned int>(__popcll(m)));
+                wbase = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(wbase), leader));
+                pos[r][arr] = wbase + static_cast<unsigned int>(__popcll(m & ((1ull << lane) - 1ull)));
             }
             if (ok && c > target) { if (arr) n1 = min(n1, key); else n0 = min(n0, key); }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 2) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&a.ws->fill[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();                                 // ONE global reservation per workgroup and array
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr)
+            if (hits[r][arr]) a.list[static_cast<int64_t>(arr) * slots + s_base[arr] + pos[r][arr]] = keys[r][arr];
     n0 = wave_min_u32(n0);
     n1 = wave_min_u32(n1);
     if (lane == 0) {
@@ -869,55 +928,98 @@ __global__ __launch_bounds__(kWideThreads) void wide_collect_kernel(WideArgs a) 
     }
 }
 
-// select the keys at ranks r and r+1 (if present) of list[0..cnt) whose top 11 bits are equal:
-// two LDS-histogram levels over bits [19:9] and [8:0]
-__device__ __forceinline__ void list_select(const unsigned int* list, unsigned int cnt, unsigned int r, unsigned int* hist,
-                                            unsigned int* key_r, unsigned int* key_r1) {
-    unsigned int found[2] = {0xffffffffu, 0xffffffffu};
-    for (int which = 0; which < 2; ++which) {
-        unsigned int want = r + which;
-        if (want >= cnt) break;
-        unsigned int prefix = 0u, mask = 0u;
-        for (int level = 0; level < 2; ++level) {
-            const int shift = level == 0 ? 9 : 0;
-            const unsigned int field = level == 0 ? 0x7ffu : 0x1ffu;
-            __syncthreads();
-            for (int k = threadIdx.x; k < kSelBins; k += kWideThreads) hist[k] = 0u;
-            __syncthreads();
-            for (unsigned int j = threadIdx.x; j < cnt; j += kWideThreads) {
-                const unsigned int key = list[j] & 0xfffffu;
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & field], 1u);
-            }
-            __syncthreads();
-            const CoarsePick p = pick_coarse_bin(hist, want);
-            prefix |= p.bin << shift;
-            mask |= field << shift;
-            want -= p.below;
+// Keys at ranks r and r+1 (r+1 only if it exists) of both lists at once.  Every key of list `arr` shares
+// its top 11 bits; the remaining 20 are resolved by two LDS-histogram passes over the lists:
+// bits [19:9] (2048 bins), then bits [8:0] inside the chosen bin (512 bins) -- during the second pass
+// the smallest key of any higher first-level bin is tracked too, which is rank r+1 when the
+// first-level bin ends at rank r.  found[arr][0/1] = low 20 bits, 0xffffffff if rank r+1 is not in the list.
+__device__ __forceinline__ void list_select2(const unsigned int* list0, unsigned int cnt0, unsigned int r0,
+                                             const unsigned int* list1, unsigned int cnt1, unsigned int r1,
+                                             unsigned int (*hist)[kSelBins], unsigned int found[2][2]) {
+    __shared__ unsigned int s_above[2];
+    const unsigned int* lists[2] = {list0, list1};
+    const unsigned int cnts[2] = {cnt0, cnt1}, ranks[2] = {r0, r1};
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    // ---- pass 1: bits [19:9]
+    for (int k = threadIdx.x; k < 2 * kSelBins; k += kWideThreads) (&hist[0][0])[k] = 0u;
+    if (threadIdx.x < 2) s_above[threadIdx.x] = 0xffffffffu;
+    __syncthreads();
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr)
+        for (unsigned int j = threadIdx.x; j < cnts[arr]; j += kWideThreads)
+            atomicAdd(&hist[arr][(lists[arr][j] >> 9) & 0x7ffu], 1u);
+    __syncthreads();
+    CoarsePick top[2];
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr) top[arr] = pick_coarse_bin(hist[arr], ranks[arr]);
+    // ---- pass 2: bits [8:0] of the keys inside the chosen first-level bin; min key of higher bins
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * kSelBins; k += kWideThreads) (&hist[0][0])[k] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr) {
+        unsigned int above = 0xffffffffu;
+        for (unsigned int j = threadIdx.x; j < cnts[arr]; j += kWideThreads) {
+            const unsigned int key = lists[arr][j] & 0xfffffu, b = key >> 9;
+            if (b == top[arr].bin) atomicAdd(&hist[arr][key & 0x1ffu], 1u);
+            else if (b > top[arr].bin) above = min(above, key);
         }
-        found[which] = prefix;
+        above = wave_min_u32(above);
+        if (lane == 0 && above != 0xffffffffu) atomicMin(&s_above[arr], above);
     }
-    *key_r = found[0];
-    *key_r1 = found[1];
+    __syncthreads();
+#pragma unroll
+    for (int arr = 0; arr < 2; ++arr) {
+        const unsigned int want = ranks[arr] - top[arr].below;
+        const CoarsePick lo = pick_coarse_bin(hist[arr], want);
+        found[arr][0] = (top[arr].bin << 9) | lo.bin;
+        found[arr][1] = 0xffffffffu;
+        if (ranks[arr] + 1u < cnts[arr]) {
+            if (want + 1u < top[arr].count) {            // rank r+1 sits in the same first-level bin
+                const CoarsePick hi = pick_coarse_bin(hist[arr], want + 1u);
+                found[arr][1] = (top[arr].bin << 9) | hi.bin;
+            } else {
+                found[arr][1] = s_above[arr];
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(kWideThreads) void wide_select_kernel(WideArgs a, Finish fin) {
-    __shared__ unsigned int hist[kSelBins];
+    __shared__ __attribute__((aligned(16))) unsigned int hist[2][kSelBins];
     __shared__ unsigned int s_omin, s_omax;
     const unsigned int N = a.ws->n;
     const bool bad = a.ws->bad != 0u;
     const int64_t slots = a.B * a.T;
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     float upper = 0.f, lower = 0.f;
+    constexpr int kRows = kWideSlotsPerBlock / kWideThreads;
+    float v_mn[kRows], v_mx[kRows];
+    bool v_ok[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {     // issued first: in flight during the selection below
+        const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
+        v_ok[r] = wide_slot(a, s, &v_mn[r], &v_mx[r]);
+    }
+    OSQ_WSTAMP(0);
     if (N > 0u && !bad) {
         const WideRanks rk = wide_ranks(N, a.q);
         float thr[2];
+        stage_coarse_tables(a.ws, hist);
+        const CoarsePick c0 = pick_coarse_bin(hist[0], rk.k_lo);
+        const CoarsePick c1 = pick_coarse_bin(hist[1], rk.k_lo);
+        __syncthreads();
+        OSQ_WSTAMP(1);
+        unsigned int found[2][2];
+        list_select2(a.list, c0.count, rk.k_lo - c0.below, a.list + slots, c1.count, rk.k_lo - c1.below, hist, found);
+        OSQ_WSTAMP(2);
+        if (threadIdx.x == 0 && blockIdx.x == 0) { OSQ_DBGVAL(6, c0.count); OSQ_DBGVAL(7, c1.count); }
+#pragma unroll
         for (int arr = 0; arr < 2; ++arr) {
-            const CoarsePick p = pick_coarse_bin(a.ws->hist[arr], rk.k_lo);
-            unsigned int lo20, hi20;
-            list_select(a.list + static_cast<int64_t>(arr) * slots, p.count, rk.k_lo - p.below, hist, &lo20, &hi20);
-            const unsigned int v_lo = (p.bin << kCoarseShift) | lo20;
+            const unsigned int top = (arr ? c1.bin : c0.bin) << kCoarseShift;
+            const unsigned int v_lo = top | found[arr][0];
             unsigned int v_hi = v_lo;
-            if (rk.k_hi != rk.k_lo) v_hi = hi20 != 0xffffffffu ? ((p.bin << kCoarseShift) | hi20) : ~a.ws->next_inv[arr];
+            if (rk.k_hi != rk.k_lo) v_hi = found[arr][1] != 0xffffffffu ? (top | found[arr][1]) : ~a.ws->next_inv[arr];
             const float lo_v = __uint_as_float(v_lo), hi_v = __uint_as_float(v_hi), diff = hi_v - lo_v;
             thr[arr] = (rk.w < 0.5f) ? __builtin_fmaf(rk.w, diff, lo_v) : __builtin_fmaf(rk.w - 1.0f, diff, hi_v);
         }
@@ -926,12 +1028,10 @@ __global__ __launch_bounds__(kWideThreads) void wide_select_kernel(WideArgs a, F
         MinMax pr;
         pr.init();
 #pragma unroll
-        for (int r = 0; r < kWideSlotsPerBlock / kWideThreads; ++r) {
-            const int64_t s = static_cast<int64_t>(blockIdx.x) * kWideSlotsPerBlock + r * kWideThreads + threadIdx.x;
-            float mn = 0.f, mx = 0.f;
-            if (wide_slot(a, s, &mn, &mx)) {
-                if (mn >= lower) pr.mn = fminf(pr.mn, mn);
-                if (mx <= upper) pr.mx = fmaxf(pr.mx, mx);
+        for (int r = 0; r < kRows; ++r) {
+            if (v_ok[r]) {
+                if (v_mn[r] >= lower) pr.mn = fminf(pr.mn, v_mn[r]);
+                if (v_mx[r] <= upper) pr.mx = fmaxf(pr.mx, v_mx[r]);
             }
         }
         pr.mn = wave_min(pr.mn);
@@ -945,6 +1045,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_select_kernel(WideArgs a, F
             atomicMax(&a.ws->thr_omax, s_omax);
         }
     }
+    OSQ_WSTAMP(3);
     __syncthreads();
     if (grid_last_block(a.tickets, gridDim.x)) {
         if (threadIdx.x == 0 && N > 0u) {
@@ -1111,7 +1212,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
-    if (batch * tokens >= kWideMinSlots && workspace && (list_scratch || !prune)) {
+    if (batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune)) {
         Workspace wsp(workspace);
         WideArgs a{token_min, token_max, batch, tokens, lengths, reinterpret_cast<WideState*>(wsp.wide()),
                    static_cast<unsigned int*>(list_scratch), wsp.counter(0), prune, qf};
@@ -1160,4 +1261,17 @@ extern "C" int osq_token_range_finalize_batched(const float* token_min, const fl
     else OSQ_LAUNCH_FINAL(0);
 #undef OSQ_LAUNCH_FINAL
     return check_launch("token_range_finalize_batched");
+}
+
+#ifdef OSQ_FINAL_TIMING
+extern "C" int osq_debug_buffer(void* p) {
+    long long* q = static_cast<long long*>(p);
+    return hipMemcpyToSymbol(HIP_SYMBOL(osq::g_osq_dbg), &q, sizeof(q)) == hipSuccess ? 0 : -2;
+}
+#endif
+
+extern "C" int osq_set_wide_min_slots(int64_t slots) {
+    OSQ_REQUIRE(slots >= 1024, "set_wide_min_slots: threshold below 1024 slots");
+    osq::g_wide_min_slots = slots;
+    return OSQ_OK;
 }

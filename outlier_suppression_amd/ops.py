@@ -304,6 +304,15 @@ def token_view(x, seq_pos, n_lengths=None):
 
 
 _token_scratch = {}
+_wide_min_slots = 32769
+
+
+def set_wide_min_slots(slots):
+    """Token-slot count from which the finaliser uses its three multi-workgroup launches (default 32769)."""
+    global _wide_min_slots
+    _hip.check(_hip.load().osq_set_wide_min_slots(int(slots)), "set_wide_min_slots")
+    _wide_min_slots = int(slots)
+
 
 
 def _scratch(device, n):
@@ -337,7 +346,7 @@ def token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, percentile, 
     lib = _hip.load()
     s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
     dev = tmin.device
-    lst = _scratch(dev, batch * tokens)[2] if batch * tokens >= 8192 else None
+    lst = _scratch(dev, batch * tokens)[2] if batch * tokens >= _wide_min_slots else None
     _hip.check(lib.osq_token_range_finalize(_hip.ptr(tmin), _hip.ptr(tmax), batch, tokens, _hip.ptr(lengths),
                                             int(bool(prune)), float(percentile if prune else 1.0), rule, int(cnt),
                                             _hip.ptr(min_val), _hip.ptr(max_val), _hip.ptr(cur), int(quant_min),

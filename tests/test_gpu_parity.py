@@ -476,8 +476,10 @@ def test_wide_finaliser_vs_oracle(eq32, dev):
     """>= 8192 token slots take the three-launch multi-workgroup finaliser: prune and plain paths, a
     narrow distribution (every key in ONE coarse bin -> the list holds all tokens), heavy duplicates,
     repeated calls (global scratch must come back zeroed)."""
+    from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization.observer import AvgPruneMinMaxObserver, AvgMinMaxObserver
     from oracle import observer_oracle as OB
+    ops.set_wide_min_slots(8192)    # default 32769: exercise the wide path at a size the oracle handles quickly
     gen = torch.Generator().manual_seed(77)
     B, Tn, H = 96, 128, 64          # 12288 slots
     cases = {
@@ -519,3 +521,4 @@ def test_wide_finaliser_vs_oracle(eq32, dev):
     st.percentile = 0.9
     OB.observe_avg_prune_minmax(st, x.numpy(), L.numpy(), 1)
     assert eq32(N(ob2.min_val), st.min_val) and eq32(N(ob2.max_val), st.max_val)
+    ops.set_wide_min_slots(32769)

@@ -6,3 +6,5 @@ keys line up; the transformer maths itself is stock PyTorch-ROCm (r
 """
 from .quant_bert import (QuantizedBertForSequenceClassification, QuantizedBertForQuestionAnswering,  # noqa: F401
                          QuantizedBertModel)
+from .quant_roberta import (QuantizedRobertaForSequenceClassification, QuantizedRobertaForQuestionAnswering,  # noqa: F401
+                            QuantizedRobertaModel)

@@ -1,11 +1,13 @@
 """Wrap an FP HuggingFace model into its quantized counterpart (reference: solver/quant_model.py:31-50)."""
 import copy
 
-from .model import quant_bert
+from .model import quant_bert, quant_roberta
 
 _WRAPPERS = {
     "BertForSequenceClassification": quant_bert.QuantizedBertForSequenceClassification,
     "BertForQuestionAnswering": quant_bert.QuantizedBertForQuestionAnswering,
+    "RobertaForSequenceClassification": quant_roberta.QuantizedRobertaForSequenceClassification,
+    "RobertaForQuestionAnswering": quant_roberta.QuantizedRobertaForQuestionAnswering,
 }
 
 

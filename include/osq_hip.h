@@ -75,6 +75,10 @@ const char* osq_last_error(void);
 int         osq_abi_version(void);
 size_t      osq_workspace_bytes(void);
 
+/* Performance knobs (results never change): "fq_unroll" 2|4|8 independent 16-byte loads per lane,
+ * "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 = non-temporal loads/stores of the dense fake-quant. */
+int osq_set_tuning(const char* key, int value);
+
 /* ------------------------------------------------------------------ fake-quant forward */
 
 /* util_quant.py:11-15 fake_quantize_per_tensor_affine, as called by

@@ -36,6 +36,7 @@ SIGNATURES = {
     "osq_last_error": (ctypes.c_char_p, []),
     "osq_abi_version": (_I, []),
     "osq_workspace_bytes": (ctypes.c_size_t, []),
+    "osq_set_tuning": (_I, [ctypes.c_char_p, _I]),
     "osq_fake_quant_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
                                                _P, _P, _I, _I, _F, _I, _I, _P]),

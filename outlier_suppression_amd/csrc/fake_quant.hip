@@ -5,13 +5,20 @@
 // elementwise passes.  Bandwidth-bound: 16-byte global loads/stores per lane,
 // four independent 16-byte loads in flight per lane before any arithmetic,
 // grid sized to a few waves per SIMD and grid-strided above that.
+#include <string>
 #include "osq_device.h"
 #include "osq_host.h"
 
 namespace osq {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 4;   // float4 loads in flight per lane
+constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel kernel)
+
+// tuning knobs of the dense per-tensor kernel (osq_set_tuning): loads in flight per lane, grid cap, and
+// whether loads / stores carry the non-temporal hint
+static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
+static int g_fq_max_blocks = 8192;
+static int g_fq_nt = 3;          // bit 0: loads, bit 1: stores
 
 template <bool WRITE_Q>
 __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float s, float z, float qmin, float qmax) {
@@ -27,7 +34,7 @@ __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float
 
 // ---------------------------------------------------------------- per-tensor, dense
 
-template <bool WRITE_Q>
+template <bool WRITE_Q, int UNROLL, int NT>
 __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float4* __restrict__ x, float4* __restrict__ y, float4* __restrict__ xq, int64_t n4,
     const float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ xqt, int tail,
@@ -37,17 +44,17 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float s = p.scale, z = p.zp;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    // main body: kUnroll independent 16-byte loads, then arithmetic, then stores
-    for (; i + (kUnroll - 1) * stride < n4; i += kUnroll * stride) {
-        float4 v[kUnroll];
+    // main body: UNROLL independent 16-byte loads, then arithmetic, then stores
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load_stream(&x[i + u * stride]);
+        for (int u = 0; u < UNROLL; ++u) v[u] = (NT & 1) ? load_stream(&x[i + u * stride]) : x[i + u * stride];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             float4 o, q;
             fq4<WRITE_Q>(v[u], o, q, s, z, qmin, qmax);
-            store_stream(&y[i + u * stride], o);
-            if (WRITE_Q) store_stream(&xq[i + u * stride], q);
+            if (NT & 2) store_stream(&y[i + u * stride], o); else y[i + u * stride] = o;
+            if (WRITE_Q) { if (NT & 2) store_stream(&xq[i + u * stride], q); else xq[i + u * stride] = q; }
         }
     }
     for (; i < n4; i += stride) {
@@ -338,16 +345,23 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
     if (aligned) {
         const int64_t n4 = n / 4;
         const int tail = static_cast<int>(n - n4 * 4);
-        const int grid = grid_for(n4, kThreads * kUnroll, kMaxBlocks);
+        const int grid = grid_for(n4, kThreads * g_fq_unroll, g_fq_max_blocks);
         const float4* x4 = reinterpret_cast<const float4*>(x);
         float4* y4 = reinterpret_cast<float4*>(y);
         float4* q4 = reinterpret_cast<float4*>(x_quant);
-        if (x_quant)
-            hipLaunchKernelGGL(fq_tensor_vec_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, n4, x + n4 * 4,
-                               y + n4 * 4, x_quant + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
-        else
-            hipLaunchKernelGGL(fq_tensor_vec_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, n4, x + n4 * 4,
-                               y + n4 * 4, nullptr, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+#define OSQ_FQ(WQ, U, N)                                                                                                  \
+    hipLaunchKernelGGL((fq_tensor_vec_kernel<WQ, U, N>), dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, n4, x + n4 * 4,   \
+                       y + n4 * 4, x_quant ? x_quant + n4 * 4 : nullptr, tail, scale, zero_point, zp_type, mode,           \
+                       grad_factor, qmin, qmax)
+#define OSQ_FQ_NT(WQ, U)                                                   \
+    switch (g_fq_nt) { case 0: OSQ_FQ(WQ, U, 0); break; case 1: OSQ_FQ(WQ, U, 1); break; \
+                       case 2: OSQ_FQ(WQ, U, 2); break; default: OSQ_FQ(WQ, U, 3); }
+        if (x_quant) { OSQ_FQ_NT(true, 4) }
+        else if (g_fq_unroll == 2) { OSQ_FQ_NT(false, 2) }
+        else if (g_fq_unroll == 8) { OSQ_FQ_NT(false, 8) }
+        else { OSQ_FQ_NT(false, 4) }
+#undef OSQ_FQ_NT
+#undef OSQ_FQ
     } else {
         const int grid = grid_for(n, kThreads, kMaxBlocks);
         if (x_quant)
@@ -470,4 +484,14 @@ extern "C" int osq_lsq_sanitize(float* scale, float* zero_point, int64_t n, floa
                        static_cast<hipStream_t>(stream), scale, zero_point, n, eps, static_cast<float>(quant_min),
                        static_cast<float>(quant_max));
     return check_launch("lsq_sanitize");
+}
+
+extern "C" int osq_set_tuning(const char* key, int value) {
+    OSQ_REQUIRE(key, "set_tuning: null key");
+    const std::string k(key);
+    if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
+    else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
+    else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 3, "fq_nt must be 0..3"); osq::g_fq_nt = value; }
+    else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
+    return OSQ_OK;
 }

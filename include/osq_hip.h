@@ -253,6 +253,43 @@ int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt,
                               float* scale_out, void* zero_point_out, int zp_type,
                               int32_t* nfev, osq_stream stream);
 
+/* ------------------------------------------------------------------ remaining observers of ObserverDict */
+
+/* LSQPlusObserver.forward (observer.py:159-173): min/max = mean -+ 3*std (unbiased) of x viewed as
+ * [outer, channels, inner]; channels == 1 is the per-tensor form (needs workspace).  Not accumulated
+ * across calls, as in the reference.  Optional qparams. */
+int osq_observe_moments(const float* x, int64_t outer, int64_t channels, int64_t inner,
+                        float* min_val, float* max_val, int quant_min, int quant_max, int symmetric,
+                        float* scale_out, void* zero_point_out, int zp_type,
+                        void* workspace, osq_stream stream);
+
+/* AvgQuantileObserver.forward (observer.py:253-282) after the tensor's own (min, max) is known
+ * (cur_minmax, 2 device floats): torch.histc(|x|, 2048, 0, max(-min, max)) with torch's binning
+ * (linear estimate + local search against the linspace edges), clip at the bin where the
+ * cumulative count reaches threshold * numel, running mean, optional qparams.  x is either flat
+ * (view == NULL, n elements) or a token view with valid lengths.  hist_scratch: 2048 uint32,
+ * zero on entry, left zeroed. */
+int osq_observe_quantile(const float* x, int64_t n, const osq_token_view* view, const int64_t* lengths,
+                         const float* cur_minmax, double threshold, uint32_t* hist_scratch,
+                         int update_rule, int64_t cnt, float* min_val, float* max_val,
+                         int quant_min, int quant_max, int symmetric,
+                         float* scale_out, void* zero_point_out, int zp_type, osq_stream stream);
+
+/* MSEObserver / AvgMSEObserver (observer.py:285-409): brute-force grid of 100 clipping ranges
+ * (1-D, symmetric or one-sided data) or 100 ranges x (quant_max-quant_min+1) zero-points (2-D);
+ * 32 candidates are evaluated per pass over the data.  loss_scratch: osq_mse_grid_candidates() floats. */
+int osq_mse_grid_candidates(int quant_min, int quant_max, int two_d);
+int osq_mse_grid_tensor(const float* x, int64_t n, const osq_token_view* view, const int64_t* lengths,
+                        const float* cur_minmax, int quant_min, int quant_max, int symmetric,
+                        int one_side, int two_d, float* loss_scratch,
+                        int update_rule, int64_t cnt, float* min_val, float* max_val,
+                        float* scale_out, void* zero_point_out, int zp_type,
+                        void* workspace, osq_stream stream);
+/* per-channel form (observer.py:297-301,316-323): one wave per row of w[rows, cols]. */
+int osq_mse_grid_rows(const float* w, int64_t rows, int64_t cols, int quant_min, int quant_max,
+                      int symmetric, int one_side, int two_d,
+                      float* best_min, float* best_max, osq_stream stream);
+
 /* ------------------------------------------------------------------ gamma migration */
 
 /* gamma_migration.py:70-71  w.weight.data *= gamma  (gamma broadcast over columns). */

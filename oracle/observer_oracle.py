@@ -360,3 +360,139 @@ def observe_msefast(st, x, lengths=None, seq_pos=-1, average=False, counter=None
         st._avg_update(best_min, best_max)
     else:
         st._running_update(best_min, best_max)
+
+
+# ---------------------------------------------------------------------------
+# remaining observers of ObserverDict
+# ---------------------------------------------------------------------------
+
+def observe_lsqplus(st, x):
+    """LSQPlusObserver.forward, observer.py:159-173: range = mean -+ 3 std (unbiased std), not accumulated.
+    Moments are taken in float64 and rounded to fp32 (torch's own accumulation order is not part of
+    the reference); compare with a 1e-6 tolerance."""
+    x = np.asarray(x, dtype=F32)
+    if x.size == 0:
+        return
+    assert st.symmetric
+    if st.ch_axis == -1:
+        mean = F32(x.astype(np.float64).mean())
+        std = F32(x.astype(np.float64).std(ddof=1))
+    else:
+        rows = _to_channel_rows(x, st.ch_axis).astype(np.float64)
+        mean = rows.mean(axis=1).astype(F32)
+        std = rows.std(axis=1, ddof=1).astype(F32)
+    st.min_val = np.asarray(mean - F32(3) * std)
+    st.max_val = np.asarray(mean + F32(3) * std)
+
+
+def linspace_edge(i, start, end, steps):
+    """torch.linspace element i in fp32 (scalar form): start + step*i below the midpoint, end - step*(steps-1-i) above."""
+    step = F32(F32(end) - F32(start)) / F32(steps - 1)
+    if i < steps // 2:
+        return F32(F32(start) + F32(step * F32(i)))
+    return F32(F32(end) - F32(step * F32(steps - i - 1)))
+
+
+def torch_histc(values, bins, vmin, vmax):
+    """torch.histc(values, bins, min, max) on the CPU (observer.py:263): linear bin estimate followed by the
+    local search against the linspace edges; the last bin is closed on the right; values outside are dropped."""
+    v = np.asarray(values, dtype=F32).reshape(-1)
+    lo, hi = F32(vmin), F32(vmax)
+    counts = np.zeros(bins, dtype=np.int64)
+    if not (hi > lo):
+        hi = F32(lo + F32(1)) if hi == lo else hi       # torch widens an empty range to [min, min + 1]... only via min==max==0
+    edges = np.array([linspace_edge(i, lo, hi, bins + 1) for i in range(bins + 1)], dtype=F32)
+    inside = (v >= lo) & (v <= hi)
+    vi = v[inside]
+    pos = (F32(vi - lo) * F32(bins) / F32(hi - lo)).astype(np.int64)
+    for e, p in zip(vi, pos):
+        a, b = max(0, p - 1), min(p + 2, bins + 1)
+        j = a + int(np.searchsorted(edges[a:b], e, side="right")) - 1
+        if j == bins:
+            j -= 1
+        counts[j] += 1
+    return counts.astype(F32)
+
+
+def quantile_clip_from_hist(hist, numel, threshold, max_range, bins):
+    """observer.py:264-270: first bin whose cumulative count reaches threshold*numel -> bin centre."""
+    cur = F32(0)
+    target = F32(threshold * numel)            # fp32 tensor compared with a Python float
+    clip = F32(max_range)
+    for i in range(bins):
+        if F32(cur + hist[i]) >= target:
+            clip = F32(F32(i + 0.5) * F32(F32(max_range) / F32(bins)))
+            break
+        cur = F32(cur + hist[i])
+    return clip
+
+
+def observe_avg_quantile(st, x, lengths=None, seq_pos=-1, threshold=0.99999, bins=2048):
+    """AvgQuantileObserver.forward, observer.py:253-282."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = _prepare(x, lengths, seq_pos)
+    mn, mx = aminmax(x)
+    max_range = F32(max(F32(-mn), mx))
+    hist = torch_histc(np.abs(x), bins, 0.0, max_range)
+    clip = quantile_clip_from_hist(hist, x.size, threshold, max_range, bins)
+    st._avg_update(F32(max(mn, F32(-clip))), F32(min(mx, clip)))
+
+
+def mse_grid_loss(x, new_min, new_max, quant_min, quant_max, symmetric):
+    """MSEObserver.loss_fx + lp_loss (observer.py:292-312), per-tensor: fp32 qparams, int zero-point."""
+    scale, zp = calculate_qparams(F32(new_min), F32(new_max), quant_min, quant_max, symmetric)
+    _, y = fake_quantize_per_tensor_affine(x, F32(scale), F32(int(zp)), quant_min, quant_max)
+    d = np.abs(y - x)
+    return F32((d * d).astype(np.float64).mean())
+
+
+def mse_grid_search(x, st, num=100):
+    """perform_1D_search / perform_2D_search (observer.py:314-364) for one tensor (or one channel row)."""
+    x = np.asarray(x, dtype=F32)
+    x_min, x_max = aminmax(x)
+    best_score, best_min, best_max = F32(1e10), x_min, x_max
+    if st.one_side_dist != "no" or st.symmetric:
+        xr = F32(max(abs(x_min), x_max))
+        for i in range(1, num + 1):
+            thres = F32(F32(xr / F32(num)) * F32(i))
+            lo = F32(0) if st.one_side_dist == "pos" else F32(-thres)
+            hi = F32(0) if st.one_side_dist == "neg" else thres
+            score = mse_grid_loss(x, lo, hi, st.quant_min, st.quant_max, st.symmetric)
+            if score < best_score:
+                best_score, best_min, best_max = score, lo, hi
+        return best_min, best_max
+    xr = F32(x_max - x_min)
+    span = F32(float(st.quant_max - st.quant_min))
+    for i in range(1, num + 1):
+        tmp_max = F32(F32(xr / F32(num)) * F32(i))
+        delta = F32(tmp_max / span)
+        for zp in range(st.quant_min, st.quant_max + 1):
+            lo = F32(max(F32(F32(0) - F32(F32(zp) * delta)), x_min))
+            hi = F32(min(F32(tmp_max - F32(F32(zp) * delta)), x_max))
+            score = mse_grid_loss(x, lo, hi, st.quant_min, st.quant_max, st.symmetric)
+            if score < best_score:
+                best_score, best_min, best_max = score, lo, hi
+    return best_min, best_max
+
+
+def observe_mse(st, x, lengths=None, seq_pos=-1, average=False):
+    """MSEObserver.forward (observer.py:366-378) / AvgMSEObserver.forward (:387-409)."""
+    x = np.asarray(x)
+    if x.size == 0:
+        return
+    x = _prepare(x, lengths, seq_pos)
+    if st.one_side_dist is None:
+        st.one_side_dist = one_side_dist(x)
+    if st.ch_axis == -1:
+        best_min, best_max = mse_grid_search(x, st)
+    else:
+        rows = _to_channel_rows(x, st.ch_axis)
+        res = [mse_grid_search(r, st) for r in rows]
+        best_min = np.array([r[0] for r in res], dtype=F32)
+        best_max = np.array([r[1] for r in res], dtype=F32)
+    if average:
+        st._avg_update(best_min, best_max)
+    else:
+        st._running_update(best_min, best_max)

@@ -59,6 +59,11 @@ SIGNATURES = {
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
     "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "osq_observe_quantile": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _D, _P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "osq_mse_grid_candidates": (_I, [_I, _I, _I]),
+    "osq_mse_grid_tensor": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "osq_mse_grid_rows": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
     "osq_gamma_fold": (_I, [_P, _P, _L, _L, _P]),
     "osq_gamma_split_bias": (_I, [_P, _P, _P, _L, _P]),
     "osq_gamma_residual": (_I, [_P, _P, _P, _P, _L, _L, _P]),

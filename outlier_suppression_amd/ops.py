@@ -463,6 +463,82 @@ def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symm
 
 
 # ---------------------------------------------------------------------------------------
+# remaining observers: LSQPlus (moments), AvgQuantile (histogram), MSE (grid)
+# ---------------------------------------------------------------------------------------
+
+def _source(x, observation_mask, seq_pos):
+    """(x, n, view_or_None, lengths) for kernels that stream either a flat tensor or valid tokens."""
+    if observation_mask is None:
+        if not is_dense(x):
+            x = x.contiguous()
+        return x, x.numel(), None, None
+    lengths = observation_mask if observation_mask.dtype == torch.int64 else observation_mask.to(torch.int64)
+    return x, x.numel(), token_view(x, seq_pos, lengths.numel()), lengths
+
+
+def observe_moments(x, ch_axis, min_val, max_val, quant_min, quant_max, symmetric, sink=None):
+    lib = _hip.load()
+    _hip.require_device(x, min_val, max_val)
+    _check_f32(x, min_val, max_val)
+    x = x.contiguous()
+    outer, channels, inner = (1, 1, x.numel()) if ch_axis == -1 else _channel_split(x, ch_axis)
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    _hip.check(lib.osq_observe_moments(_hip.ptr(x), outer, channels, inner, _hip.ptr(min_val), _hip.ptr(max_val),
+                                       int(quant_min), int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
+                                       _hip.ptr(_hip.workspace(x.device)), _hip.stream_ptr(x.device)), "observe_moments")
+
+
+def observe_quantile(x, observation_mask, seq_pos, cur, threshold, hist_scratch, rule, cnt, min_val, max_val,
+                     quant_min, quant_max, symmetric, sink=None):
+    lib = _hip.load()
+    _hip.require_device(x, cur, hist_scratch, min_val, max_val)
+    _check_f32(x, min_val, max_val)
+    x, n, view, lengths = _source(x, observation_mask, seq_pos)
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    _hip.check(lib.osq_observe_quantile(_hip.ptr(x), n, ctypes.byref(view) if view is not None else None, _hip.ptr(lengths),
+                                        _hip.ptr(cur), float(threshold), _hip.ptr(hist_scratch), rule, int(cnt),
+                                        _hip.ptr(min_val), _hip.ptr(max_val), int(quant_min), int(quant_max),
+                                        int(bool(symmetric)), s_ptr, z_ptr, z_type, _hip.stream_ptr(x.device)),
+               "observe_quantile")
+
+
+def mse_grid_tensor(x, observation_mask, seq_pos, cur, quant_min, quant_max, symmetric, one_side, two_d, rule, cnt,
+                    min_val, max_val, sink=None):
+    lib = _hip.load()
+    _hip.require_device(x, cur, min_val, max_val)
+    _check_f32(x, min_val, max_val)
+    x, n, view, lengths = _source(x, observation_mask, seq_pos)
+    n_cand = int(lib.osq_mse_grid_candidates(int(quant_min), int(quant_max), int(bool(two_d))))
+    losses = torch.empty(n_cand, dtype=torch.float32, device=x.device)
+    s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
+    _hip.check(lib.osq_mse_grid_tensor(_hip.ptr(x), n, ctypes.byref(view) if view is not None else None, _hip.ptr(lengths),
+                                       _hip.ptr(cur), int(quant_min), int(quant_max), int(bool(symmetric)), SIDE[one_side],
+                                       int(bool(two_d)), _hip.ptr(losses), rule, int(cnt), _hip.ptr(min_val),
+                                       _hip.ptr(max_val), s_ptr, z_ptr, z_type, _hip.ptr(_hip.workspace(x.device)),
+                                       _hip.stream_ptr(x.device)), "mse_grid_tensor")
+    return losses
+
+
+def mse_grid_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
+    lib = _hip.load()
+    _hip.require_device(w)
+    _check_f32(w)
+    ch_axis = ch_axis % w.dim()
+    if ch_axis != 0:
+        order = list(range(w.dim()))
+        order[ch_axis], order[0] = 0, ch_axis
+        w = w.permute(order)
+    rows2d = w.reshape(w.shape[0], -1).contiguous()
+    rows, cols = rows2d.shape
+    bmin = torch.empty(rows, dtype=torch.float32, device=w.device)
+    bmax = torch.empty(rows, dtype=torch.float32, device=w.device)
+    _hip.check(lib.osq_mse_grid_rows(_hip.ptr(rows2d), rows, cols, int(quant_min), int(quant_max), int(bool(symmetric)),
+                                     SIDE[one_side], int(bool(two_d)), _hip.ptr(bmin), _hip.ptr(bmax),
+                                     _hip.stream_ptr(w.device)), "mse_grid_rows")
+    return bmin, bmax
+
+
+# ---------------------------------------------------------------------------------------
 # gamma migration
 # ---------------------------------------------------------------------------------------
 

@@ -238,3 +238,100 @@ class AvgMSEFastObserver(MSEFastObserver):
         super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
         self.cnt = 0
         assert self.ch_axis == -1
+
+
+class LSQPlusObserver(ObserverBase):
+    """observer.py:148-173: weight range = mean -+ 3 std (LSQ+ initialisation); symmetric only; every
+    call overwrites the statistic."""
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        assert self.symmetric is True
+        self.mean = None
+        self.std = None
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        self._home(x.device, None if self.ch_axis == -1 else x.shape[self.ch_axis])
+        ops.observe_moments(x, self.ch_axis, self.min_val, self.max_val, self.quant_min, self.quant_max, self.symmetric,
+                            sink)
+
+
+class AvgQuantileObserver(ObserverBase):
+    """observer.py:240-282: clip at the histogram bin where the cumulative count of |x| reaches
+    ``threshold`` of the elements; averaged over batches; per-tensor only."""
+
+    update_rule = UPDATE_AVERAGE
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1, ema_ratio=0.9, threshold=0.99999, bins=2048):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        assert self.ch_axis == -1, "Quantile observer only support in per-tensor scheme."
+        if bins != 2048:
+            raise NotImplementedError("the HIP histogram is built for the reference's 2048 bins")
+        self.ema_ratio, self.threshold, self.bins = ema_ratio, threshold, bins
+        self.cnt = 0
+        self._hist = None
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        if observation_mask is not None:
+            assert self.ch_axis == -1
+        cur = ops.batch_minmax(x, observation_mask, seq_pos)
+        self._home(x.device)
+        if self._hist is None or self._hist.device != x.device:
+            self._hist = torch.zeros(self.bins, dtype=torch.int32, device=x.device)
+        ops.observe_quantile(x, observation_mask, seq_pos, cur, self.threshold, self._hist, self.update_rule,
+                             self._counter(), self.min_val, self.max_val, self.quant_min, self.quant_max,
+                             self.symmetric, sink)
+        self._bump()
+
+
+class MSEObserver(ObserverBase):
+    """observer.py:285-378: brute-force search of the clipping range by quantisation MSE (100 ranges; times
+    every zero-point when the data is two-sided and the scheme asymmetric); running min/max."""
+
+    update_rule = UPDATE_RUNNING
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.p = 2.0
+        self.num = 100
+        self.one_side_dist = None
+
+    def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
+        if observation_mask is not None:
+            assert self.ch_axis == -1
+        cur = ops.batch_minmax(x, observation_mask, seq_pos)
+        if self.one_side_dist is None:          # observer.py:373-374, decided once (one host read)
+            mn, mx = cur.tolist()
+            self.one_side_dist = "pos" if mn >= 0.0 else "neg" if mx <= 0.0 else "no"
+        two_d = not (self.one_side_dist != "no" or self.symmetric)
+        if self.ch_axis == -1:
+            self._home(x.device)
+            ops.mse_grid_tensor(x, observation_mask, seq_pos, cur, self.quant_min, self.quant_max, self.symmetric,
+                                self.one_side_dist, two_d, self.update_rule, self._counter(), self.min_val, self.max_val,
+                                sink)
+        else:
+            bmin, bmax = ops.mse_grid_rows(x, self.ch_axis, self.quant_min, self.quant_max, self.symmetric,
+                                           self.one_side_dist, two_d)
+            self._home(x.device, bmin.numel())
+            ops.observer_update(bmin, bmax, self.update_rule, self._counter(), self.min_val, self.max_val)
+            if sink is not None and sink.scale is not None:
+                ops.calculate_qparams(self.min_val, self.max_val, self.quant_min, self.quant_max, self.symmetric,
+                                      scale_out=sink.scale, zero_point_out=sink.zero_point)
+        self._bump()
+
+    def forward(self, x_orig, observation_mask=None, seq_pos=-1):
+        if x_orig.numel() == 0:
+            return x_orig
+        self.observe_into(x_orig.detach(), observation_mask, seq_pos, None)
+        return None     # as the reference (observer.py:366-378 returns nothing)
+
+
+class AvgMSEObserver(MSEObserver):
+    """observer.py:381-409."""
+
+    update_rule = UPDATE_AVERAGE
+
+    def __init__(self, bit=8, symmetric=False, ch_axis=-1):
+        super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
+        self.cnt = 0
+        assert self.ch_axis == -1

@@ -381,7 +381,67 @@ def gen_gamma():
          res_before=y_before.detach().numpy(), res_after=y_after.detach().numpy(), W=W.numpy(), W_folded=Wf.numpy())
 
 
+# ---------------------------------------------------------------------------
+# remaining observers of ObserverDict: LSQPlusObserver, AvgQuantileObserver, MSEObserver, AvgMSEObserver
+# (observer.py:148-173, 240-282, 285-409)
+# ---------------------------------------------------------------------------
+def gen_other_observers():
+    gen = torch.Generator().manual_seed(4242)
+    out = {}
+    # LSQPlusObserver: mean +- 3 std, symmetric only
+    x = activation_like(gen, (4, 16, 32))
+    ob = O.LSQPlusObserver(bit=8, symmetric=True, ch_axis=-1)
+    ob(x)
+    out["lsqp_x"], out["lsqp_min"], out["lsqp_max"] = x.numpy(), ob.min_val.numpy(), ob.max_val.numpy()
+    w = torch.randn(24, 40, generator=gen) * 0.05
+    ob = O.LSQPlusObserver(bit=4, symmetric=True, ch_axis=0)
+    ob(w)
+    s, z = ob.calculate_qparams(ob.min_val, ob.max_val)
+    out["lsqp_w"], out["lsqp_wmin"], out["lsqp_wmax"], out["lsqp_wscale"] = w.numpy(), ob.min_val.numpy(), ob.max_val.numpy(), s.numpy()
+    # AvgQuantileObserver: 2048-bin histogram of |x|, clip where the cumulative count reaches threshold*numel
+    k = 0
+    for threshold, masked in ((0.99999, True), (0.99, True), (0.9, False), (0.999, True)):
+        ob = O.AvgQuantileObserver(bit=6, symmetric=False, ch_axis=-1, threshold=threshold)
+        xs, lens, mins, maxs = [], [], [], []
+        for it in range(3):
+            x = activation_like(gen, (4, 16, 32))
+            L = torch.randint(1, 17, (4,), generator=gen)
+            ob(x, observation_mask=L if masked else None, seq_pos=1 if masked else -1)
+            xs.append(x.numpy().copy()); lens.append(L.numpy().copy())
+            mins.append(np.asarray(ob.min_val.numpy()).copy()); maxs.append(np.asarray(ob.max_val.numpy()).copy())
+        out[f"aq{k}_x"], out[f"aq{k}_len"] = np.stack(xs), np.stack(lens)
+        out[f"aq{k}_min"], out[f"aq{k}_max"] = np.stack(mins), np.stack(maxs)
+        out[f"aq{k}_meta"] = np.array([threshold, float(masked)])
+        k += 1
+    out["aq_n"] = k
+    # one larger histogram case to pin the binning itself
+    xl = activation_like(gen, (8, 64, 96), outlier_dims=3)
+    mx = torch.max(-xl.min(), xl.max())
+    out["hist_x"], out["hist_counts"] = xl.numpy(), torch.histc(torch.abs(xl), bins=2048, min=0.0, max=mx).numpy()
+    # MSEObserver / AvgMSEObserver: brute-force grid (100 ranges x (qmax-qmin+1) zero-points in 2-D)
+    k = 0
+    specs = [("MSEObserver", activation_like(gen, (4, 16, 32)), 4, True, -1, 1),                      # 1-D symmetric
+             ("MSEObserver", torch.relu(activation_like(gen, (4, 16, 32))), 4, False, -1, 1),          # 1-D one-sided
+             ("MSEObserver", activation_like(gen, (4, 16, 32)), 4, False, -1, 1),                      # 2-D (100 x 16)
+             ("MSEObserver", torch.randn(12, 40, generator=gen) * 0.05, 4, True, 0, 1),               # per-channel 1-D
+             ("AvgMSEObserver", torch.stack([activation_like(gen, (2, 8, 32)) for _ in range(2)]), 4, False, -1, 2)]
+    for (cls_name, x, bit, sym, ch_axis, reps) in specs:
+        ob = QM.ObserverDict[cls_name](bit=bit, symmetric=sym, ch_axis=ch_axis)
+        mins, maxs = [], []
+        for r in range(reps):
+            ob(x[r] if reps > 1 else x)
+            mins.append(np.asarray(ob.min_val.numpy()).copy()); maxs.append(np.asarray(ob.max_val.numpy()).copy())
+        out[f"mse{k}_x"], out[f"mse{k}_min"], out[f"mse{k}_max"] = x.numpy(), np.stack(mins), np.stack(maxs)
+        out[f"mse{k}_info"] = np.array([cls_name, str(bit), str(int(sym)), str(ch_axis), str(reps), ob.one_side_dist])
+        k += 1
+    out["mse_n"] = k
+    save("other_observers", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "other":
+        gen_other_observers()
+        sys.exit(0)
     gen_fake_quant()
     gen_lsqplus()
     gen_qparams()
@@ -389,3 +449,4 @@ if __name__ == "__main__":
     gen_msefast()
     gen_modules()
     gen_gamma()
+    gen_other_observers()

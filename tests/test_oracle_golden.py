@@ -212,3 +212,42 @@ def test_torch_eager_restatement_matches_golden(golden, eq32):
         assert eq32(y.numpy(), y_np)
         checked += 1
     assert checked >= 5
+
+
+def test_other_observers(golden, eq32):
+    """LSQPlusObserver, AvgQuantileObserver (incl. the torch.histc replica), MSEObserver / AvgMSEObserver."""
+    import torch
+    g = golden("other_observers")
+    st = OB.ObserverState(bit=8, symmetric=True)
+    OB.observe_lsqplus(st, g["lsqp_x"])
+    np.testing.assert_allclose(st.min_val, g["lsqp_min"], rtol=2e-6)
+    np.testing.assert_allclose(st.max_val, g["lsqp_max"], rtol=2e-6)
+    st = OB.ObserverState(bit=4, symmetric=True, ch_axis=0)
+    OB.observe_lsqplus(st, g["lsqp_w"])
+    np.testing.assert_allclose(st.min_val, g["lsqp_wmin"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(st.max_val, g["lsqp_wmax"], rtol=1e-5, atol=1e-7)
+    # histogram replica: exact counts on the golden case and against the installed torch on fresh data
+    x = g["hist_x"]
+    rng = float(max(-x.min(), x.max()))
+    assert np.array_equal(OB.torch_histc(np.abs(x), 2048, 0.0, rng), g["hist_counts"])
+    r = np.random.default_rng(3).standard_normal(20000).astype(F32) * 3
+    assert np.array_equal(OB.torch_histc(np.abs(r), 2048, 0.0, float(np.abs(r).max())),
+                          torch.histc(torch.from_numpy(np.abs(r)), bins=2048, min=0.0, max=float(np.abs(r).max())).numpy())
+    for k in range(int(g["aq_n"])):
+        threshold, masked = float(g[f"aq{k}_meta"][0]), bool(g[f"aq{k}_meta"][1])
+        st = OB.ObserverState(bit=6)
+        for it in range(3):
+            OB.observe_avg_quantile(st, g[f"aq{k}_x"][it], g[f"aq{k}_len"][it] if masked else None, 1 if masked else -1,
+                                    threshold=threshold)
+            assert eq32(st.min_val, g[f"aq{k}_min"][it]) and eq32(st.max_val, g[f"aq{k}_max"][it]), (k, it)
+    for k in range(int(g["mse_n"])):
+        cls, bit, sym, ch_axis, reps, osd = (str(v) for v in g[f"mse{k}_info"])
+        st = OB.ObserverState(bit=int(bit), symmetric=bool(int(sym)), ch_axis=int(ch_axis))
+        x = g[f"mse{k}_x"]
+        for r_ in range(int(reps)):
+            OB.observe_mse(st, x[r_] if int(reps) > 1 else x, average=cls.startswith("Avg"))
+            # grid points are compared by fp32 losses whose summation order differs: near-ties may pick the
+            # neighbouring grid point (1 % of the range)
+            np.testing.assert_allclose(st.min_val, g[f"mse{k}_min"][r_], rtol=0.03, atol=1e-6)
+            np.testing.assert_allclose(st.max_val, g[f"mse{k}_max"][r_], rtol=0.03, atol=1e-6)
+        assert st.one_side_dist == osd

@@ -8,3 +8,4 @@ from .quant_bert import (QuantizedBertForSequenceClassification, QuantizedBertFo
                          QuantizedBertModel)
 from .quant_roberta import (QuantizedRobertaForSequenceClassification, QuantizedRobertaForQuestionAnswering,  # noqa: F401
                             QuantizedRobertaModel)
+from .quant_bart import QuantizedBartForConditionalGeneration, QuantizedBartModel  # noqa: F401

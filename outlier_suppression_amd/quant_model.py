@@ -1,13 +1,14 @@
 """Wrap an FP HuggingFace model into its quantized counterpart (reference: solver/quant_model.py:31-50)."""
 import copy
 
-from .model import quant_bert, quant_roberta
+from .model import quant_bart, quant_bert, quant_roberta
 
 _WRAPPERS = {
     "BertForSequenceClassification": quant_bert.QuantizedBertForSequenceClassification,
     "BertForQuestionAnswering": quant_bert.QuantizedBertForQuestionAnswering,
     "RobertaForSequenceClassification": quant_roberta.QuantizedRobertaForSequenceClassification,
     "RobertaForQuestionAnswering": quant_roberta.QuantizedRobertaForQuestionAnswering,
+    "BartForConditionalGeneration": quant_bart.QuantizedBartForConditionalGeneration,
 }
 
 

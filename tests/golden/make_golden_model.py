@@ -188,5 +188,109 @@ def main():
           "full:", np.abs(out["logits_full_quant"] - out["logits_wrapped_fp"]).max())
 
 
+def tiny_bart():
+    """Seeded tiny BART in the 4.18-era module layout the reference wrappers expect (plain nn.Embedding token
+    tables + embed_scale on the stacks)."""
+    from torch import nn
+    from transformers import BartConfig, BartForConditionalGeneration
+    torch.manual_seed(20240930)
+    cfg = BartConfig(vocab_size=120, d_model=32, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2,
+                     decoder_attention_heads=2, encoder_ffn_dim=64, decoder_ffn_dim=64, max_position_embeddings=40,
+                     dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, pad_token_id=1, bos_token_id=0,
+                     eos_token_id=2, decoder_start_token_id=2)
+    fp = BartForConditionalGeneration(cfg).eval()
+
+    def plain(e):
+        p = nn.Embedding(e.num_embeddings, e.embedding_dim, padding_idx=e.padding_idx)
+        p.weight.data = e.weight.data.clone()
+        return p
+    fp.model.shared = plain(fp.model.shared)
+    for m in (fp.model.encoder, fp.model.decoder):
+        m.embed_tokens = plain(m.embed_tokens)
+        m.embed_scale = 1.0
+        m.gradient_checkpointing = False
+    fp.model.encoder.max_source_positions = 40
+    fp.model.decoder.max_target_positions = 40
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(11)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(torch.rand(32, generator=g) * 1.2 + 0.4)
+                m.weight[7] = 3.5
+                m.bias.copy_(torch.randn(32, generator=g) * 0.2)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.Linear) and m is not fp.lm_head:
+                m.weight.mul_(4.0)
+    return cfg, fp
+
+
+def main_bart():
+    """BART: wrap -> gamma migration -> weight calibration -> one observer pass at percentile 0.9 (set_ratio +
+    calibrate, token_wise_clipping.py:12-47) -> activation quantisation.  Exercises the reference's BART quirks:
+    3-D attention probabilities against a length-B mask, cross-attention keys masked with decoder lengths."""
+    QB, GM, TWC, ST, QuantizeBase = import_reference()
+    gu = types.ModuleType("transformers.generation_utils")
+    from transformers.generation import GenerationMixin
+    gu.GenerationMixin = GenerationMixin
+    sys.modules["transformers.generation_utils"] = gu
+    from quant_transformer.model import quant_bart as RB
+    torch.set_num_threads(1)
+    cfg, fp = tiny_bart()
+    out = {f"sd::{k}": v.numpy() for k, v in fp.state_dict().items()}
+    B, S, Td, NB = 3, 14, 6, 3
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for b in range(NB):
+        L = torch.randint(4, S + 1, (B,), generator=g)
+        L[b % B] = S
+        mask = (torch.arange(S)[None, :] < L[:, None]).long()
+        ids = torch.randint(3, 120, (B, S), generator=g) * mask + (1 - mask)
+        DL = torch.randint(2, Td + 1, (B,), generator=g)
+        DL[(b + 1) % B] = Td
+        dmask = (torch.arange(Td)[None, :] < DL[:, None]).long()
+        dids = torch.randint(3, 120, (B, Td), generator=g) * dmask + (1 - dmask)
+        batches.append({"input_ids": ids, "attention_mask": mask, "decoder_input_ids": dids, "decoder_attention_mask": dmask})
+    for k in ("input_ids", "attention_mask", "decoder_input_ids", "decoder_attention_mask"):
+        out[k] = np.stack([b[k].numpy() for b in batches])
+    a_q = Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    model = RB.QuantizedBartForConditionalGeneration(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
+                                                     is_remove_padding=True).eval()
+    kw = dict(use_cache=False, return_dict=False)
+    with torch.no_grad():
+        out["logits_wrapped_fp"] = np.stack([model(**b, **kw)[0].numpy() for b in batches])
+    model = GM.delay_ln(model, Cfg(a_qconfig=a_q, w_qconfig=w_q), Cfg(model_type="bart", task_type="summ"))
+    with torch.no_grad():
+        out["logits_after_gamma"] = np.stack([model(**b, **kw)[0].numpy() for b in batches])
+    out["module_names"] = np.array([n for n, _ in model.named_modules()])
+    ST.enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+    with torch.no_grad():
+        model(**batches[0], **kw)
+    ST.disable_all(model)
+    ST.set_observer_name(model)
+    TWC.set_ratio(model, 0.9)
+    with torch.no_grad():
+        for b in batches:
+            model(**b, **kw)
+    names, scales, zps = quantizer_table(model, QuantizeBase)
+    out["q_names"] = np.array(names)
+    for i, (s, z) in enumerate(zip(scales, zps)):
+        out[f"q_scale::{i}"], out[f"q_zp::{i}"] = s, z
+    obs = [(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+    out["act_min"] = np.array([float(m.observer.min_val) for _, m in obs])
+    out["act_max"] = np.array([float(m.observer.max_val) for _, m in obs])
+    TWC.enable_quantization(model)
+    with torch.no_grad():
+        out["logits_act_quant"] = np.stack([model(**b, **kw)[0].numpy() for b in batches])
+    path = os.path.join(OUT, "bart_tiny_pipeline.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(names), "quantizers; drift gamma",
+          np.abs(out["logits_after_gamma"] - out["logits_wrapped_fp"]).max(), "act-quant",
+          np.abs(out["logits_act_quant"] - out["logits_wrapped_fp"]).max())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bart":
+        main_bart()
+    else:
+        main()

@@ -80,3 +80,57 @@ def test_same_tree_names_and_fp_logits(ref, case):
         o = ours(input_ids=ids, attention_mask=mask)
     for a, b in zip(r[:len(o)], o):
         assert torch.equal(a, b)
+
+
+def test_bart_same_tree_names_and_fp_logits(ref):
+    M, QB, RQ, RefQuantizeBase = ref
+    import transformers as T
+    from torch import nn
+    gu = types.ModuleType("transformers.generation_utils")
+    from transformers.generation import GenerationMixin
+    gu.GenerationMixin = GenerationMixin
+    sys.modules["transformers.generation_utils"] = gu
+    from quant_transformer.model import quant_bart as RB
+    from outlier_suppression_amd.model import quant_bart as OB
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    torch.manual_seed(2)
+    cfg = T.BartConfig(vocab_size=120, d_model=32, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2,
+                       decoder_attention_heads=2, encoder_ffn_dim=64, decoder_ffn_dim=64, max_position_embeddings=40,
+                       dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, pad_token_id=1, bos_token_id=0,
+                       eos_token_id=2, decoder_start_token_id=2)
+    fp = T.BartForConditionalGeneration(cfg).eval()
+
+    def plain(e):      # the 4.18-era layout the reference wrappers expect: plain nn.Embedding + embed_scale on the stack
+        p = nn.Embedding(e.num_embeddings, e.embedding_dim, padding_idx=e.padding_idx)
+        p.weight.data = e.weight.data.clone()
+        return p
+    fp.model.shared = plain(fp.model.shared)
+    for m in (fp.model.encoder, fp.model.decoder):
+        m.embed_tokens = plain(m.embed_tokens)
+        m.embed_scale = 1.0
+        m.gradient_checkpointing = False
+    fp.model.encoder.max_source_positions = 40
+    fp.model.decoder.max_target_positions = 40
+    a_q = M.Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = M.Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    theirs = RB.QuantizedBartForConditionalGeneration(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
+                                                      is_remove_padding=True).eval()
+    ours = OB.QuantizedBartForConditionalGeneration(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
+                                                    is_remove_padding=True).eval()
+    ref_q = [n for n, m in theirs.named_modules() if isinstance(m, RefQuantizeBase)]
+    our_q = [n for n, m in ours.named_modules() if isinstance(m, QuantizeBase)]
+    assert our_q == ref_q and len(our_q) == 2 * 8 + 2 * 14 + 2 + 2 * 6 + 2 * 10 + 3 + 2 + 1
+    assert [n for n, _ in ours.named_modules()] == [n for n, _ in theirs.named_modules()]
+    ids = torch.randint(3, 100, (3, 12))
+    L = torch.tensor([12, 7, 4])
+    mask = (torch.arange(12)[None] < L[:, None]).long()
+    ids = ids * mask + (1 - mask)
+    dids = torch.randint(3, 100, (3, 6))
+    DL = torch.tensor([6, 3, 5])
+    dmask = (torch.arange(6)[None] < DL[:, None]).long()
+    dids = dids * dmask + (1 - dmask)
+    with torch.no_grad():
+        r = theirs(input_ids=ids, attention_mask=mask, decoder_input_ids=dids, decoder_attention_mask=dmask,
+                   use_cache=False, return_dict=False)
+        o = ours(input_ids=ids, attention_mask=mask, decoder_input_ids=dids, decoder_attention_mask=dmask)
+    assert torch.equal(r[0], o[0])

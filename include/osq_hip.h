@@ -207,7 +207,7 @@ int osq_token_range_finalize_batched(const float* token_min, const float* token_
                                      int64_t problem_stride, int n_quantizers, int n_batches,
                                      int64_t batch, int64_t tokens, const int64_t* lengths,
                                      const int32_t* prune_flags, double percentile,
-                                     float* cur_table, osq_stream stream);
+                                     float* cur_table, void* workspace, osq_stream stream);
 
 /* Running statistic for a batch (min, max) that is already known -- the replay step
  * of sharded calibration (gathered per-batch statistics applied in global batch

@@ -15,5 +15,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace osq
 
 extern "C" const char* osq_last_error(void) { return osq::g_error; }
-extern "C" int osq_abi_version(void) { return 1; }
-extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes; }
+extern "C" int osq_abi_version(void) { return 2; }
+extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes; }

@@ -250,10 +250,22 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
         publish_f64(&partials[2 * blockIdx.x + 1], b);
     }
     if (grid_last_block(counter, gridDim.x)) {
+        // all loads first (ordered agent-scope loads consumed one by one cost a memory round trip each),
+        // then the same lane-strided summation order as before
+        constexpr int kPer = kMaxBlocks / kThreads;
+        double pa[kPer], pb[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned int k = threadIdx.x + j * kThreads, kc = k < gridDim.x ? k : gridDim.x - 1;
+            pa[j] = consume_f64(&partials[2 * kc]);
+            pb[j] = consume_f64(&partials[2 * kc + 1]);
+        }
         double a = 0.0, b = 0.0;
-        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) {
-            a += consume_f64(&partials[2 * k]);
-            b += consume_f64(&partials[2 * k + 1]);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const bool in = threadIdx.x + j * kThreads < gridDim.x;
+            a += in ? pa[j] : 0.0;
+            b += in ? pb[j] : 0.0;
         }
         // fixed combination order: lane-strided partial sums, then wave tree, then waves in order
         a = wave_sum(a);
@@ -492,6 +504,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 3, "fq_nt must be 0..3"); osq::g_fq_nt = value; }
+    else if (osq::set_observer_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
     return OSQ_OK;
 }

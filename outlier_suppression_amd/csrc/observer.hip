@@ -6,6 +6,7 @@
 // Wave64 shuffle reductions, LDS across waves, and a last-workgroup finaliser so
 // that a whole observer call (reduce -> running statistic -> scale/zero_point) is
 // one launch for flat / per-channel tensors and two for masked activations.
+#include <string>
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -67,13 +68,18 @@ struct Finish {   // what happens once a batch's (min, max) is known
     int zp_type;
 };
 
-__device__ __forceinline__ void finish_entry(const Finish& f, int64_t idx, float cur_min, float cur_max) {
+// have_state: the caller already holds min_val[idx] / max_val[idx] in (st_min, st_max)
+__device__ __forceinline__ void finish_entry(const Finish& f, int64_t idx, float cur_min, float cur_max,
+                                             bool have_state = false, float st_min = 0.f, float st_max = 0.f) {
     if (f.cur) { f.cur[2 * idx] = cur_min; f.cur[2 * idx + 1] = cur_max; }
     float mn = cur_min, mx = cur_max;
     if (f.rule != OSQ_UPDATE_NONE && f.min_val && f.max_val) {
-        apply_update(f.rule, f.cnt, cur_min, cur_max, &f.min_val[idx], &f.max_val[idx]);
-        mn = f.min_val[idx];
-        mx = f.max_val[idx];
+        if (!have_state) { st_min = f.min_val[idx]; st_max = f.max_val[idx]; }
+        mn = st_min;
+        mx = st_max;
+        apply_update(f.rule, f.cnt, cur_min, cur_max, &mn, &mx);
+        f.min_val[idx] = mn;
+        f.max_val[idx] = mx;
     }
     if (f.scale_out) {
         float s, z;
@@ -113,30 +119,53 @@ __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __
     acc.init();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    // running state for the finish step: fetched now by the thread that may need it, so that the last
+    // workgroup's tail has no dependent load left (every serial memory round trip there costs ~1 us)
+    float st_min = 0.f, st_max = 0.f;
+    if (threadIdx.x == 0 && fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val) {
+        st_min = fin.min_val[0];
+        st_max = fin.max_val[0];
+    }
     for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        const float4 a = load_stream(&x[i]), b = load_stream(&x[i + stride]), c = load_stream(&x[i + 2 * stride]),
+                     d = load_stream(&x[i + 3 * stride]);
         acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
     }
     for (; i < n4; i += stride) acc.add4(x[i]);
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc.add(xt[threadIdx.x]);
     acc = block_reduce(acc);
+    // ONE 8-byte partial per workgroup: {min, max}, a NaN minimum flags "NaN seen" (fminf never yields one)
+    unsigned long long* part64 = reinterpret_cast<unsigned long long*>(partials);
     if (threadIdx.x == 0) {
-        publish_f32(&partials[3 * blockIdx.x], acc.mn);
-        publish_f32(&partials[3 * blockIdx.x + 1], acc.mx);
-        publish_f32(&partials[3 * blockIdx.x + 2], acc.bad ? 1.0f : 0.0f);
+        const float pm = acc.bad ? __builtin_nanf("") : acc.mn;
+        __hip_atomic_store(&part64[blockIdx.x],
+                           (static_cast<unsigned long long>(__float_as_uint(acc.mx)) << 32) | __float_as_uint(pm),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (grid_last_block(counter, gridDim.x)) {
+        // every load is issued before any is consumed: read in a loop that uses each value at once, the
+        // (ordered) agent-scope loads cost one memory round trip per iteration -- most of the old 8 us tail
+        constexpr int kPer = kMaxBlocks / kThreads;
+        unsigned long long raw[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned int k = threadIdx.x + j * kThreads;
+            raw[j] = __hip_atomic_load(&part64[k < gridDim.x ? k : gridDim.x - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         MinMax t;
         t.init();
-        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) {
-            t.mn = fminf(t.mn, consume_f32(&partials[3 * k]));
-            t.mx = fmaxf(t.mx, consume_f32(&partials[3 * k + 1]));
-            t.bad |= consume_f32(&partials[3 * k + 2]) != 0.0f;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const float pm = __uint_as_float(static_cast<unsigned int>(raw[j] & 0xffffffffull));
+            const float px = __uint_as_float(static_cast<unsigned int>(raw[j] >> 32));
+            t.mn = fminf(t.mn, pm);
+            t.mx = fmaxf(t.mx, px);
+            t.bad |= (pm != pm);
         }
         t = block_reduce(t);
         if (threadIdx.x == 0) {
             t.poison();
-            finish_entry(fin, 0, t.mn, t.mx);
+            finish_entry(fin, 0, t.mn, t.mx, true, st_min, st_max);
             grid_reset(counter, gridDim.x);
         }
     }
@@ -209,7 +238,12 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
         len = l < len ? l : len;
     }
     const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
-    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kTokPerBlock + w * kTokPerWave;
+    // Workgroups reach the XCDs round-robin in linear order (y * gridDim.x + x): with 8 chunks per sample
+    // chunk x would always land on XCD x, and since late chunks are mostly padding, XCD 0 would read 7x
+    // the bytes of XCD 7 (measured: the 54 %-valid tensor took as long as the full one).  Rotating the
+    // chunk index by the sample index spreads every chunk position over all XCDs.
+    const int64_t chunk = (static_cast<int64_t>(blockIdx.x) + blockIdx.y) % gridDim.x;
+    const int64_t t0 = chunk * kTokPerBlock + w * kTokPerWave;
     if (t0 >= len) return;
     const int ntok = (len - t0) < kTokPerWave ? static_cast<int>(len - t0) : kTokPerWave;
     const float* base = x + b * v.stride_batch + t0 * v.stride_token;
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
             for (int k = 0; k < kTokPerWave; ++k) {
                 const int kk = k < ntok ? k : 0;                 // short tail: re-read token 0, result unused
-                val[k] = reinterpret_cast<const float4*>(base + kk * v.stride_token)[j];
+                val[k] = load_stream(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j);
             }
 #pragma unroll
             for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
@@ -237,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
                 for (int k = 0; k < kTokPerWave; ++k) {
                     const int kk = k < ntok ? k : 0;
-                    val[k] = reinterpret_cast<const float4*>(seg + kk * v.stride_token)[j];
+                    val[k] = load_stream(reinterpret_cast<const float4*>(seg + kk * v.stride_token) + j);
                 }
 #pragma unroll
                 for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
@@ -671,6 +705,12 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 #undef OSQ_FOR_EACH_VALID
 }
 
+}  // namespace osq
+
+#include "token_select.h"   // two-workgroup fast path (one per side), used whenever its layout rules hold
+
+namespace osq {
+
 // ---------------------------------------------------------------- wide finaliser (many token slots)
 
 // One CU pulls only ~10 B/clk from the fabric, so a single workgroup needs ~10 us just to READ the
@@ -691,6 +731,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 // above the register-cache limit of the single-workgroup kernel, where that kernel would re-read the
 // arrays from L2 in every pass (~25 us per pass at 65536 slots).  osq_set_wide_min_slots() overrides.
 static int64_t g_wide_min_slots = 32769;
+static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
 constexpr int kCoarseShift = 20;
@@ -1082,6 +1123,35 @@ static inline int check_finish_args(int update_rule, const float* min_val, const
     return 1;
 }
 
+
+// Layout rules of token_select_kernel: 16-byte groups (slot count and problem stride multiples of 4,
+// aligned arrays), T >= 4 so that a group straddles at most two samples, at most 32 values per thread
+// (64 would spill at 1024 threads per workgroup).
+static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t B, int64_t T, int64_t stride,
+                                  int64_t problems) {
+    const int64_t S = B * T;
+    return g_final_fast && T >= 4 && (S & 3) == 0 && S <= 4 * 8 * kSelThreads && aligned16(tmin) && aligned16(tmax) &&
+           (stride & 3) == 0 && problems >= 1 && problems <= static_cast<int64_t>(kWsMeetBytes / 8) && problems <= 65535;
+}
+
+bool set_observer_tuning(const char* key, int value) {
+    const std::string k(key);
+    if (k == "final_fast") { g_final_fast = value != 0; return true; }
+    return false;
+}
+
+static inline void launch_select(hipStream_t st, const SelectArgs& a, const Finish& fin, const FinalBatch& fb,
+                                 int64_t problems) {
+    const int64_t groups_per_thread = ((a.B * a.T) / 4 + kSelThreads - 1) / kSelThreads;
+    const dim3 grid(2, static_cast<unsigned>(problems));
+#define OSQ_LAUNCH_SELECT(R4) hipLaunchKernelGGL(token_select_kernel<R4>, grid, dim3(kSelThreads), 0, st, a, fin, fb)
+    if (groups_per_thread <= 1) OSQ_LAUNCH_SELECT(1);
+    else if (groups_per_thread <= 2) OSQ_LAUNCH_SELECT(2);
+    else if (groups_per_thread <= 4) OSQ_LAUNCH_SELECT(4);
+    else OSQ_LAUNCH_SELECT(8);
+#undef OSQ_LAUNCH_SELECT
+}
+
 }  // namespace osq
 
 using namespace osq;
@@ -1212,7 +1282,13 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
-    if (batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune)) {
+    const bool wide = batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune);
+    if (!wide && workspace && select_fast_ok(token_min, token_max, batch, tokens, 0, 1)) {
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet()};
+        launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr}, 1);
+        return check_launch("token_range_finalize(select)");
+    }
+    if (wide) {
         Workspace wsp(workspace);
         WideArgs a{token_min, token_max, batch, tokens, lengths, reinterpret_cast<WideState*>(wsp.wide()),
                    static_cast<unsigned int*>(list_scratch), wsp.counter(0), prune, qf};
@@ -1240,7 +1316,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
 extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,
                                                 int n_quantizers, int n_batches, int64_t batch, int64_t tokens,
                                                 const int64_t* lengths, const int32_t* prune_flags, double percentile,
-                                                float* cur_table, osq_stream stream) {
+                                                float* cur_table, void* workspace, osq_stream stream) {
     OSQ_REQUIRE(token_min && token_max && cur_table && batch > 0 && tokens > 0, "token_range_finalize_batched: empty or null input");
     OSQ_REQUIRE(n_quantizers > 0 && n_batches > 0 && problem_stride >= batch * tokens, "token_range_finalize_batched: bad table shape");
     OSQ_REQUIRE(percentile >= 0.0 && percentile <= 1.0, "token_range_finalize_batched: percentile outside [0, 1]");
@@ -1249,6 +1325,12 @@ extern "C" int osq_token_range_finalize_batched(const float* token_min, const fl
     const FinalBatch fb{problem_stride, n_batches, n_quantizers, prune_flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
+    const int64_t problems = static_cast<int64_t>(n_quantizers) * n_batches;
+    if (workspace && select_fast_ok(token_min, token_max, batch, tokens, problem_stride, problems)) {
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, 1, qf, Workspace(workspace).meet()};
+        launch_select(st, a, fin, fb, problems);
+        return check_launch("token_range_finalize_batched(select)");
+    }
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
     const dim3 grid(static_cast<unsigned>(n_quantizers) * static_cast<unsigned>(n_batches));
 #define OSQ_LAUNCH_FINAL(S)                                                                                     \

@@ -12,8 +12,10 @@ constexpr int kMaxBlocks = 2048;          // 256 CUs x 8 workgroups of 256 threa
 constexpr size_t kWsHeaderBytes = 4096;   // ticket counters, one 64-byte line each (33 used)
 constexpr size_t kWsScratchBytes = 64 * 1024;
 constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
+constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of token_select_kernel (8 B per problem)
 
 void set_error(const char* fmt, ...);
+bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -34,7 +36,7 @@ static inline int check_launch(const char* what) {
     return OSQ_OK;
 }
 
-// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state].  Counters are zero between
+// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state][64 KiB rendezvous words].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
@@ -43,6 +45,9 @@ struct Workspace {
     double* doubles() const { return reinterpret_cast<double*>(base + kWsHeaderBytes); }
     float* floats() const { return reinterpret_cast<float*>(base + kWsHeaderBytes); }
     void* wide() const { return base + kWsHeaderBytes + kWsScratchBytes; }
+    unsigned long long* meet() const {
+        return reinterpret_cast<unsigned long long*>(base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes);
+    }
 };
 
 }  // namespace osq

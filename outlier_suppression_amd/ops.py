@@ -307,8 +307,14 @@ _token_scratch = {}
 _wide_min_slots = 32769
 
 
+def set_tuning(key, value):
+    """Performance / path-selection knobs of the library (osq_set_tuning); results never change."""
+    _hip.check(_hip.load().osq_set_tuning(key.encode(), int(value)), f"set_tuning({key})")
+
+
 def set_wide_min_slots(slots):
-    """Token-slot count from which the finaliser uses its three multi-workgroup launches (default 32769)."""
+    """Token-slot count from which the finaliser uses its three multi-workgroup launches (default 32769:
+    above the register capacity of the two-workgroup kernel)."""
     global _wide_min_slots
     _hip.check(_hip.load().osq_set_wide_min_slots(int(slots)), "set_wide_min_slots")
     _wide_min_slots = int(slots)
@@ -365,7 +371,8 @@ def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, 
     _hip.check(lib.osq_token_range_finalize_batched(_hip.ptr(token_min), _hip.ptr(token_max), token_min.stride(1),
                                                     int(n_quantizers), int(n_batches), int(batch), int(tokens),
                                                     _hip.ptr(lengths), _hip.ptr(prune_flags), float(percentile),
-                                                    _hip.ptr(cur_table), _hip.stream_ptr(token_min.device)),
+                                                    _hip.ptr(cur_table), _hip.ptr(_hip.workspace(token_min.device)),
+                                                    _hip.stream_ptr(token_min.device)),
                "token_range_finalize_batched")
 
 

@@ -524,6 +524,69 @@ def test_wide_finaliser_vs_oracle(eq32, dev):
     ops.set_wide_min_slots(32769)
 
 
+def test_finaliser_paths_agree_with_oracle(eq32, dev):
+    """The token range finaliser has three implementations -- two workgroups (one per side, the default
+    up to 32768 slots), the single-workgroup kernel (layouts the fast one rejects) and the three-launch
+    wide one -- which must all reproduce the oracle bit for bit: geometries with T % 4 != 0 (16-byte
+    groups straddling two samples), empty samples, one valid token, duplicates, narrow ranges,
+    percentiles 0 / 1 / in between, repeated calls (the rendezvous word must come back to zero)."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgPruneMinMaxObserver, AvgMinMaxObserver
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(123)
+    geoms = [(8, 6, 16), (8, 5, 8), (4, 4, 8), (32, 128, 32), (3, 40, 64), (64, 128, 16), (16, 36, 8), (1, 4, 4)]
+    makers = {
+        "spread": lambda B, Tn, H: torch.randn(B, Tn, H, generator=gen) * torch.rand(B, Tn, 1, generator=gen) * 9,
+        "narrow": lambda B, Tn, H: 4.0 + torch.rand(B, Tn, H, generator=gen) * 0.4,
+        "dups": lambda B, Tn, H: torch.randint(-3, 4, (B, Tn, H), generator=gen).float(),
+        "negative": lambda B, Tn, H: -1.0 - torch.rand(B, Tn, H, generator=gen) * 5,
+    }
+    def run(path):
+        ops.set_tuning("final_fast", 0 if path == "single" else 1)
+        ops.set_wide_min_slots(1024 if path == "wide" else 32769)
+        try:
+            for (B, Tn, H) in geoms:
+                for name, make in makers.items():
+                    for cls, fn, p in ((AvgPruneMinMaxObserver, OB.observe_avg_prune_minmax, 0.9),
+                                       (AvgPruneMinMaxObserver, OB.observe_avg_prune_minmax, 1.0),
+                                       (AvgPruneMinMaxObserver, OB.observe_avg_prune_minmax, 0.0),
+                                       (AvgPruneMinMaxObserver, OB.observe_avg_prune_minmax, 0.5),
+                                       (AvgMinMaxObserver, OB.observe_avg_minmax, None)):
+                        ob = cls(bit=6).to(dev)
+                        ob.set_name("x_post_act_fake_quantize.observer")
+                        st = OB.ObserverState(bit=6, name=ob.name)
+                        if p is not None:
+                            ob.set_percentile(p)
+                            st.percentile = p
+                        for it in range(3):
+                            x = make(B, Tn, H)
+                            L = torch.randint(0 if it == 1 else 1, Tn + 1, (B,), generator=gen)
+                            if it == 2:
+                                L[:] = 0
+                                L[B // 2] = 1                  # a single valid token in the whole batch
+                            else:
+                                L[0] = Tn
+                            ob(x.to(dev), L.to(dev), 1)
+                            fn(st, x.numpy(), L.numpy(), 1)
+                            assert eq32(N(ob.min_val), st.min_val) and eq32(N(ob.max_val), st.max_val), \
+                                (path, (B, Tn, H), name, cls.__name__, p, it)
+            # all-padding batch: nothing observed, state untouched; then a NaN among the valid tokens poisons
+            ob = AvgPruneMinMaxObserver(bit=6).to(dev)
+            ob.set_name("x")
+            ob.set_percentile(0.9)
+            x = torch.randn(8, 16, 32, generator=gen)
+            ob(x.to(dev), torch.zeros(8, dtype=torch.int64, device=dev), 1)
+            assert torch.isinf(ob.max_val).item() and torch.isinf(ob.min_val).item()
+            x[2, 1, 3] = float("nan")
+            ob(x.to(dev), torch.full((8,), 16, device=dev), 1)
+            assert torch.isnan(ob.min_val).item() and torch.isnan(ob.max_val).item()
+        finally:
+            ops.set_tuning("final_fast", 1)
+            ops.set_wide_min_slots(32769)
+    for path in ("select", "single", "wide"):
+        run(path)
+
+
 # ----------------------------------------------------------------------------------- remaining observers (N3)
 
 def test_other_observers_golden(golden, eq32, dev):

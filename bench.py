@@ -210,8 +210,9 @@ def main():
     def step(i):
         return q(xs[i % len(xs)], lengths, 1)
 
-    for i in range(args.warmup):
-        step(i)
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
     # per-batch statistics table for the sharded-calibration exchange (N > 1)
     table = torch.zeros(args.steps, 1, 2, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -223,13 +224,15 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        x = xs[i % len(xs)]
-        # same three launches as q(x, lengths, 1); split here only to bracket the dominant kernel with events
-        q._observe(x, lengths, 1)
-        ev[i][0].record()
-        y = q._quantize(x)
-        ev[i][1].record()
+    with torch.no_grad():                      # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
+        for i in range(args.steps):
+            x = xs[i % len(xs)]
+            # same three launches as q(x, lengths, 1); split here only to bracket the dominant kernel with events
+            q._observe(x, lengths, 1)
+            ev[i][0].record()
+            y = q._quantize(x)
+            ev[i][1].record()
+    host_dt = time.perf_counter() - t0         # enqueue time: if this is close to dt the loop is host-bound
     if world > 1:
         # the path's one real exchange: per-batch statistics, gathered once and replayed in batch order
         table[:, 0, 0] = q.observer.min_val
@@ -272,6 +275,7 @@ def main():
                                "-> running average -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]; configs[1] site shape",
                    "launches_per_step": 3, "buffers_cycled": len(xs),
                    "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
+                   "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 5),
                    "pct_hbm_peak": round(100.0 * value * GIB / 1e9 / (HBM_PEAK_GBS * world), 2)},
         "roofline": {"bound": "hbm", "kernel": "fq_tensor_vec_kernel<false> (fake-quant forward, 8 B/elem)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -47,7 +47,15 @@ typedef enum osq_zp_type { OSQ_ZP_INT32 = 0, OSQ_ZP_FLOAT32 = 1 } osq_zp_type;
 typedef enum osq_param_mode {
     OSQ_PARAM_FIXED = 0,   /* util_quant.py:11-26   use as is                                  */
     OSQ_PARAM_LSQ = 1,     /* util_quant.py:29-45   scale <- grad_scale(scale, g)              */
-    OSQ_PARAM_LSQPLUS = 2  /* util_quant.py:48-67   zp <- round_ste(zp); both <- grad_scale()  */
+    OSQ_PARAM_LSQPLUS = 2, /* util_quant.py:48-67   zp <- round_ste(zp); both <- grad_scale()  */
+    OSQ_PARAM_MODE_MASK = 3,
+    /* flag for the per-tensor forward entry points, OR-ed into `mode`: first repair the parameters
+     * IN PLACE the way LSQFakeQuantize / LSQPlusFakeQuantize.forward do while their observer is off
+     * (fake_quant.py:152-153, 188-191: scale.abs_(); scale.clamp_(min=finfo(float32).eps); LSQ+ also
+     * zero_point.clamp_(quant_min, quant_max)), then quantise with the repaired values -- the same
+     * result as osq_lsq_sanitize followed by the plain call, in one launch.  `scale` (and a float32
+     * `zero_point`) are written through despite their const qualifier. */
+    OSQ_PARAM_SANITIZE = 16
 } osq_param_mode;
 
 /* running-statistic rule applied after a batch's (min, max) is known */
@@ -191,6 +199,19 @@ int osq_token_range_finalize(const float* token_min, const float* token_max,
                              int quant_min, int quant_max, int symmetric,
                              float* scale_out, void* zero_point_out, int zp_type,
                              void* workspace, void* list_scratch, osq_stream stream);
+
+/* osq_token_minmax followed by osq_token_range_finalize on the same stream: a whole masked
+ * observation (AvgPruneMinMaxObserver / AvgMinMaxObserver / MinMaxObserver.forward with a mask,
+ * observer.py:130-145, 184-203, 214-237) behind one call of the host binding.  token_min/token_max:
+ * caller-owned scratch of batch*tokens floats each (their contents are the per-token extrema afterwards). */
+int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t* lengths,
+                       float* token_min, float* token_max,
+                       int prune, double percentile,
+                       int update_rule, int64_t cnt, float* min_val, float* max_val,
+                       float* cur_minmax,
+                       int quant_min, int quant_max, int symmetric,
+                       float* scale_out, void* zero_point_out, int zp_type,
+                       void* workspace, void* list_scratch, osq_stream stream);
 
 int osq_set_wide_min_slots(int64_t slots);
 

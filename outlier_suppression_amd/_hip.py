@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libosq_hip.so")
 # zero-point storage / parameter mode / update rule (mirrors include/osq_hip.h)
 ZP_INT32, ZP_FLOAT32 = 0, 1
 PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
+PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 
 _P = ctypes.c_void_p
@@ -49,6 +50,7 @@ SIGNATURES = {
     "osq_observe_channels": (_I, [_P, _L, _L, _L, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "osq_token_minmax": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
     "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "osq_observe_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_set_wide_min_slots": (_I, [_L]),
     "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _P, _D, _P, _P, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
@@ -113,12 +115,25 @@ def require_device(*tensors):
                                f"(got device={t.device}); there is no CPU path.")
 
 
+# The three helpers below run on every launch: they return plain ints (ctypes converts an int to a
+# void* argument by itself) and use the raw-stream query, which costs a fraction of building a
+# torch.cuda.Stream object.  A quantizer call is three launches of 10-35 us: host time per launch matters.
 def ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
+
+
+def _device_index(device):
+    idx = None if device is None else device.index
+    return torch.cuda.current_device() if idx is None else idx
+
+
+def raw_stream(device=None):
+    """hipStream_t of torch's current stream on ``device`` as an int."""
+    return torch._C._cuda_getCurrentRawStream(_device_index(device))
 
 
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return raw_stream(device)
 
 
 _workspaces = {}
@@ -126,8 +141,7 @@ _workspaces = {}
 
 def workspace(device):
     """Zero-initialised scratch for (device, current stream); kernels leave their counters zeroed."""
-    s = torch.cuda.current_stream(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), s.cuda_stream)
+    key = (_device_index(device), raw_stream(device))
     ws = _workspaces.get(key)
     if ws is None:
         nbytes = int(load().osq_workspace_bytes())

@@ -32,6 +32,32 @@ __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float
     y.w = dequantize_value(q.w, s, z);
 }
 
+// LSQFakeQuantize / LSQPlusFakeQuantize.forward with the observer off first repair their parameters in
+// place -- scale.abs_(); scale.clamp_(min=eps); zero_point.clamp_(qmin, qmax) (fake_quant.py:152-153,
+// 188-191) -- and then quantise with them.  With OSQ_PARAM_SANITIZE in `mode` the consuming launch does
+// both: every thread derives the repaired values itself (the repair is idempotent, so it does not matter
+// whether a thread sees the raw or the already repaired word) and thread 0 of workgroup 0 writes them back.
+constexpr float kLsqEps = 1.1920928955078125e-07f;     // torch.finfo(torch.float32).eps, the modules' `eps` buffer
+
+__device__ __forceinline__ QParams tensor_params(const float* scale_p, const void* zp_p, int zp_type, int mode, float g,
+                                                 float qmin, float qmax) {
+    float s = scale_p[0], z = load_zp(zp_p, zp_type);
+    const int base = mode & OSQ_PARAM_MODE_MASK;
+    if (mode & OSQ_PARAM_SANITIZE) {
+        s = fabsf(s);
+        s = (s < kLsqEps) ? kLsqEps : s;                // clamp_(min=eps) keeps NaN
+        if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) {
+            z = (z < qmin) ? qmin : z;
+            z = (z > qmax) ? qmax : z;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const_cast<float*>(scale_p)[0] = s;
+            if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) static_cast<float*>(const_cast<void*>(zp_p))[0] = z;
+        }
+    }
+    return effective_params(s, z, base, g);
+}
+
 // ---------------------------------------------------------------- per-tensor, dense
 
 template <bool WRITE_Q, int UNROLL, int NT>
@@ -40,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ xqt, int tail,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
-    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const float s = p.scale, z = p.zp;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -76,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_scalar_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, int64_t n,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
-    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
         const float q = quantize_value(x[i], p.scale, p.zp, qmin, qmax);
@@ -96,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_strided_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, Strided4 d, int64_t n,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
-    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
         int64_t r = i, xo = 0, yo = 0;
@@ -349,7 +375,8 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
                                          int mode, float grad_factor, int quant_min, int quant_max,
                                          osq_stream stream) {
     OSQ_REQUIRE(n >= 0 && (n == 0 || (x && y)) && scale && zero_point, "fake_quant_per_tensor: null pointer or n < 0");
-    OSQ_REQUIRE(mode >= OSQ_PARAM_FIXED && mode <= OSQ_PARAM_LSQPLUS, "fake_quant_per_tensor: bad mode");
+    OSQ_REQUIRE((mode & ~(OSQ_PARAM_MODE_MASK | OSQ_PARAM_SANITIZE)) == 0 && (mode & OSQ_PARAM_MODE_MASK) <= OSQ_PARAM_LSQPLUS,
+                "fake_quant_per_tensor: bad mode");
     if (n == 0) return OSQ_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);

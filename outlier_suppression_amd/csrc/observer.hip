@@ -1313,6 +1313,21 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     return check_launch("token_range_finalize");
 }
 
+extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t* lengths,
+                                  float* token_min, float* token_max,
+                                  int prune, double percentile,
+                                  int update_rule, int64_t cnt, float* min_val, float* max_val,
+                                  float* cur_minmax,
+                                  int quant_min, int quant_max, int symmetric,
+                                  float* scale_out, void* zero_point_out, int zp_type,
+                                  void* workspace, void* list_scratch, osq_stream stream) {
+    const int rc = osq_token_minmax(x, view, lengths, token_min, token_max, stream);
+    if (rc != OSQ_OK) return rc;
+    return osq_token_range_finalize(token_min, token_max, view->batch, view->tokens, lengths, prune, percentile,
+                                    update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric,
+                                    scale_out, zero_point_out, zp_type, workspace, list_scratch, stream);
+}
+
 extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,
                                                 int n_quantizers, int n_batches, int64_t batch, int64_t tokens,
                                                 const int64_t* lengths, const int32_t* prune_flags, double percentile,

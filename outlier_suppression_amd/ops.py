@@ -8,8 +8,8 @@ import ctypes
 import torch
 
 from . import _hip
-from ._hip import (PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, UPDATE_AVERAGE, UPDATE_NONE, UPDATE_RUNNING,  # noqa: F401
-                   ZP_FLOAT32, ZP_INT32)
+from ._hip import (PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, PARAM_MODE_MASK, PARAM_SANITIZE, UPDATE_AVERAGE,  # noqa: F401
+                   UPDATE_NONE, UPDATE_RUNNING, ZP_FLOAT32, ZP_INT32)
 
 
 def _zp_type(zero_point):
@@ -178,7 +178,7 @@ class _FakeQuantFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale, zero_point, ch_axis, quant_min, quant_max, mode, grad_factor):
-        ctx.cfg = (ch_axis, quant_min, quant_max, mode, grad_factor)
+        ctx.cfg = (ch_axis, quant_min, quant_max, mode & PARAM_MODE_MASK, grad_factor)    # PARAM_SANITIZE is forward-only
         ctx.save_for_backward(x, scale, zero_point)
         if ch_axis == -1:
             return fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode, grad_factor)
@@ -251,6 +251,9 @@ class QParamSink:
         return _hip.ptr(self.scale), _hip.ptr(self.zero_point), _zp_type(self.zero_point)
 
 
+_NO_SINK = QParamSink()
+
+
 def observe_flat(x, rule, cnt, min_val, max_val, quant_min, quant_max, symmetric, sink=None, cur=None):
     """Global min/max of a dense tensor + running statistic (+ qparams): ONE launch."""
     lib = _hip.load()
@@ -280,12 +283,19 @@ def observe_channels(x, ch_axis, rule, cnt, min_val, max_val, quant_min, quant_m
                                         z_ptr, z_type, _hip.stream_ptr(x.device)), "observe_channels")
 
 
+_view_cache = {}
+
+
 def token_view(x, seq_pos, n_lengths=None):
     """Describe x as [batch, tokens, feat_outer, feat_inner] the way observer.py:72-80 permutes it.
 
     With a length-B mask on a tensor whose dim 0 is larger (BART's [B*h, T, S] attention
     probabilities) ``zip`` in observer.py:82 only visits the first B rows: ``n_lengths`` trims batch.
     """
+    key = (x.shape, x.stride(), seq_pos, n_lengths)
+    view = _view_cache.get(key)          # a model calls each site with the same geometry over and over
+    if view is not None:
+        return view
     if x.dim() not in (3, 4):
         raise NotImplementedError("masked observers support 3-D and 4-D activations (observer.py:76-79)")
     seq_pos = seq_pos % x.dim()
@@ -300,7 +310,10 @@ def token_view(x, seq_pos, n_lengths=None):
     else:
         fi = others[1]
         outer, inner, s_outer, s_inner = 1, sz[fi], 0, st[fi]
-    return _hip.TokenView(batch, sz[seq_pos], outer, inner, st[0], st[seq_pos], s_outer, s_inner)
+    view = _hip.TokenView(batch, sz[seq_pos], outer, inner, st[0], st[seq_pos], s_outer, s_inner)
+    if len(_view_cache) < 4096:
+        _view_cache[key] = view
+    return view
 
 
 _token_scratch = {}
@@ -322,13 +335,22 @@ def set_wide_min_slots(slots):
 
 
 def _scratch(device, n):
-    """(token_min, token_max, list_scratch): per (device, stream) scratch, grown on demand."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _token_scratch.get(key)
-    if buf is None or buf.numel() < 4 * n:
-        buf = torch.empty(4 * max(n, 4096), dtype=torch.float32, device=device)
-        _token_scratch[key] = buf
-    return buf[:n], buf[n:2 * n], buf[2 * n:4 * n]
+    """(token_min, token_max, list_scratch): per (device, stream) scratch, grown on demand.  The three
+    views are cached per slot count: building tensor views costs microseconds on a path that runs per site."""
+    key = (device.index, _hip.raw_stream(device))
+    entry = _token_scratch.get(key)
+    if entry is not None:
+        views = entry[1].get(n)
+        if views is not None:
+            return views
+    if entry is None or entry[0].numel() < 4 * n:
+        entry = (torch.empty(4 * max(n, 4096), dtype=torch.float32, device=device), {})
+        _token_scratch[key] = entry
+    buf = entry[0]
+    views = (buf[:n], buf[n:2 * n], buf[2 * n:4 * n])
+    if len(entry[1]) < 64:
+        entry[1][n] = views
+    return views
 
 
 def token_minmax(x, seq_pos, lengths=None, out=None):
@@ -359,6 +381,31 @@ def token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, percentile, 
                                             int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
                                             _hip.ptr(_hip.workspace(dev)), _hip.ptr(lst), _hip.stream_ptr(dev)),
                "token_range_finalize")
+
+
+def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, max_val, quant_min, quant_max,
+                   symmetric, sink=None, cur=None):
+    """token_minmax + token_range_finalize behind ONE call of the binding (the per-site hot path of a
+    calibration forward: host time per quantizer call is of the order of the kernels' own run time).
+    Returns (batch, tokens, lengths_int64)."""
+    lib = _hip.load()
+    _hip.require_device(x, lengths)
+    _check_f32(x)
+    if lengths is not None and lengths.dtype != torch.int64:
+        lengths = lengths.to(torch.int64)
+    view = token_view(x, seq_pos, None if lengths is None else lengths.numel())
+    dev = x.device
+    n = view.batch * view.tokens
+    tmin, tmax, lst = _scratch(dev, n)
+    s_ptr, z_ptr, z_type = (sink or _NO_SINK).args()
+    rc = lib.osq_observe_tokens(x.data_ptr(), ctypes.byref(view), _hip.ptr(lengths), tmin.data_ptr(), tmax.data_ptr(),
+                                1 if prune else 0, float(percentile) if prune else 1.0, rule, int(cnt),
+                                _hip.ptr(min_val), _hip.ptr(max_val), _hip.ptr(cur), int(quant_min), int(quant_max),
+                                1 if symmetric else 0, s_ptr, z_ptr, z_type, _hip.workspace(dev).data_ptr(),
+                                lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))
+    if rc != 0:
+        _hip.check(rc, "observe_tokens")
+    return view.batch, view.tokens, lengths
 
 
 def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, batch, tokens, lengths, prune_flags,

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, QParamSink
+from ..ops import PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, PARAM_SANITIZE, QParamSink
 from .observer import MinMaxObserver
 
 
@@ -60,6 +60,9 @@ class QuantizeBase(nn.Module):
     def _qparam_storage(self, device, channels):
         """scale / zero_point tensors on ``device`` with ``channels`` entries (1 for per-tensor),
         resized like fake_quant.py:112-114 / 184-186 when the observer turns out per-channel."""
+        s, z = self.scale, self.zero_point
+        if s.device == device and z.device == device and s.numel() == channels and z.numel() == channels:
+            return s.data, z.data               # the steady state: nothing to move or resize
         for name in ("scale", "zero_point"):
             t = getattr(self, name)
             data = t.data if isinstance(t, nn.Parameter) else t
@@ -92,9 +95,9 @@ class QuantizeBase(nn.Module):
             return 1.0 / (X.numel() / X.shape[self.ch_axis] * self.quant_max) ** 0.5
         return 1.0 / (X.numel() * self.quant_max) ** 0.5
 
-    def _quantize(self, X):
+    def _quantize(self, X, flags=0):
         return ops.fake_quant(X, self.scale, self.zero_point, self.ch_axis, self.quant_min, self.quant_max,
-                              self.param_mode, self._grad_factor(X) if self.param_mode != PARAM_FIXED else 1.0)
+                              self.param_mode | flags, self._grad_factor(X) if self.param_mode != PARAM_FIXED else 1.0)
 
     # ---- state dict: scale / zero_point change size on the first observation ----------
     def _save_to_state_dict(self, destination, prefix, keep_vars):
@@ -160,12 +163,15 @@ class _LearnableFakeQuantize(QuantizeBase):
                                "move the model with .cuda() (there is no CPU path)")
 
     def forward(self, X, observation_mask=None, seq_pos=-1):
+        flags = 0
         if self.observer_enabled == 1:
             self._observe(X, observation_mask, seq_pos)
+        elif self.fake_quant_enabled == 1 and self.ch_axis == -1 and self.scale.is_cuda and X.numel() > 0:
+            flags = PARAM_SANITIZE        # per-tensor: the repair happens inside the fake-quant launch
         else:
             self._sanitize()
         if self.fake_quant_enabled == 1:
-            X = self._quantize(X)
+            X = self._quantize(X, flags)
         return X
 
 

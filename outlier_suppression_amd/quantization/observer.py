@@ -76,20 +76,19 @@ class ObserverBase(nn.Module):
     def _observe_tokens(self, x, lengths, seq_pos, prune, sink):
         if self._token_cache is not None:     # keep the per-token extrema; thresholds are applied later, per candidate
             _, _, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths, out=self._token_cache)
-            self._last_site = ("tokens", batch, tokens, lengths)
+            object.__setattr__(self, "_last_site", ("tokens", batch, tokens, lengths))   # nn.Module.__setattr__ costs microseconds
             return
-        tmin, tmax, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths)
-        self._last_site = ("tokens", batch, tokens, lengths)
         self._home(x.device)
         rule, cur = self.update_rule, None
         if self._capture is not None:      # record this batch only; calibration.replay() applies the rule later
             rule, cur, sink = ops.UPDATE_NONE, self._capture, None
-        ops.token_range_finalize(tmin, tmax, batch, tokens, lengths, prune, getattr(self, "percentile", 1.0),
-                                 rule, self._counter(), self.min_val, self.max_val,
-                                 self.quant_min, self.quant_max, self.symmetric, sink, cur)
+        batch, tokens, lengths = ops.observe_tokens(x, seq_pos, lengths, prune, getattr(self, "percentile", 1.0),
+                                                    rule, self._counter(), self.min_val, self.max_val,
+                                                    self.quant_min, self.quant_max, self.symmetric, sink, cur)
+        object.__setattr__(self, "_last_site", ("tokens", batch, tokens, lengths))
 
     def _observe_flat(self, x, sink):
-        self._last_site = ("flat",)
+        object.__setattr__(self, "_last_site", ("flat",))
         self._home(x.device)
         rule, cur = self.update_rule, None
         if self._capture is not None:

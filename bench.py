@@ -215,7 +215,17 @@ def main():
             step(i)
     # per-batch statistics table for the sharded-calibration exchange (N > 1)
     table = torch.zeros(args.steps, 1, 2, device=dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events that ride on the fake-quant dispatch packets themselves (hipExtLaunchKernelGGL inside the
+    # library): elapsed(start, stop) is the kernel's own run time on its stream, the figure rocprofv3
+    # --kernel-trace reports.  Events recorded around the call would add the dispatch latency of the
+    # kernel boundary (2-3 us) to every sample.
+    import ctypes
+    lib = _hip.load()
+    pairs = []
+    for _ in range(args.steps):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _hip.check(lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b)), "timing_events_create")
+        pairs.append((a, b))
 
     def barrier():
         if world > 1:
@@ -227,11 +237,10 @@ def main():
     with torch.no_grad():                      # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
         for i in range(args.steps):
             x = xs[i % len(xs)]
-            # same three launches as q(x, lengths, 1); split here only to bracket the dominant kernel with events
+            # same three launches as q(x, lengths, 1); split here only to hang the timing events on the dominant kernel
             q._observe(x, lengths, 1)
-            ev[i][0].record()
+            lib.osq_time_next_fake_quant(*pairs[i])
             y = q._quantize(x)
-            ev[i][1].record()
     host_dt = time.perf_counter() - t0         # enqueue time: if this is close to dt the loop is host-bound
     if world > 1:
         # the path's one real exchange: per-batch statistics, gathered once and replayed in batch order
@@ -246,14 +255,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    fq_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    fq_ms = []
+    for a, b in pairs:
+        us = ctypes.c_float()
+        _hip.check(lib.osq_timing_elapsed_us(a, b, ctypes.byref(us)), "timing_elapsed_us")
+        fq_ms.append(us.value * 1e-3)
+        lib.osq_timing_events_destroy(a, b)
+    fq_ms.sort()
     fq_avg_ms = sum(fq_ms) / len(fq_ms)
     achieved = 8.0 * n_elem / (fq_avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("fq_tensor_vec_kernel", {}).get("hbm_bytes_per_launch")
+            table = json.load(open(tpath))      # PMC passes of tools/collect_profiles.sh, committed under profiles/
+            traffic = next((v.get("hbm_bytes_per_launch") for k, v in table.items()
+                            if k.startswith("fq_tensor_vec_kernel") and isinstance(v, dict)), None)
         except Exception:
             traffic = None
 

@@ -87,6 +87,15 @@ size_t      osq_workspace_bytes(void);
  * "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 = non-temporal loads/stores of the dense fake-quant. */
 int osq_set_tuning(const char* key, int value);
 
+/* Measurement aid (bench.py).  The events given to osq_time_next_fake_quant ride on the dispatch packet
+ * of the NEXT dense osq_fake_quant_per_tensor launch issued by the calling thread, so
+ * osq_timing_elapsed_us(start, stop) is that kernel's own run time on its stream -- the duration
+ * rocprofv3 --kernel-trace reports -- not the stream-order interval between two recorded events. */
+int osq_timing_events_create(void** start, void** stop);
+int osq_timing_events_destroy(void* start, void* stop);
+int osq_time_next_fake_quant(void* start, void* stop);
+int osq_timing_elapsed_us(void* start, void* stop, float* us);
+
 /* ------------------------------------------------------------------ fake-quant forward */
 
 /* util_quant.py:11-15 fake_quantize_per_tensor_affine, as called by
@@ -187,10 +196,12 @@ int osq_token_minmax(const float* x, const osq_token_view* view, const int64_t* 
  *   prune == 0: plain min/max over the valid tokens (observer.py:193), also used
  *               when 'attention_probs' is in the observer's name (observer.py:62-63);
  * then the update rule (observer.py:194-202 or 143-144) and optional qparams.
- * Up to 32768 token slots: one launch, one workgroup (extrema cached in registers).  Above, when
- * `workspace` and `list_scratch` (2 * batch * tokens uint32, caller-owned, contents irrelevant)
- * are given: three multi-workgroup launches (one CU pulls only ~10 B/clk, so a single workgroup
- * cannot re-read hundreds of KB per pass).  osq_set_wide_min_slots() moves the switch point. */
+ * Up to 32768 token slots, 16-byte aligned arrays, batch*tokens % 4 == 0, tokens >= 4 and a
+ * `workspace`: one launch of TWO workgroups, one per side of the statistic (token_max / -token_min),
+ * that meet through an 8-byte exchange in the workspace.  Other layouts: one launch, one workgroup.
+ * Above 32768 slots, when `workspace` and `list_scratch` (2 * batch * tokens uint32, caller-owned,
+ * contents irrelevant) are given: three multi-workgroup launches.  osq_set_wide_min_slots() moves that
+ * switch point; osq_set_tuning("final_fast", 0) disables the two-workgroup kernel (tests). */
 int osq_token_range_finalize(const float* token_min, const float* token_max,
                              int64_t batch, int64_t tokens, const int64_t* lengths,
                              int prune, double percentile,
@@ -223,7 +234,8 @@ int osq_set_wide_min_slots(int64_t slots);
  * lengths is [n_batches, batch]; prune_flags[quantizer] == 0 for 'attention_probs'
  * quantizers.  One launch re-thresholds all pairs for `percentile` and writes each pair's
  * (min, max) to cur_table[(batch_index*n_quantizers + quantizer)*2] -- per-batch statistics
- * that are then replayed in batch order with osq_observer_update. */
+ * that are then replayed in batch order with osq_observer_update.  `workspace` (nullable): with it,
+ * and the layout rules of osq_token_range_finalize met, every pair gets two workgroups. */
 int osq_token_range_finalize_batched(const float* token_min, const float* token_max,
                                      int64_t problem_stride, int n_quantizers, int n_batches,
                                      int64_t batch, int64_t tokens, const int64_t* lengths,

@@ -38,6 +38,10 @@ SIGNATURES = {
     "osq_abi_version": (_I, []),
     "osq_workspace_bytes": (ctypes.c_size_t, []),
     "osq_set_tuning": (_I, [ctypes.c_char_p, _I]),
+    "osq_timing_events_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+    "osq_timing_events_destroy": (_I, [_P, _P]),
+    "osq_time_next_fake_quant": (_I, [_P, _P]),
+    "osq_timing_elapsed_us": (_I, [_P, _P, ctypes.POINTER(_F)]),
     "osq_fake_quant_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
                                                _P, _P, _I, _I, _F, _I, _I, _P]),

@@ -9,4 +9,4 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o r -- "$@" > "$out/run.log" 2>&1 || { tail -20 "$out/run.log"; exit 1; }
 db=$(find "$out/trace" -name '*.db' | head -1)
-python profiles/summarize_rocprof.py "$db" "$out/kernels.md" ${BYGRID:+--by-grid} | grep -v "at::native\|rocclr\|^$" | head -40
+python tools/summarize_rocprof.py "$db" "$out/kernels.md" ${BYGRID:+--by-grid} | grep -v "at::native\|rocclr\|^$" | head -40; rm -rf "$out/trace"

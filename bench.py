@@ -192,11 +192,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # test hook (1-GPU box): OSQ_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with a gloo group so that the
+    # N > 1 control flow (sharding, exchange, barriers, max-over-ranks clock) can be exercised without N GPUs
+    share = os.environ.get("OSQ_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)    # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)    # "nccl" is RCCL on ROCm
 
     from outlier_suppression_amd import _hip, calibration
     _hip.load()
@@ -215,6 +223,8 @@ def main():
             step(i)
     # per-batch statistics table for the sharded-calibration exchange (N > 1)
     table = torch.zeros(args.steps, 1, 2, device=dev)
+    if world > 1:   # untimed: the first collective of a process group builds the RCCL communicator
+        calibration.gather_batch_table(table, args.steps * world)
     # HIP events that ride on the fake-quant dispatch packets themselves (hipExtLaunchKernelGGL inside the
     # library): elapsed(start, stop) is the kernel's own run time on its stream, the figure rocprofv3
     # --kernel-trace reports.  Events recorded around the call would add the dispatch latency of the

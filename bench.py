@@ -99,8 +99,9 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
     gamma migration -> weight calibration -> token-wise-clipping grid (30 candidates, step 0.01) ->
     LSQ+ learn-scale (3 epochs, lr 1e-5).  Clock: batches resident on device -> every quantizer has
     its final scale / zero_point.  N > 1: the grid search is sharded (batch b on rank b mod N, one
-    all-gather of statistics and one of losses per candidate); learn-scale is sequential Adam and runs
-    replicated on every rank."""
+    all-gather of statistics and one of losses per candidate); learn-scale is sequential Adam: every step
+    is split inside the batch (32/N samples per rank, gradients averaged by one small all-reduce;
+    DESIGN.md section 6)."""
     import logging
     from types import SimpleNamespace as NS
     import torch.distributed as dist
@@ -140,7 +141,15 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         sync()
         t_start = t0 = time.perf_counter()
         with torch.no_grad():
-            fp_output = [model(**b)[0].detach() for b in batches]
+            if world > 1:    # FP targets: each rank runs its own batches, the [batches, 32, 2] logits are all-gathered
+                rows = (n_batches + world - 1) // world
+                mine_out = [model(**batches[b])[0].detach() for b in mine]
+                local = torch.zeros(rows, *mine_out[0].shape, device=dev)
+                for j, o in enumerate(mine_out):
+                    local[j] = o
+                fp_output = list(calibration.gather_batch_table(local, n_batches).unbind(0))
+            else:
+                fp_output = [model(**b)[0].detach() for b in batches]
         sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter()
         m = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type="bert", task_type="glue"))
         sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter()
@@ -157,7 +166,8 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         else:
             ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
         sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
-        TWC.learn_scale(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
+        # N > 1: every Adam step is split inside the batch (32/N samples per rank, averaged gradients)
+        TWC.learn_scale_sharded(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
         sync(); phases["learn_scale"] = time.perf_counter() - t0
         return time.perf_counter() - t_start, phases, ratio
 
@@ -167,6 +177,9 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
            "twc_candidates": 30,
            "search": ("cached per-token extrema + 1 re-threshold launch per candidate, sharded over ranks" if search == "cached"
                       else "literal reference order: 2 model passes per candidate"),
+           "learn_scale": ("sequential Adam, one process" if world == 1 else
+                           f"sequential Adam, every step data-parallel inside the batch ({B // world} samples per rank, "
+                           "one all-reduce of the 196 gradients per step)" if B % world == 0 else "replicated on every rank"),
            "n_gpus": world}
     return out
 

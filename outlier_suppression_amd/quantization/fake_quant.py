@@ -91,9 +91,11 @@ class QuantizeBase(nn.Module):
         """fake_quant.py:157-166 / 195-204."""
         if not getattr(self, "use_grad_scaling", False):
             return 1.0
+        # numel_multiplier: ranks of a data-parallel learn-scale step each see 1/W of the tensor
+        numel = X.numel() * getattr(self, "numel_multiplier", 1)
         if self.ch_axis != -1:
-            return 1.0 / (X.numel() / X.shape[self.ch_axis] * self.quant_max) ** 0.5
-        return 1.0 / (X.numel() * self.quant_max) ** 0.5
+            return 1.0 / (numel / X.shape[self.ch_axis] * self.quant_max) ** 0.5
+        return 1.0 / (numel * self.quant_max) ** 0.5
 
     def _quantize(self, X, flags=0):
         return ops.fake_quant(X, self.scale, self.zero_point, self.ch_axis, self.quant_min, self.quant_max,

@@ -109,6 +109,74 @@ def learn_scale(trainer, fp_input, fp_output, config_quant_learn):
             sched.step()
 
 
+def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=None):
+    """``learn_scale`` with every optimisation step split over the ranks of ``group`` (data parallel INSIDE
+    each batch).  The reference's loop is sequential Adam, so the batches cannot be dealt out the way the
+    observer passes are; instead every rank holds all batches and takes samples [r*B/W, (r+1)*B/W) of each:
+
+      * loss: MSE is a mean, and with equal slices the full-batch loss is the average of the ranks'
+        losses, so the full-batch gradient is the average of the local gradients -- ONE all-reduce of
+        the flattened (scale, zero_point) gradients per step (2 x quantizers floats: latency-bound);
+      * grad_factor = 1/sqrt(numel * quant_max) (fake_quant.py:195-204) must see the FULL tensor's numel:
+        ``numel_multiplier`` on the quantizers restores it;
+      * every rank then takes the same Adam / cosine step on identical parameters.
+
+    Same mathematics as ``learn_scale``; summation order differs (per-rank partial sums), so the learned
+    parameters agree to float rounding (~1e-6 relative), not bit for bit -- the single-GPU run itself is
+    only within that of the reference.  Falls back to the replicated loop when the task is not "glue"
+    or the batch does not divide evenly.
+    """
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    sizes = {next(iter(b.values())).shape[0] for b in fp_input}
+    if world == 1 or task_type != "glue" or any(sz % world for sz in sizes):
+        return learn_scale(trainer, fp_input, fp_output, config_quant_learn)
+    model = trainer.model
+    disable_all(model)
+    logger.info("*** begin learn the scale now! (intra-batch data parallel over %d ranks) ***", world)
+    params, quantizers = [], []
+    for _, q in _act_quantizers(model):
+        q.enable_fake_quant()
+        q.disable_observer()
+        q.numel_multiplier = world
+        quantizers.append(q)
+        if isinstance(q, LSQPlusFakeQuantize):
+            params += [q.scale, q.zero_point]
+        elif isinstance(q, LSQFakeQuantize):
+            params.append(q.scale)
+    opt = torch.optim.Adam(params, lr=config_quant_learn["lr"])
+    steps = config_quant_learn["epoch"] * len(fp_input)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps, eta_min=0.0)
+    shapes = [p.shape for p in params]
+    counts = [p.numel() for p in params]
+    staged = dist.get_backend(group) == "gloo"        # CPU tests / ranks sharing one GPU: stage through the host
+    try:
+        for _ in range(config_quant_learn["epoch"]):
+            for i, batch in enumerate(fp_input):
+                per = next(iter(batch.values())).shape[0] // world
+                lo, hi = rank * per, (rank + 1) * per
+                local = {k: v[lo:hi] for k, v in batch.items()}
+                opt.zero_grad()
+                loss = batch_loss(model(**local), local, fp_output[i][lo:hi])
+                loss.backward()
+                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+                if staged:
+                    host = flat.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    flat = host.to(flat.device)
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                flat /= world
+                for p, g, shp in zip(params, torch.split(flat, counts), shapes):
+                    p.grad = g.reshape(shp)
+                opt.step()
+                sched.step()
+    finally:
+        for q in quantizers:
+            q.numel_multiplier = 1
+
+
 def cac_step_iters(a_bit, bs, config_data):
     """token_wise_clipping.py:118-129."""
     seq = config_data.max_seq_length if hasattr(config_data, "max_seq_length") else config_data.max_source_length

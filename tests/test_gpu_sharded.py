@@ -72,6 +72,12 @@ def _run(rank, world, port, out_dir):
              zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]),
              mn=np.stack([q.observer.min_val.cpu().numpy() for q in qs]),
              cnt=np.array([q.observer.cnt for q in qs]))
+    # fine stage: sequential Adam on (scale, zero_point).  One process: the reference's loop; two ranks:
+    # every step split inside the batch (half the samples each, averaged gradients)
+    TWC.learn_scale_sharded(NS(model=model), batches, fp_output, {"lr": 1e-3, "epoch": 2})
+    np.savez(os.path.join(out_dir, f"learn_w{world}_r{rank}.npz"),
+             scale=np.stack([q.scale.detach().cpu().numpy() for q in qs]),
+             zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]))
     if world > 1:
         dist.destroy_process_group()
 
@@ -90,3 +96,13 @@ def test_two_ranks_equal_one(tmp_path):
         assert np.array_equal(two["scale"], one["scale"]) and np.array_equal(two["zp"], one["zp"])
         assert np.array_equal(two["mn"], one["mn"]) and np.array_equal(two["cnt"], one["cnt"])
     assert int(one["cnt"][0]) == 4
+    # learn-scale: same mathematics, per-rank partial sums -> float-rounding agreement; ranks identical to each other
+    base = np.load(tmp_path / "w1_r0.npz")
+    l1 = np.load(tmp_path / "learn_w1_r0.npz")
+    l2 = [np.load(tmp_path / f"learn_w2_r{r}.npz") for r in (0, 1)]
+    assert np.array_equal(l2[0]["scale"], l2[1]["scale"]) and np.array_equal(l2[0]["zp"], l2[1]["zp"])
+    assert not np.array_equal(l1["scale"], base["scale"])          # the parameters did move
+    np.testing.assert_allclose(l2[0]["scale"], l1["scale"], rtol=2e-5, atol=0)
+    np.testing.assert_allclose(l2[0]["zp"], l1["zp"], rtol=2e-5, atol=2e-5)
+    moved = np.abs(l1["scale"] - base["scale"]).max()
+    assert np.abs(l2[0]["scale"] - l1["scale"]).max() < 1e-2 * moved   # far below the size of the learned update

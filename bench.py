@@ -93,6 +93,60 @@ def cpu_baseline(seed, budget_s=20.0):
                       f"thread probe ms/step: " + ", ".join(f"{c}t={probe[c] * 1e3:.1f}" for c in candidates)}
 
 
+def kernel_table(dev, xs, lengths, reps=20):
+    """Every kernel of the path on the BASELINE tensor, one at a time, each launch timed by HIP events that ride
+    on its own dispatch packet (osq_time_next_launch), inputs cycled through buffers larger than the Infinity
+    Cache.  Algorithmic bytes per BASELINE.md: fake-quant 8 B/elem, observers 4 B per observed elem, LSQ+ backward
+    12 B/elem; the selection kernel reads the per-token extrema (8 B per token slot) and is latency/issue bound."""
+    import ctypes
+    from outlier_suppression_amd import _hip, ops
+    lib = _hip.load()
+    n = xs[0].numel()
+    valid = int(lengths.sum().item()) * SHAPE[2]
+    full = torch.full_like(lengths, SHAPE[1])
+    s = torch.tensor([0.7], device=dev)
+    zf = torch.tensor([31.0], device=dev)
+    mn = torch.tensor(float("inf"), device=dev)
+    mx = torch.tensor(float("-inf"), device=dev)
+    cur = torch.empty(2, device=dev)
+    gy = torch.randn_like(xs[0])
+    tok = ops.token_minmax(xs[0], 1, lengths)
+
+    def timed(which, fn):
+        out = []
+        for i in range(reps + 3):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            _hip.check(lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b)), "timing_events_create")
+            lib.osq_time_next_launch(which, a, b)
+            fn(i)
+            us = ctypes.c_float()
+            _hip.check(lib.osq_timing_elapsed_us(a, b, ctypes.byref(us)), "timing_elapsed_us")
+            lib.osq_timing_events_destroy(a, b)
+            if i >= 3:
+                out.append(us.value)
+        return sum(out) / len(out)
+
+    rows = {}
+
+    def add(name, us, nbytes):
+        rows[name] = {"avg_us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 1),
+                      "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3)}
+
+    with torch.no_grad():
+        add("fake_quant_forward", timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(
+            xs[i % len(xs)], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * n)
+        add("observe_flat (MinMax / AvgMinMax, no mask)", timed(_hip.TIME_OBSERVE_FLAT, lambda i: ops.observe_flat(
+            xs[i % len(xs)], ops.UPDATE_RUNNING, 0, mn, mx, 0, 63, False)), 4 * n)
+        add("token_minmax, all tokens", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xs[i % len(xs)], 1, full)), 4 * n)
+        add("token_minmax, bench lengths", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xs[i % len(xs)], 1, lengths)), 4 * valid)
+        add("token_select p=0.95 (32768 slots)", timed(_hip.TIME_TOKEN_SELECT, lambda i: ops.token_range_finalize(
+            tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
+            8 * SHAPE[0] * SHAPE[1])
+        add("lsq_plus_backward", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
+            xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
+    return rows
+
+
 def calibration_wall_clock(dev, rank, world, search="cached"):
     """BASELINE configs[1]: BERT-base (random init, HF default config), CoLA-shaped calibration set
     (256 samples = 8 batches of [32, 128], synthetic ids / lengths), twc_fine_gamma W6A6:
@@ -193,6 +247,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel timing table")
     ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
     args = ap.parse_args()
 
@@ -262,7 +317,7 @@ def main():
             x = xs[i % len(xs)]
             # same three launches as q(x, lengths, 1); split here only to hang the timing events on the dominant kernel
             q._observe(x, lengths, 1)
-            lib.osq_time_next_fake_quant(*pairs[i])
+            lib.osq_time_next_launch(_hip.TIME_FAKE_QUANT, *pairs[i])
             y = q._quantize(x)
     host_dt = time.perf_counter() - t0         # enqueue time: if this is close to dt the loop is host-bound
     if world > 1:
@@ -323,6 +378,8 @@ def main():
                      "avg_launch_us": round(fq_avg_ms * 1e3, 2), "median_launch_us": round(fq_ms[len(fq_ms) // 2] * 1e3, 2),
                      "algorithmic_bytes_per_launch": 8 * n_elem},
     }
+    if rank == 0 and not args.no_kernel_table:
+        out["kernels"] = kernel_table(dev, xs, lengths)
     if not args.no_calib:
         calib = calibration_wall_clock(dev, rank, world, args.calib_search)
         out["calibration"] = calib

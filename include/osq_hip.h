@@ -87,13 +87,21 @@ size_t      osq_workspace_bytes(void);
  * "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 = non-temporal loads/stores of the dense fake-quant. */
 int osq_set_tuning(const char* key, int value);
 
-/* Measurement aid (bench.py).  The events given to osq_time_next_fake_quant ride on the dispatch packet
- * of the NEXT dense osq_fake_quant_per_tensor launch issued by the calling thread, so
+/* Measurement aid (bench.py).  The events given to osq_time_next_launch ride on the dispatch packet of the
+ * NEXT launch of kernel family `which` issued by the calling thread (other launches pass untouched), so
  * osq_timing_elapsed_us(start, stop) is that kernel's own run time on its stream -- the duration
  * rocprofv3 --kernel-trace reports -- not the stream-order interval between two recorded events. */
+typedef enum osq_timed_kernel {
+    OSQ_TIME_NONE = 0,
+    OSQ_TIME_FAKE_QUANT = 1,     /* dense osq_fake_quant_per_tensor                      */
+    OSQ_TIME_LSQ_BACKWARD = 2,   /* osq_lsq_backward_per_tensor                          */
+    OSQ_TIME_OBSERVE_FLAT = 3,   /* osq_observe_flat (aligned input)                     */
+    OSQ_TIME_TOKEN_MINMAX = 4,   /* osq_token_minmax / first launch of osq_observe_tokens */
+    OSQ_TIME_TOKEN_SELECT = 5    /* two-workgroup launch of osq_token_range_finalize      */
+} osq_timed_kernel;
 int osq_timing_events_create(void** start, void** stop);
 int osq_timing_events_destroy(void* start, void* stop);
-int osq_time_next_fake_quant(void* start, void* stop);
+int osq_time_next_launch(int which, void* start, void* stop);
 int osq_timing_elapsed_us(void* start, void* stop, float* us);
 
 /* ------------------------------------------------------------------ fake-quant forward */

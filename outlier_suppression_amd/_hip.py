@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libosq_hip.so")
 ZP_INT32, ZP_FLOAT32 = 0, 1
 PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
 PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
+TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 
 _P = ctypes.c_void_p
@@ -40,7 +41,7 @@ SIGNATURES = {
     "osq_set_tuning": (_I, [ctypes.c_char_p, _I]),
     "osq_timing_events_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P)]),
     "osq_timing_events_destroy": (_I, [_P, _P]),
-    "osq_time_next_fake_quant": (_I, [_P, _P]),
+    "osq_time_next_launch": (_I, [_I, _P, _P]),
     "osq_timing_elapsed_us": (_I, [_P, _P, ctypes.POINTER(_F)]),
     "osq_fake_quant_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),

@@ -20,8 +20,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
 static int g_fq_max_blocks = 8192;
 static int g_fq_nt = 3;          // bit 0: loads, bit 1: stores
-// measurement aid (osq_time_next_fake_quant): events riding on the next dense per-tensor dispatch
-static thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+static int g_bwd_blocks = kMaxBlocks;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n))
 
 template <bool WRITE_Q>
 __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float s, float z, float qmin, float qmax) {
@@ -391,8 +390,8 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
         const float4* x4 = reinterpret_cast<const float4*>(x);
         float4* y4 = reinterpret_cast<float4*>(y);
         float4* q4 = reinterpret_cast<float4*>(x_quant);
-        const hipEvent_t ev0 = g_time_start, ev1 = g_time_stop;      // non-null: time this dispatch itself
-        g_time_start = g_time_stop = nullptr;
+        const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT);      // non-null events: time this dispatch itself
+        const hipEvent_t ev0 = th.start, ev1 = th.stop;
 #define OSQ_FQ(WQ, U, N)                                                                                                  \
     hipExtLaunchKernelGGL((fq_tensor_vec_kernel<WQ, U, N>), dim3(grid), dim3(kThreads), 0, st, ev0, ev1, 0, x4, y4, q4,   \
                           n4, x + n4 * 4, y + n4 * 4, x_quant ? x_quant + n4 * 4 : nullptr, tail, scale, zero_point,       \
@@ -496,7 +495,8 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     const int tail = static_cast<int>(n - n4 * 4);
     const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
     Workspace ws(workspace);
-    hipLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+    const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
+    hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
                        grad_out + n4 * 4, grad_x + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax,
                        grad_scale, grad_zero_point, ws.doubles(), ws.counter(0));
@@ -530,51 +530,12 @@ extern "C" int osq_lsq_sanitize(float* scale, float* zero_point, int64_t n, floa
     return check_launch("lsq_sanitize");
 }
 
-// ---- measurement aid: HIP events attached to a dispatch packet (hipExtLaunchKernelGGL) time the kernel's
-// own execution -- what rocprofv3 --kernel-trace reports -- instead of the stream-order interval between
-// two recorded events, which also contains the dispatch latency of the kernel boundary (~2-3 us).
-extern "C" int osq_timing_events_create(void** start, void** stop) {
-    OSQ_REQUIRE(start && stop, "timing_events_create: null pointer");
-    hipEvent_t a = nullptr, b = nullptr;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-        osq::set_error("timing_events_create: hipEventCreate failed");
-        return OSQ_ERR_HIP;
-    }
-    *start = a;
-    *stop = b;
-    return OSQ_OK;
-}
-
-extern "C" int osq_timing_events_destroy(void* start, void* stop) {
-    if (start) (void)hipEventDestroy(static_cast<hipEvent_t>(start));
-    if (stop) (void)hipEventDestroy(static_cast<hipEvent_t>(stop));
-    return OSQ_OK;
-}
-
-extern "C" int osq_time_next_fake_quant(void* start, void* stop) {
-    OSQ_REQUIRE((start == nullptr) == (stop == nullptr), "time_next_fake_quant: give both events or neither");
-    osq::g_time_start = static_cast<hipEvent_t>(start);
-    osq::g_time_stop = static_cast<hipEvent_t>(stop);
-    return OSQ_OK;
-}
-
-extern "C" int osq_timing_elapsed_us(void* start, void* stop, float* us) {
-    OSQ_REQUIRE(start && stop && us, "timing_elapsed_us: null pointer");
-    float ms = 0.f;
-    if (hipEventSynchronize(static_cast<hipEvent_t>(stop)) != hipSuccess ||
-        hipEventElapsedTime(&ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) != hipSuccess) {
-        osq::set_error("timing_elapsed_us: events not recorded");
-        return OSQ_ERR_HIP;
-    }
-    *us = ms * 1000.0f;
-    return OSQ_OK;
-}
-
 extern "C" int osq_set_tuning(const char* key, int value) {
     OSQ_REQUIRE(key, "set_tuning: null key");
     const std::string k(key);
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
+    else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }
     else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 3, "fq_nt must be 0..3"); osq::g_fq_nt = value; }
     else if (osq::set_observer_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }

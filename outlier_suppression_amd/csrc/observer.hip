@@ -7,6 +7,7 @@
 // that a whole observer call (reduce -> running statistic -> scale/zero_point) is
 // one launch for flat / per-channel tensors and two for masked activations.
 #include <string>
+#include <hip/hip_ext.h>
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -114,7 +115,8 @@ __global__ void update_kernel(const float* __restrict__ cur_min, const float* __
 __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __restrict__ x, int64_t n4,
                                                                 const float* __restrict__ xt, int tail,
                                                                 float* __restrict__ partials,
-                                                                unsigned int* __restrict__ counter, Finish fin) {
+                                                                unsigned int* __restrict__ counter, Finish fin,
+                                                                int layout) {
     MinMax acc;
     acc.init();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -126,12 +128,27 @@ __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __
         st_min = fin.min_val[0];
         st_max = fin.max_val[0];
     }
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = load_stream(&x[i]), b = load_stream(&x[i + stride]), c = load_stream(&x[i + 2 * stride]),
-                     d = load_stream(&x[i + 3 * stride]);
-        acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
+    if (layout == 1) {
+        // contiguous spans: workgroup b streams float4 [b*span, (b+1)*span) in 16 KB steps (4 x 4 KB per
+        // iteration), instead of four loads that are gridDim.x * 4 KB apart
+        const int64_t span = ((n4 + gridDim.x - 1) / gridDim.x + 4 * kThreads - 1) / (4 * kThreads) * (4 * kThreads);
+        const int64_t lo = static_cast<int64_t>(blockIdx.x) * span;
+        const int64_t hi = lo + span < n4 ? lo + span : n4;
+        int64_t j = lo + threadIdx.x;
+        for (; j + 3 * kThreads < hi; j += 4 * kThreads) {
+            const float4 a = load_stream(&x[j]), b = load_stream(&x[j + kThreads]), c = load_stream(&x[j + 2 * kThreads]),
+                         d = load_stream(&x[j + 3 * kThreads]);
+            acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
+        }
+        for (; j < hi; j += kThreads) acc.add4(x[j]);
+    } else {
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = load_stream(&x[i]), b = load_stream(&x[i + stride]), c = load_stream(&x[i + 2 * stride]),
+                         d = load_stream(&x[i + 3 * stride]);
+            acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
+        }
+        for (; i < n4; i += stride) acc.add4(x[i]);
     }
-    for (; i < n4; i += stride) acc.add4(x[i]);
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc.add(xt[threadIdx.x]);
     acc = block_reduce(acc);
     // ONE 8-byte partial per workgroup: {min, max}, a NaN minimum flags "NaN seen" (fminf never yields one)
@@ -731,6 +748,11 @@ namespace osq {
 // above the register-cache limit of the single-workgroup kernel, where that kernel would re-read the
 // arrays from L2 in every pass (~25 us per pass at 65536 slots).  osq_set_wide_min_slots() overrides.
 static int64_t g_wide_min_slots = 32769;
+static int g_obs_layout = 0;
+// Grid cap of observe_flat (osq_set_tuning("obs_blocks", n), <= kMaxBlocks).  The four loads of a thread are
+// gridDim.x * 4 KB apart: power-of-two grids (1024, 2048) put them on the same memory channels and measured
+// 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
+static int g_obs_blocks = 768;
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
@@ -1137,6 +1159,8 @@ static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t 
 bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
+    if (k == "obs_layout") { g_obs_layout = value; return true; }
+    if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
     return false;
 }
 
@@ -1144,7 +1168,9 @@ static inline void launch_select(hipStream_t st, const SelectArgs& a, const Fini
                                  int64_t problems) {
     const int64_t groups_per_thread = ((a.B * a.T) / 4 + kSelThreads - 1) / kSelThreads;
     const dim3 grid(2, static_cast<unsigned>(problems));
-#define OSQ_LAUNCH_SELECT(R4) hipLaunchKernelGGL(token_select_kernel<R4>, grid, dim3(kSelThreads), 0, st, a, fin, fb)
+    const TimingHook th = take_timing_hook(OSQ_TIME_TOKEN_SELECT);
+#define OSQ_LAUNCH_SELECT(R4) \
+    hipExtLaunchKernelGGL(token_select_kernel<R4>, grid, dim3(kSelThreads), 0, st, th.start, th.stop, 0, a, fin, fb)
     if (groups_per_thread <= 1) OSQ_LAUNCH_SELECT(1);
     else if (groups_per_thread <= 2) OSQ_LAUNCH_SELECT(2);
     else if (groups_per_thread <= 4) OSQ_LAUNCH_SELECT(4);
@@ -1197,9 +1223,11 @@ extern "C" int osq_observe_flat(const float* x, int64_t n,
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (aligned16(x)) {
         const int64_t n4 = n / 4;
-        const int grid = grid_for(n4, kThreads * 4, kMaxBlocks);
-        hipLaunchKernelGGL(observe_flat_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x), n4,
-                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(), ws.counter(1), fin);
+        const int grid = grid_for(n4, kThreads * 4, g_obs_blocks);
+        const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_FLAT);
+        hipExtLaunchKernelGGL(observe_flat_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0,
+                              reinterpret_cast<const float4*>(x), n4,
+                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(), ws.counter(1), fin, g_obs_layout);
     } else {
         // misaligned base: peel to the next 16-byte boundary by treating the head as the "tail" is not
         // possible with one pointer, so fall back to the per-channel kernel with a single channel.
@@ -1251,11 +1279,12 @@ extern "C" int osq_token_minmax(const float* x, const osq_token_view* view, cons
         }
         OSQ_REQUIRE(v.batch <= 65535, "token_minmax: batch exceeds grid.y");
         const dim3 tgrid(static_cast<unsigned>((v.tokens + kTokPerBlock - 1) / kTokPerBlock), static_cast<unsigned>(v.batch));
+        const TimingHook th = take_timing_hook(OSQ_TIME_TOKEN_MINMAX);
         if (v.feat_outer == 1)
-            hipLaunchKernelGGL(token_minmax_vec_kernel<true>, tgrid, dim3(kThreads), 0, st, x, v, lengths, token_min,
+            hipExtLaunchKernelGGL(token_minmax_vec_kernel<true>, tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, token_min,
                                token_max, lgG, inner4);
         else
-            hipLaunchKernelGGL(token_minmax_vec_kernel<false>, tgrid, dim3(kThreads), 0, st, x, v, lengths, token_min,
+            hipExtLaunchKernelGGL(token_minmax_vec_kernel<false>, tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, token_min,
                                token_max, lgG, inner4);
     } else {
         hipLaunchKernelGGL(token_minmax_generic_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, token_min,

@@ -17,6 +17,13 @@ constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of toke
 void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
 
+// Measurement aid (osq_time_next_launch): events that the next launch of kernel family `which` on this thread
+// carries on its dispatch packet (hipExtLaunchKernelGGL); {nullptr, nullptr} = plain launch.
+struct TimingHook {
+    hipEvent_t start, stop;
+};
+TimingHook take_timing_hook(int which);
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define OSQ_REQUIRE(cond, msg)                       \

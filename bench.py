@@ -146,6 +146,29 @@ def kernel_table(dev, xs, lengths, reps=20):
             8 * SHAPE[0] * SHAPE[1])
         add("lsq_plus_backward", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
             xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
+        # LayerNorm site of a quantized block: GammaResidual -> split LayerNorm -> + beta/gamma -> fake-quant, one launch
+        gamma = torch.rand(SHAPE[2], device=dev) + 0.5
+        shift = torch.randn(SHAPE[2], device=dev)
+        quant = (s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+        add("residual+layernorm+fake_quant (one launch)", timed(_hip.TIME_LAYERNORM, lambda i: ops.residual_layernorm_fake_quant(
+            xs[i % len(xs)], gy, gamma, None, shift, 1e-5, quant)), 12 * n)
+        # the same site as the eager sequence (4 launches; stream-order events around the whole sequence)
+        import torch.nn.functional as F
+        ev = []
+        for i in range(reps + 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = ops.gamma_residual(xs[i % len(xs)], gy, gamma)
+            r = F.layer_norm(r, (SHAPE[2],), None, None, 1e-5)
+            r += shift
+            r = ops.fake_quant_per_tensor(r, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        seq_us = sum(a.elapsed_time(b) for a, b in ev[3:]) / reps * 1e3
+        rows["same site, eager sequence (gamma_residual, layer_norm, add, fake_quant)"] = {
+            "avg_us": round(seq_us, 2), "algorithmic_MB": round(12 * n / 1e6, 1), "GBps": round(12 * n / seq_us / 1e3, 1),
+            "frac_of_8TBps": round(12 * n / seq_us / 1e3 / HBM_PEAK_GBS, 3)}
     return rows
 
 

@@ -97,7 +97,8 @@ typedef enum osq_timed_kernel {
     OSQ_TIME_LSQ_BACKWARD = 2,   /* osq_lsq_backward_per_tensor                          */
     OSQ_TIME_OBSERVE_FLAT = 3,   /* osq_observe_flat (aligned input)                     */
     OSQ_TIME_TOKEN_MINMAX = 4,   /* osq_token_minmax / first launch of osq_observe_tokens */
-    OSQ_TIME_TOKEN_SELECT = 5    /* two-workgroup launch of osq_token_range_finalize      */
+    OSQ_TIME_TOKEN_SELECT = 5,   /* two-workgroup launch of osq_token_range_finalize      */
+    OSQ_TIME_LAYERNORM = 6       /* osq_residual_layernorm_fake_quant                     */
 } osq_timed_kernel;
 int osq_timing_events_create(void** start, void** stop);
 int osq_timing_events_destroy(void* start, void* stop);
@@ -345,6 +346,26 @@ int osq_gamma_split_bias(const float* beta, const float* gamma, float* bias_out,
  * (gamma == NULL: input + hidden).  rows x cols contiguous. */
 int osq_gamma_residual(const float* input, const float* hidden, const float* gamma,
                        float* out, int64_t rows, int64_t cols, osq_stream stream);
+
+/* ------------------------------------------------------------------ residual + LayerNorm + fake-quant */
+
+/* One pass for what a LayerNorm site of the quantized models runs as four eager steps
+ * (model/quant_bert.py:211-216 / 298-303 with model/util_layernorm.py:14-18, 32-37, 49-52):
+ *     r = x * gamma + hidden        GammaResidual.forward      (hidden == NULL: r = x; gamma == NULL: x + hidden)
+ *     n = layer_norm(r, eps)        over the last axis, cols
+ *     n = n * weight + bias         QuantizedLayerNorm: the LayerNorm's affine pair;
+ *                                   QuantizedSplitLayerNorm: weight == NULL, bias = beta/gamma
+ *     y = fake_quantize(n)          scale == NULL: y = n (observer passes, qoutput == False)
+ * rows x cols contiguous fp32, cols % 4 == 0, cols <= 4096, 16-byte aligned operands (else
+ * OSQ_ERR_UNSUPPORTED and the caller keeps the eager sequence).  mode / grad_factor / zp_type as in
+ * osq_fake_quant_per_tensor, including OSQ_PARAM_SANITIZE.  8 B per element (12 with a residual)
+ * instead of 24-32.  Inference only: autograd passes use the eager sequence. */
+int osq_residual_layernorm_fake_quant(const float* x, const float* hidden, const float* gamma,
+                                      const float* weight, const float* bias, double eps,
+                                      float* y, int64_t rows, int64_t cols,
+                                      const float* scale, const void* zero_point, int zp_type,
+                                      int mode, float grad_factor, int quant_min, int quant_max,
+                                      osq_stream stream);
 
 #ifdef __cplusplus
 }

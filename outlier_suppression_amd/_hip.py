@@ -18,6 +18,7 @@ ZP_INT32, ZP_FLOAT32 = 0, 1
 PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
 PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
+TIME_LAYERNORM = 6
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 
 _P = ctypes.c_void_p
@@ -74,6 +75,7 @@ SIGNATURES = {
     "osq_gamma_fold": (_I, [_P, _P, _L, _L, _P]),
     "osq_gamma_split_bias": (_I, [_P, _P, _P, _L, _P]),
     "osq_gamma_residual": (_I, [_P, _P, _P, _P, _L, _L, _P]),
+    "osq_residual_layernorm_fake_quant": (_I, [_P, _P, _P, _P, _P, _D, _P, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
 }
 
 _lib = None

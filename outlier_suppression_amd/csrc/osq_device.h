@@ -39,6 +39,32 @@ __device__ __forceinline__ QParams effective_params(float scale, float zp, int m
     return {scale, zp};
 }
 
+// LSQFakeQuantize / LSQPlusFakeQuantize.forward with the observer off first repair their parameters in
+// place -- scale.abs_(); scale.clamp_(min=eps); zero_point.clamp_(qmin, qmax) (fake_quant.py:152-153,
+// 188-191) -- and then quantise with them.  With OSQ_PARAM_SANITIZE in `mode` the consuming launch does
+// both: every thread derives the repaired values itself (the repair is idempotent, so it does not matter
+// whether a thread sees the raw or the already repaired word) and thread 0 of workgroup 0 writes them back.
+constexpr float kLsqEps = 1.1920928955078125e-07f;     // torch.finfo(torch.float32).eps, the modules' `eps` buffer
+
+__device__ __forceinline__ QParams tensor_params(const float* scale_p, const void* zp_p, int zp_type, int mode, float g,
+                                                 float qmin, float qmax) {
+    float s = scale_p[0], z = load_zp(zp_p, zp_type);
+    const int base = mode & OSQ_PARAM_MODE_MASK;
+    if (mode & OSQ_PARAM_SANITIZE) {
+        s = fabsf(s);
+        s = (s < kLsqEps) ? kLsqEps : s;                // clamp_(min=eps) keeps NaN
+        if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) {
+            z = (z < qmin) ? qmin : z;
+            z = (z > qmax) ? qmax : z;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const_cast<float*>(scale_p)[0] = s;
+            if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) static_cast<float*>(const_cast<void*>(zp_p))[0] = z;
+        }
+    }
+    return effective_params(s, z, base, g);
+}
+
 // util_quant.py:12-13: x_int = round_ste(x/scale) + zp ; x_quant = clamp(x_int, qmin, qmax).
 // True IEEE division; (rint(u) - u) + u reproduces round_ste's value for every input
 // (== rint(u) for finite u, NaN for +-inf); the compare/select clamp lets NaN through

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm
+from ..util_layernorm import GammaResidual, QuantizedLayerNorm, residual_layernorm
 
 
 def shift_tokens_right(input_ids, pad_token_id, decoder_start_token_id):
@@ -156,12 +156,12 @@ class QuantizedBartEncoderLayer(QuantizedModule):
         residual = hidden_states
         h = self._drop(self.self_attn(hidden_states, attention_mask=attention_mask, observation_mask=observation_mask),
                        self.dropout)
-        h = self.self_attn_layer_norm(self.before_self_attn_layer_norm_residual(residual, h), observation_mask)
+        h = residual_layernorm(self.before_self_attn_layer_norm_residual, self.self_attn_layer_norm, residual, h, observation_mask)
         residual = h
         h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
         h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
         h = self._drop(self.fc2(h), self.dropout)
-        return self.final_layer_norm(self.before_final_layer_norm_residual(residual, h), observation_mask)
+        return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 
 
 class QuantizedBartDecoderLayer(QuantizedModule):
@@ -196,18 +196,18 @@ class QuantizedBartDecoderLayer(QuantizedModule):
         residual = hidden_states
         h = self._drop(self.self_attn(hidden_states, attention_mask=attention_mask, observation_mask=observation_mask),
                        self.dropout)
-        h = self.self_attn_layer_norm(self.before_self_attn_layer_norm_residual(residual, h), observation_mask)
+        h = residual_layernorm(self.before_self_attn_layer_norm_residual, self.self_attn_layer_norm, residual, h, observation_mask)
         if encoder_hidden_states is not None:
             residual = h
             h = self._drop(self.encoder_attn(h, key_value_states=encoder_hidden_states,
                                              attention_mask=encoder_attention_mask, observation_mask=observation_mask),
                            self.dropout)
-            h = self.encoder_attn_layer_norm(self.before_encoder_attn_layer_norm_residual(residual, h), observation_mask)
+            h = residual_layernorm(self.before_encoder_attn_layer_norm_residual, self.encoder_attn_layer_norm, residual, h, observation_mask)
         residual = h
         h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
         h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
         h = self._drop(self.fc2(h), self.dropout)
-        return self.final_layer_norm(self.before_final_layer_norm_residual(residual, h), observation_mask)
+        return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 
 
 class _BartStack(QuantizedModule):

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm
+from ..util_layernorm import GammaResidual, QuantizedLayerNorm, residual_layernorm
 
 
 class QuantizedBertEmbeddings(QuantizedModule):
@@ -100,8 +100,7 @@ class _DenseResidualNorm(QuantizedModule):
 
     def forward(self, hidden_states, input_tensor, observation_mask=None):
         hidden_states = self.dropout(self.dense(hidden_states))
-        hidden_states = self.before_LayerNorm_residual(input_tensor, hidden_states)
-        return self.LayerNorm(hidden_states, observation_mask)
+        return residual_layernorm(self.before_LayerNorm_residual, self.LayerNorm, input_tensor, hidden_states, observation_mask)
 
 
 class QuantizedBertSelfOutput(_DenseResidualNorm):

@@ -632,3 +632,45 @@ def gamma_residual(inp, hidden, gamma=None):
     _hip.check(lib.osq_gamma_residual(_hip.ptr(a), _hip.ptr(h), _hip.ptr(gamma), _hip.ptr(out), a.numel() // cols, cols,
                                       _hip.stream_ptr(a.device)), "gamma_residual")
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# residual + LayerNorm + fake-quant in one pass
+# ---------------------------------------------------------------------------------------
+
+def layernorm_fusable(x, *operands):
+    """Layout rules of osq_residual_layernorm_fake_quant."""
+    cols = x.shape[-1] if x.dim() else 0
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() and cols % 4 == 0 and cols <= 4096
+            and x.data_ptr() % 16 == 0):
+        return False
+    for t in operands:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
+            return False
+    return True
+
+
+def residual_layernorm_fake_quant(x, hidden, gamma, weight, bias, eps, quant=None):
+    """y = fake_quant(layer_norm(x*gamma + hidden) * weight + bias) in ONE launch; every operand but x may be None.
+    quant: None (no fake-quant) or (scale, zero_point, quant_min, quant_max, mode, grad_factor)."""
+    lib = _hip.load()
+    _hip.require_device(x, hidden, gamma, weight, bias)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if hidden is not None and hidden.shape != x.shape:
+        raise ValueError("residual_layernorm_fake_quant: hidden must have x's shape")
+    for name, t in (("gamma", gamma), ("weight", weight), ("bias", bias)):
+        if t is not None and t.numel() != cols:
+            raise ValueError(f"residual_layernorm_fake_quant: {name} must have {cols} entries")
+    y = torch.empty_like(x)
+    if quant is None:
+        s_ptr, z_ptr, z_type, mode, gf, qmin, qmax = None, None, ZP_INT32, PARAM_FIXED, 1.0, 0, 1
+    else:
+        scale, zero_point, qmin, qmax, mode, gf = quant
+        _hip.require_device(scale, zero_point)
+        s_ptr, z_ptr, z_type = scale.data_ptr(), zero_point.data_ptr(), _zp_type(zero_point)
+    _hip.check(lib.osq_residual_layernorm_fake_quant(x.data_ptr(), _hip.ptr(hidden), _hip.ptr(gamma), _hip.ptr(weight),
+                                                     _hip.ptr(bias), float(eps), y.data_ptr(), rows, cols, s_ptr, z_ptr,
+                                                     z_type, int(mode), float(gf), int(qmin), int(qmax),
+                                                     _hip.raw_stream(x.device)), "residual_layernorm_fake_quant")
+    return y

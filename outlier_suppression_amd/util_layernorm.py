@@ -1,8 +1,10 @@
 """LayerNorm wrappers used by Gamma Migration, with the reference's class names.
 
-Reference: quant_transformer/model/util_layernorm.py.  The normalisation itself stays stock
-PyTorch-ROCm (model maths is out of scope); the quantizer on the output is
-the HIP path, beta/gamma is computed by the HIP split-bias kernel.
+Reference: quant_transformer/model/util_layernorm.py.  Under autograd the normalisation stays stock
+PyTorch-ROCm followed by the HIP quantizer (the eager sequence of the reference).  Without autograd --
+every calibration / evaluation forward -- a LayerNorm site is ONE HIP launch: residual (GammaResidual),
+normalisation, affine pair or beta/gamma shift, and the output fake-quant (SURVEY.md 8f N4,
+``ops.residual_layernorm_fake_quant``); ``FUSE_LAYERNORM = False`` restores the eager sequence everywhere.
 """
 import torch
 import torch.nn.functional as F
@@ -10,6 +12,38 @@ from torch import nn
 
 from . import ops
 from .quantization import QuantizedModule, Quantizer
+from .quantization.fake_quant import _LearnableFakeQuantize
+
+FUSE_LAYERNORM = True
+
+
+def _fused_site(mod, x, hidden, gamma, weight, bias, eps, observation_mask):
+    """One launch for residual + LayerNorm (+ fake-quant when the site's quantizer is in its plain quantising state)."""
+    q = mod.layernorm_post_act_fake_quantize if mod.qoutput else None
+    quant = None
+    if q is not None and q.fake_quant_enabled == 1 and q.observer_enabled != 1 and q.ch_axis == -1 and q.scale.is_cuda:
+        mode = q.param_mode
+        if isinstance(q, _LearnableFakeQuantize):
+            mode |= ops.PARAM_SANITIZE            # observer off: the parameter repair of fake_quant.py:188-191 rides along
+        quant = (q.scale.data, q.zero_point.data, q.quant_min, q.quant_max, mode,
+                 q._grad_factor(x) if q.param_mode != ops.PARAM_FIXED else 1.0)
+    y = ops.residual_layernorm_fake_quant(x, hidden, gamma, weight, bias, eps, quant)
+    if q is not None and quant is None:           # observing, disabled, or per-channel: the quantizer's own path
+        y = q(y, observation_mask, 1)
+    return y
+
+
+def _can_fuse(x, *operands):
+    return (FUSE_LAYERNORM and not torch.is_grad_enabled() and x.dim() >= 2 and ops.layernorm_fusable(x, *operands))
+
+
+def residual_layernorm(residual, layernorm, shortcut, hidden_states, observation_mask=None):
+    """``layernorm(residual(shortcut, hidden_states), observation_mask)`` -- the pair every transformer block ends
+    its two halves with (quant_bert.py:211-216, 298-303; quant_bart.py:342-353) -- as one launch when possible."""
+    gamma = residual.gamma.data if residual.mul_gamma else None
+    if shortcut.shape == hidden_states.shape and _can_fuse(shortcut, hidden_states, gamma):
+        return layernorm.forward_fused(shortcut, hidden_states, gamma, observation_mask)
+    return layernorm(residual(shortcut, hidden_states), observation_mask)
 
 
 class QuantizedLayerNorm(QuantizedModule):
@@ -22,7 +56,18 @@ class QuantizedLayerNorm(QuantizedModule):
         if qoutput:
             self.layernorm_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, hidden_states, observation_mask=None):
+    def forward_fused(self, x, hidden, gamma, observation_mask=None):
+        ln = self.layernorm
+        if len(ln.normalized_shape) != 1 or not ops.layernorm_fusable(x, ln.weight, ln.bias):
+            if hidden is not None:
+                x = ops.gamma_residual(x, hidden, gamma)
+            return self.forward(x, observation_mask, _fused=False)
+        return _fused_site(self, x, hidden, gamma, None if ln.weight is None else ln.weight.data,
+                           None if ln.bias is None else ln.bias.data, ln.eps, observation_mask)
+
+    def forward(self, hidden_states, observation_mask=None, _fused=True):
+        if _fused and isinstance(self.layernorm, nn.LayerNorm) and _can_fuse(hidden_states):
+            return self.forward_fused(hidden_states, None, None, observation_mask)
         hidden_states = self.layernorm(hidden_states)
         if self.qoutput:
             hidden_states = self.layernorm_post_act_fake_quantize(hidden_states, observation_mask, 1)
@@ -50,7 +95,16 @@ class QuantizedSplitLayerNorm(QuantizedModule):
         if qoutput:
             self.layernorm_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, hidden_states, observation_mask=None):
+    def forward_fused(self, x, hidden, gamma, observation_mask=None):
+        if len(self.layernorm.normalized_shape) != 1 or not ops.layernorm_fusable(x, self.bias):
+            if hidden is not None:
+                x = ops.gamma_residual(x, hidden, gamma)
+            return self.forward(x, observation_mask, _fused=False)
+        return _fused_site(self, x, hidden, gamma, None, self.bias.data, self.layernorm.eps, observation_mask)
+
+    def forward(self, hidden_states, observation_mask=None, _fused=True):
+        if _fused and _can_fuse(hidden_states):
+            return self.forward_fused(hidden_states, None, None, observation_mask)
         hidden_states = F.layer_norm(hidden_states, self.layernorm.normalized_shape, None, None, self.layernorm.eps)
         hidden_states += self.bias
         if self.qoutput:

@@ -368,6 +368,85 @@ def test_gamma_golden(golden, eq32, dev):
     assert eq32(N(ops.gamma_residual(T(g["x"], dev), T(g["hidden"], dev), T(g["gamma"], dev))), g["res_after"])
 
 
+def test_fused_residual_layernorm_fake_quant(dev):
+    """One-launch LayerNorm site (residual + LayerNorm + affine / beta-over-gamma shift + fake-quant) against the
+    eager sequence it replaces (util_layernorm.py:14-18, 32-37, 49-52).  The normalisation cannot be bit-compared
+    with torch's kernel (different summation), so: un-quantised output within 2e-6 absolute of eager; quantised
+    output equal to fake_quant(own normalised output) bit for bit, and equal to the eager chain except where the
+    normalised value sits within 4e-6 of a rounding boundary (there it may differ by exactly one step)."""
+    import torch.nn.functional as F
+    from outlier_suppression_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    for shape in ((32, 128, 768), (4, 7, 64), (3, 5, 4096), (6, 1024), (2, 3, 260)):
+        H = shape[-1]
+        x = (torch.randn(*shape, generator=gen) * 2).to(dev)
+        hid = torch.randn(*shape, generator=gen).to(dev)
+        gamma = (torch.rand(H, generator=gen) + 0.5).to(dev)
+        w = (torch.rand(H, generator=gen) + 0.5).to(dev)
+        b = torch.randn(H, generator=gen).to(dev)
+        scale = torch.tensor([0.11], device=dev)
+        zp = torch.tensor([29.0], device=dev)
+        for use_hid, use_gamma, use_w, use_b, eps in ((1, 1, 0, 1, 1e-5), (1, 0, 1, 1, 1e-12), (0, 0, 1, 1, 1e-12), (0, 0, 0, 0, 1e-5)):
+            r = x
+            if use_hid:
+                r = (x * gamma if use_gamma else x) + hid
+            ref = F.layer_norm(r, (H,), None, None, eps)
+            if use_w:
+                ref = ref * w
+            if use_b:
+                ref = ref + b
+            args = (x, hid if use_hid else None, gamma if (use_hid and use_gamma) else None, w if use_w else None,
+                    b if use_b else None, eps)
+            y = ops.residual_layernorm_fake_quant(*args)
+            assert (y - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item()), (shape, use_hid, use_w)
+            yq = ops.residual_layernorm_fake_quant(*args, quant=(scale, zp, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
+            assert torch.equal(yq, ops.fake_quant_per_tensor(y, scale, zp, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
+            eager = ops.fake_quant_per_tensor(ref.contiguous(), scale, zp, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+            diff = yq != eager
+            if diff.any():
+                frac = ref / scale.item()
+                near_tie = ((frac - frac.floor()) - 0.5).abs() < 4e-6 / scale.item()
+                assert bool((near_tie | ~diff).all()), shape
+                assert ((yq - eager).abs()[diff] - scale.item()).abs().max().item() < 1e-5
+                assert diff.float().mean().item() < 1e-3
+    # layouts the kernel rejects surface as an error, and the modules fall back to the eager sequence
+    with pytest.raises(RuntimeError):
+        ops.residual_layernorm_fake_quant(torch.randn(4, 102, device=dev), None, None, None, None, 1e-5)
+    # module level: fused forward == eager forward of the same modules, incl. the LSQ+ parameter repair
+    from outlier_suppression_amd import util_layernorm as UL
+    cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    ln = torch.nn.LayerNorm(64, eps=1e-12).to(dev)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    for cls in (UL.QuantizedLayerNorm, UL.QuantizedSplitLayerNorm):
+        mod = cls(ln, None, cfg).to(dev)
+        res = UL.GammaResidual()
+        res.set_gamma(ln.weight)
+        res = res.to(dev)
+        q = mod.layernorm_post_act_fake_quantize
+        xs, hs = torch.randn(5, 9, 64, device=dev), torch.randn(5, 9, 64, device=dev)
+        L = torch.tensor([9, 3, 1, 9, 5], device=dev)
+        outs = {}
+        for fuse in (True, False):
+            UL.FUSE_LAYERNORM = fuse
+            try:
+                with torch.no_grad():
+                    q.enable_observer(); q.disable_fake_quant()
+                    q.observer.min_val.fill_(float("inf")); q.observer.max_val.fill_(float("-inf")); q.observer.cnt = 0
+                    y_obs = UL.residual_layernorm(res, mod, xs, hs, L)
+                    q.disable_observer(); q.enable_fake_quant()
+                    q.scale.data.neg_()                               # the repair must run in both forms
+                    y_q = UL.residual_layernorm(res, mod, xs, hs, L)
+                    outs[fuse] = (y_obs.clone(), y_q.clone(), q.scale.item(), q.zero_point.item())
+            finally:
+                UL.FUSE_LAYERNORM = True
+        assert (outs[True][0] - outs[False][0]).abs().max().item() < 5e-6
+        assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) < 1e-6 * outs[False][2]
+        assert (outs[True][1] - outs[False][1]).abs().max().item() <= outs[False][2] * 1.001   # at most one step, at ties
+        assert (outs[True][1] != outs[False][1]).float().mean().item() < 5e-3
+
+
 # ----------------------------------------------------------------------------------- full size, properties
 
 def test_full_size_properties(dev):

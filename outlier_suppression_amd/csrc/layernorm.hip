@@ -60,14 +60,19 @@ __global__ __launch_bounds__(kLnThreads) void residual_layernorm_fq_kernel(LnArg
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kLnWaves;
     QParams p{1.f, 0.f};
     if (a.scale) p = tensor_params(a.scale, a.zero_point, a.zp_type, a.mode, a.grad_factor, a.qmin, a.qmax);
-    // per-column operands stay in registers across the rows of this wave
-    float4 g[R], w[R], b[R];
+    // per-column operands stay in registers across the rows of this wave while the row is short (<= 1024
+    // columns: every LayerNorm of BERT / RoBERTa / BART); longer rows re-read them (L1/L2 hits) per row
+    constexpr bool KEEP = R <= 4;
+    constexpr int RK = KEEP ? R : 1;
+    float4 g[RK], w[RK], b[RK];
+    if (KEEP) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int c = lane + k * OSQ_WAVE, cc = c < a.cols4 ? c : a.cols4 - 1;
-        g[k] = (a.hidden && a.gamma) ? a.gamma[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
-        w[k] = a.weight ? a.weight[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
-        b[k] = a.bias ? a.bias[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < RK; ++k) {
+            const int c = lane + k * OSQ_WAVE, cc = c < a.cols4 ? c : a.cols4 - 1;
+            g[k] = (a.hidden && a.gamma) ? a.gamma[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
+            w[k] = a.weight ? a.weight[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
+            b[k] = a.bias ? a.bias[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     for (int64_t row = wave0; row < a.rows; row += nwaves) {
         const float4* xr = a.x + row * a.cols4;
@@ -83,7 +88,11 @@ __global__ __launch_bounds__(kLnThreads) void residual_layernorm_fq_kernel(LnArg
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (hr) {
-                if (a.gamma) { v[k].x *= g[k].x; v[k].y *= g[k].y; v[k].z *= g[k].z; v[k].w *= g[k].w; }
+                if (a.gamma) {
+                    const int c = lane + k * OSQ_WAVE;
+                    const float4 gk = KEEP ? g[KEEP ? k : 0] : a.gamma[c < a.cols4 ? c : a.cols4 - 1];
+                    v[k].x *= gk.x; v[k].y *= gk.y; v[k].z *= gk.z; v[k].w *= gk.w;
+                }
                 v[k].x += h[k].x; v[k].y += h[k].y; v[k].z += h[k].z; v[k].w += h[k].w;
             }
             if (lane + k * OSQ_WAVE < a.cols4) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
@@ -105,7 +114,9 @@ __global__ __launch_bounds__(kLnThreads) void residual_layernorm_fq_kernel(LnArg
             const int c = lane + k * OSQ_WAVE;
             if (c < a.cols4) {
                 float t[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                const float ww[4] = {w[k].x, w[k].y, w[k].z, w[k].w}, bb[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+                const float4 wk = KEEP ? w[KEEP ? k : 0] : (a.weight ? a.weight[c] : make_float4(1.f, 1.f, 1.f, 1.f));
+                const float4 bk = KEEP ? b[KEEP ? k : 0] : (a.bias ? a.bias[c] : make_float4(0.f, 0.f, 0.f, 0.f));
+                const float ww[4] = {wk.x, wk.y, wk.z, wk.w}, bb[4] = {bk.x, bk.y, bk.z, bk.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float u = (t[e] - mean) * rstd;

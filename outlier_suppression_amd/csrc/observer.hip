@@ -268,11 +268,28 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
     for (int k = 0; k < kTokPerWave; ++k) acc[k].init();
     if (SINGLE_SEGMENT) {
-        for (int j = lane; j < inner4; j += OSQ_WAVE) {
+        // three column steps at a time (768 columns = exactly one trip): 12 independent 16-byte loads per lane
+        // are issued before the first is reduced; the short loop below takes what is left
+        int j = lane;
+        for (; j + 2 * OSQ_WAVE < inner4; j += 3 * OSQ_WAVE) {
+            float4 val[3][kTokPerWave];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < kTokPerWave; ++k) {
+                    const int kk = k < ntok ? k : 0;             // short tail: re-read token 0, result unused
+                    val[u][k] = load_stream(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j + u * OSQ_WAVE);
+                }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[u][k]);
+        }
+        for (; j < inner4; j += OSQ_WAVE) {
             float4 val[kTokPerWave];
 #pragma unroll
             for (int k = 0; k < kTokPerWave; ++k) {
-                const int kk = k < ntok ? k : 0;                 // short tail: re-read token 0, result unused
+                const int kk = k < ntok ? k : 0;
                 val[k] = load_stream(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j);
             }
 #pragma unroll

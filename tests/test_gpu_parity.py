@@ -415,17 +415,18 @@ def test_fused_residual_layernorm_fake_quant(dev):
     # module level: fused forward == eager forward of the same modules, incl. the LSQ+ parameter repair
     from outlier_suppression_amd import util_layernorm as UL
     cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    ln = torch.nn.LayerNorm(64, eps=1e-12).to(dev)
+    ln = torch.nn.LayerNorm(64, eps=1e-12)
     with torch.no_grad():
-        ln.weight.uniform_(0.5, 1.5)
-        ln.bias.normal_()
+        ln.weight.copy_(torch.rand(64, generator=gen) + 0.5)
+        ln.bias.copy_(torch.randn(64, generator=gen))
+    ln = ln.to(dev)
     for cls in (UL.QuantizedLayerNorm, UL.QuantizedSplitLayerNorm):
         mod = cls(ln, None, cfg).to(dev)
         res = UL.GammaResidual()
         res.set_gamma(ln.weight)
         res = res.to(dev)
         q = mod.layernorm_post_act_fake_quantize
-        xs, hs = torch.randn(5, 9, 64, device=dev), torch.randn(5, 9, 64, device=dev)
+        xs, hs = torch.randn(5, 9, 64, generator=gen).to(dev), torch.randn(5, 9, 64, generator=gen).to(dev)
         L = torch.tensor([9, 3, 1, 9, 5], device=dev)
         outs = {}
         for fuse in (True, False):
@@ -441,10 +442,12 @@ def test_fused_residual_layernorm_fake_quant(dev):
                     outs[fuse] = (y_obs.clone(), y_q.clone(), q.scale.item(), q.zero_point.item())
             finally:
                 UL.FUSE_LAYERNORM = True
-        assert (outs[True][0] - outs[False][0]).abs().max().item() < 5e-6
+        assert (outs[True][0] - outs[False][0]).abs().max().item() < 4e-6 * max(1.0, outs[False][0].abs().max().item())
         assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) < 1e-6 * outs[False][2]
         assert (outs[True][1] - outs[False][1]).abs().max().item() <= outs[False][2] * 1.001   # at most one step, at ties
-        assert (outs[True][1] != outs[False][1]).float().mean().item() < 5e-3
+        # the observed range (hence scale) may differ by an ulp between the two forms: count whole-step flips only
+        flips = (outs[True][1] - outs[False][1]).abs() > 0.5 * outs[False][2]
+        assert flips.float().mean().item() < 5e-3
 
 
 # ----------------------------------------------------------------------------------- full size, properties

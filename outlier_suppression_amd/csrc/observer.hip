@@ -115,8 +115,7 @@ __global__ void update_kernel(const float* __restrict__ cur_min, const float* __
 __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __restrict__ x, int64_t n4,
                                                                 const float* __restrict__ xt, int tail,
                                                                 float* __restrict__ partials,
-                                                                unsigned int* __restrict__ counter, Finish fin,
-                                                                int layout) {
+                                                                unsigned int* __restrict__ counter, Finish fin) {
     MinMax acc;
     acc.init();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -128,27 +127,12 @@ __global__ __launch_bounds__(kThreads) void observe_flat_kernel(const float4* __
         st_min = fin.min_val[0];
         st_max = fin.max_val[0];
     }
-    if (layout == 1) {
-        // contiguous spans: workgroup b streams float4 [b*span, (b+1)*span) in 16 KB steps (4 x 4 KB per
-        // iteration), instead of four loads that are gridDim.x * 4 KB apart
-        const int64_t span = ((n4 + gridDim.x - 1) / gridDim.x + 4 * kThreads - 1) / (4 * kThreads) * (4 * kThreads);
-        const int64_t lo = static_cast<int64_t>(blockIdx.x) * span;
-        const int64_t hi = lo + span < n4 ? lo + span : n4;
-        int64_t j = lo + threadIdx.x;
-        for (; j + 3 * kThreads < hi; j += 4 * kThreads) {
-            const float4 a = load_stream(&x[j]), b = load_stream(&x[j + kThreads]), c = load_stream(&x[j + 2 * kThreads]),
-                         d = load_stream(&x[j + 3 * kThreads]);
-            acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
-        }
-        for (; j < hi; j += kThreads) acc.add4(x[j]);
-    } else {
-        for (; i + 3 * stride < n4; i += 4 * stride) {
-            const float4 a = load_stream(&x[i]), b = load_stream(&x[i + stride]), c = load_stream(&x[i + 2 * stride]),
-                         d = load_stream(&x[i + 3 * stride]);
-            acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
-        }
-        for (; i < n4; i += stride) acc.add4(x[i]);
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = load_stream(&x[i]), b = load_stream(&x[i + stride]), c = load_stream(&x[i + 2 * stride]),
+                     d = load_stream(&x[i + 3 * stride]);
+        acc.add4(a); acc.add4(b); acc.add4(c); acc.add4(d);
     }
+    for (; i < n4; i += stride) acc.add4(x[i]);
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc.add(xt[threadIdx.x]);
     acc = block_reduce(acc);
     // ONE 8-byte partial per workgroup: {min, max}, a NaN minimum flags "NaN seen" (fminf never yields one)
@@ -765,7 +749,6 @@ namespace osq {
 // above the register-cache limit of the single-workgroup kernel, where that kernel would re-read the
 // arrays from L2 in every pass (~25 us per pass at 65536 slots).  osq_set_wide_min_slots() overrides.
 static int64_t g_wide_min_slots = 32769;
-static int g_obs_layout = 0;
 // Grid cap of observe_flat (osq_set_tuning("obs_blocks", n), <= kMaxBlocks).  The four loads of a thread are
 // gridDim.x * 4 KB apart: power-of-two grids (1024, 2048) put them on the same memory channels and measured
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
@@ -1176,7 +1159,6 @@ static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t 
 bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
-    if (k == "obs_layout") { g_obs_layout = value; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
     return false;
 }
@@ -1244,7 +1226,7 @@ extern "C" int osq_observe_flat(const float* x, int64_t n,
         const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_FLAT);
         hipExtLaunchKernelGGL(observe_flat_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0,
                               reinterpret_cast<const float4*>(x), n4,
-                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(), ws.counter(1), fin, g_obs_layout);
+                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(), ws.counter(1), fin);
     } else {
         // misaligned base: peel to the next 16-byte boundary by treating the head as the "tail" is not
         // possible with one pointer, so fall back to the per-channel kernel with a single channel.

@@ -753,6 +753,7 @@ static int64_t g_wide_min_slots = 32769;
 // gridDim.x * 4 KB apart: power-of-two grids (1024, 2048) put them on the same memory channels and measured
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
 static int g_obs_blocks = 768;
+static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
@@ -1159,6 +1160,7 @@ static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t 
 bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
+    if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
     return false;
 }
@@ -1312,7 +1314,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
     const bool wide = batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune);
     if (!wide && workspace && select_fast_ok(token_min, token_max, batch, tokens, 0, 1)) {
-        const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet()};
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet(), g_select_shortcut};
         launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr}, 1);
         return check_launch("token_range_finalize(select)");
     }
@@ -1370,7 +1372,7 @@ extern "C" int osq_token_range_finalize_batched(const float* token_min, const fl
     const float qf = static_cast<float>(percentile);
     const int64_t problems = static_cast<int64_t>(n_quantizers) * n_batches;
     if (workspace && select_fast_ok(token_min, token_max, batch, tokens, problem_stride, problems)) {
-        const SelectArgs a{token_min, token_max, batch, tokens, lengths, 1, qf, Workspace(workspace).meet()};
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, 1, qf, Workspace(workspace).meet(), g_select_shortcut};
         launch_select(st, a, fin, fb, problems);
         return check_launch("token_range_finalize_batched(select)");
     }

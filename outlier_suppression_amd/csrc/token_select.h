@@ -35,6 +35,7 @@ struct SelectArgs {
     int prune;
     float q;
     unsigned long long* meet;     // one rendezvous word per problem, zero when idle
+    int shortcut;                 // 0: always run the threshold pass over the registers (tests)
 };
 
 #ifdef OSQ_FINAL_TIMING
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
     __shared__ unsigned int hist[kSelBins];
     __shared__ unsigned int list[kListCap];
     __shared__ SelState sel;
-    __shared__ unsigned int s_n, s_bad, s_kmin, s_kmax, s_plain, s_fill, s_next, s_found[2], s_sel;
+    __shared__ unsigned int s_n, s_bad, s_kmin, s_kmax, s_plain, s_fill, s_next, s_found[2], s_sel, s_pos;
     __shared__ unsigned int s_wtot[kSelWaves];
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
     for (int k = tid; k < kSelBins; k += kSelThreads) hist[k] = 0u;
     if (tid == 0) {
         s_n = 0u; s_bad = 0u; s_kmin = 0xffffffffu; s_kmax = 0u; s_plain = 0u; s_fill = 0u;
-        s_next = 0xffffffffu; s_found[0] = s_found[1] = 0xffffffffu; s_sel = 0u;
+        s_next = 0xffffffffu; s_found[0] = s_found[1] = 0xffffffffu; s_sel = 0u; s_pos = 0u;
     }
     OSQ_SSTAMP(1);
 
@@ -205,8 +206,10 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
                 __syncthreads();
             }
             const unsigned int lo = uniform(sel.lo), wd = uniform(sel.width), sh = uniform(sel.shift);
-            // the range check also keeps poisoned slots (key 0x7fc00000) out: sending them all to one trash
-            // bin instead was measured 5x slower (same-address LDS atomics serialise)
+            // The range check also keeps poisoned slots (key 0x7fc00000) out.  Measured alternatives: all of them
+            // into ONE trash bin is 5x slower (same-address LDS atomics serialise); one trash bin per lane with a
+            // v_min instead of the compare + exec masking is no faster (6.6k vs 6.4k cycles at 32768 slots) --
+            // the pass is bound by the LDS atomic rate (~10 clocks per wave instruction), and masking does fewer.
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const unsigned int d = abs_key(v[i]) - lo;
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         }
         OSQ_SSTAMP(3);
         unsigned int v_lo, v_hi;     // keys at floor(rank) / ceil(rank)
+        bool shortcut_done = false;  // uniform
         if (!sel.done && listed) {
             // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
             const unsigned int lo = uniform(sel.lo), wd = uniform(sel.width);
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const unsigned int key = abs_key(v[i]);
-                if (key - lo < wd) list[atomicAdd(&s_fill, 1u)] = key;
+                if (key - lo < wd) list[atomicAdd(&s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
             }
             if (need_next) {
                 // smallest key at or above the bin's end: keys below it wrap to huge values under the
@@ -269,10 +273,10 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
             __syncthreads();
             const unsigned int cnt = s_fill, want = sel.rank;
             if (static_cast<unsigned int>(tid) < cnt) {     // rank by counting, ties broken by position
-                const unsigned int mine = list[tid];
+                const unsigned int mine = list[tid] & 0x7fffffffu;
                 unsigned int r = 0u;
                 for (unsigned int j = 0; j < cnt; ++j) {
-                    const unsigned int o = list[j];
+                    const unsigned int o = list[j] & 0x7fffffffu;
                     r += (o < mine || (o == mine && j < static_cast<unsigned int>(tid))) ? 1u : 0u;
                 }
                 if (r == want) s_found[0] = mine;
@@ -280,7 +284,33 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
             }
             __syncthreads();
             v_lo = s_found[0];
-            v_hi = s_found[1] != 0xffffffffu ? s_found[1] : s_next;
+            const bool hi_listed = s_found[1] != 0xffffffffu;
+            v_hi = hi_listed ? s_found[1] : s_next;
+            // Shortcut for the threshold pass.  The keys at ranks floor/ceil are neighbours in sorted order, so
+            // no key lies strictly between them, thr lies in [lo_v, hi_v], and every value with a larger key
+            // is either negative or above thr.  If some element with key lo_v is non-negative, then
+            // max(v[v <= thr]) is lo_v -- or hi_v when thr reaches it and a non-negative element has that
+            // key.  Both facts are in the list (it holds every element of the bin, with sign) as long as the
+            // upper key is listed or not reached; otherwise the register pass below decides.
+            if (a.shortcut) {
+                if (static_cast<unsigned int>(tid) < cnt) {
+                    const unsigned int e = list[tid];
+                    if (!(e >> 31)) {
+                        if (e == v_lo) atomicOr(&s_pos, 1u);
+                        if (e == v_hi) atomicOr(&s_pos, 2u);
+                    }
+                }
+                __syncthreads();
+                const unsigned int pos = s_pos;
+                const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
+                const float d = hi_f - lo_f;
+                const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
+                const bool reaches_hi = hi_f > lo_f && t >= hi_f;
+                if ((pos & 1u) && (!reaches_hi || hi_listed)) {
+                    shortcut_done = true;
+                    result = (reaches_hi && (pos & 2u)) ? hi_f : lo_f;
+                }
+            }
         } else {
             // every level ran (massive duplicates): sel.lo is the key at rank k_lo, sel.le = #keys <= it
             v_lo = uniform(sel.lo);
@@ -304,14 +334,16 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         const float lo_v = __uint_as_float(v_lo), hi_v = __uint_as_float(v_hi), diff = hi_v - lo_v;
         float thr = (w < 0.5f) ? __builtin_fmaf(w, diff, lo_v) : __builtin_fmaf(w - 1.0f, diff, hi_v);   // torch lerp
         thr = __uint_as_float(uniform(__float_as_uint(thr)));
-        // ---- max(v[v <= thr])
-        float best = -__builtin_inff();
+        if (!shortcut_done) {
+            // ---- max(v[v <= thr]) over the registers
+            float best = -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < R; ++i) best = (v[i] <= thr) ? fmaxf(best, v[i]) : best;
-        best = wave_max(best);
-        if (lane == 0) atomicMax(&s_sel, ordered_bits(best));
-        __syncthreads();
-        result = from_ordered_bits(s_sel);
+            for (int i = 0; i < R; ++i) best = (v[i] <= thr) ? fmaxf(best, v[i]) : best;
+            best = wave_max(best);
+            if (lane == 0) atomicMax(&s_sel, ordered_bits(best));
+            __syncthreads();
+            result = from_ordered_bits(s_sel);
+        }
     }
     OSQ_SSTAMP(5);
     // ---- rendezvous of the two sides: first arriver leaves {value, present | bad}, second finishes

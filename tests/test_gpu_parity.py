@@ -683,6 +683,7 @@ def test_finaliser_paths_agree_with_oracle(eq32, dev):
     }
     def run(path):
         ops.set_tuning("final_fast", 0 if path == "single" else 1)
+        ops.set_tuning("select_shortcut", 0 if path == "select_full_pass" else 1)
         ops.set_wide_min_slots(1024 if path == "wide" else 32769)
         try:
             for (B, Tn, H) in geoms:
@@ -722,9 +723,51 @@ def test_finaliser_paths_agree_with_oracle(eq32, dev):
             assert torch.isnan(ob.min_val).item() and torch.isnan(ob.max_val).item()
         finally:
             ops.set_tuning("final_fast", 1)
+            ops.set_tuning("select_shortcut", 1)
             ops.set_wide_min_slots(32769)
-    for path in ("select", "single", "wide"):
+    for path in ("select", "select_full_pass", "single", "wide"):
         run(path)
+
+
+def test_select_shortcut_equals_full_pass(dev):
+    """token_select_kernel answers max(v[v <= thr]) from the candidate list when an element with the lower
+    order-statistic key is non-negative, and by a pass over the registers otherwise: both must give the same bits
+    on mixed signs, heavy duplicates, tiny N, thresholds that land exactly on the upper key, all percentiles."""
+    from outlier_suppression_amd import ops
+    gen = torch.Generator().manual_seed(2024)
+    cur = [torch.empty(2, device=dev), torch.empty(2, device=dev)]
+    n_cases = 0
+    for trial in range(120):
+        B = int(torch.randint(1, 40, (1,), generator=gen))
+        T_ = int(torch.randint(1, 20, (1,), generator=gen)) * 4
+        kind = trial % 6
+        shape = (B * T_,)
+        if kind == 0:
+            tmax = torch.randn(shape, generator=gen)
+        elif kind == 1:
+            tmax = torch.randint(-3, 4, shape, generator=gen).float()
+        elif kind == 2:
+            tmax = -torch.rand(shape, generator=gen) - 0.5
+        elif kind == 3:
+            tmax = torch.randn(shape, generator=gen).abs() * torch.where(torch.rand(shape, generator=gen) < 0.1, -1.0, 1.0)
+        elif kind == 4:
+            tmax = torch.randint(0, 2, shape, generator=gen).float() * 2 - 1        # only +1 / -1
+        else:
+            tmax = torch.randn(shape, generator=gen) * 1e-3 + 5.0
+        tmin = tmax - torch.rand(shape, generator=gen) * (1.0 if kind != 1 else 0.0) - (torch.randint(0, 3, shape, generator=gen).float() if kind == 1 else 0.0)
+        L = torch.randint(0, T_ + 1, (B,), generator=gen)
+        L[int(torch.randint(0, B, (1,), generator=gen))] = T_
+        tmin_d, tmax_d, L_d = tmin.to(dev), tmax.to(dev), L.to(dev)
+        for p in (0.0, 0.3, 0.5, 0.77, 0.9, 0.95, 0.99, 1.0):
+            for k, flag in enumerate((1, 0)):
+                ops.set_tuning("select_shortcut", flag)
+                ops.token_range_finalize(tmin_d, tmax_d, B, T_, L_d, True, p, ops.UPDATE_NONE, 0, None, None, 0, 63, False,
+                                         None, cur[k])
+            ops.set_tuning("select_shortcut", 1)
+            a, b = cur[0].cpu(), cur[1].cpu()
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (trial, kind, B, T_, p, a, b)
+            n_cases += 1
+    assert n_cases == 960
 
 
 # ----------------------------------------------------------------------------------- remaining observers (N3)

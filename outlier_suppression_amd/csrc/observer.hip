@@ -227,7 +227,10 @@ constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;      // consecutive t
 // Lane layout inside a token: the wave is split into 64/G groups of G lanes; group g walks
 // feature segments g, g + 64/G, ...; G = 64 for one long segment ([B,T,768]), G = 16 for
 // head_dim 64 ([B,h,T,64] and its views) so that no lane idles on short segments.
-template <bool SINGLE_SEGMENT>
+template <bool NT>
+__device__ __forceinline__ float4 tok_load(const float4* p) { return NT ? load_stream(p) : *p; }
+
+template <bool SINGLE_SEGMENT, bool NT>
 __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float* __restrict__ x, osq_token_view v,
                                                                     const int64_t* __restrict__ lengths,
                                                                     float* __restrict__ tok_min,
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
                 for (int k = 0; k < kTokPerWave; ++k) {
                     const int kk = k < ntok ? k : 0;             // short tail: re-read token 0, result unused
-                    val[u][k] = load_stream(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j + u * OSQ_WAVE);
+                    val[u][k] = tok_load<NT>(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j + u * OSQ_WAVE);
                 }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
             for (int k = 0; k < kTokPerWave; ++k) {
                 const int kk = k < ntok ? k : 0;
-                val[k] = load_stream(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j);
+                val[k] = tok_load<NT>(reinterpret_cast<const float4*>(base + kk * v.stride_token) + j);
             }
 #pragma unroll
             for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
 #pragma unroll
                 for (int k = 0; k < kTokPerWave; ++k) {
                     const int kk = k < ntok ? k : 0;
-                    val[k] = load_stream(reinterpret_cast<const float4*>(seg + kk * v.stride_token) + j);
+                    val[k] = tok_load<NT>(reinterpret_cast<const float4*>(seg + kk * v.stride_token) + j);
                 }
 #pragma unroll
                 for (int k = 0; k < kTokPerWave; ++k) acc[k].add4(val[k]);
@@ -753,6 +756,7 @@ static int64_t g_wide_min_slots = 32769;
 // gridDim.x * 4 KB apart: power-of-two grids (1024, 2048) put them on the same memory channels and measured
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
 static int g_obs_blocks = 768;
+static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 constexpr int kWideThreads = 256;
@@ -1160,6 +1164,7 @@ static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t 
 bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
+    if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
     return false;
@@ -1281,12 +1286,12 @@ extern "C" int osq_token_minmax(const float* x, const osq_token_view* view, cons
         OSQ_REQUIRE(v.batch <= 65535, "token_minmax: batch exceeds grid.y");
         const dim3 tgrid(static_cast<unsigned>((v.tokens + kTokPerBlock - 1) / kTokPerBlock), static_cast<unsigned>(v.batch));
         const TimingHook th = take_timing_hook(OSQ_TIME_TOKEN_MINMAX);
-        if (v.feat_outer == 1)
-            hipExtLaunchKernelGGL(token_minmax_vec_kernel<true>, tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, token_min,
-                               token_max, lgG, inner4);
-        else
-            hipExtLaunchKernelGGL(token_minmax_vec_kernel<false>, tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, token_min,
-                               token_max, lgG, inner4);
+#define OSQ_TOK(SEG, NT) \
+    hipExtLaunchKernelGGL((token_minmax_vec_kernel<SEG, NT>), tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, \
+                          token_min, token_max, lgG, inner4)
+        if (v.feat_outer == 1) { if (g_tok_nt) OSQ_TOK(true, true); else OSQ_TOK(true, false); }
+        else { if (g_tok_nt) OSQ_TOK(false, true); else OSQ_TOK(false, false); }
+#undef OSQ_TOK
     } else {
         hipLaunchKernelGGL(token_minmax_generic_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, token_min,
                            token_max);

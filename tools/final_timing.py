@@ -1,4 +1,6 @@
-"""Development aid: phase timestamps of token_finalize_kernel (needs `make -C csrc dbg`)."""
+"""Development aid: phase timestamps (shader clocks, ~2.5 GHz) of the token finaliser, taken by thread 0 of the
+side-0 workgroup of token_select_kernel: [issue, loads + pass 0, histogram + scan, list + ranking, threshold,
+exchange + finish].  Needs the -DOSQ_FINAL_TIMING build: `make -C outlier_suppression_amd/csrc dbg`."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,4 +20,4 @@ for B in (32, 256):
             torch.cuda.synchronize()
         st = cur[2:2 + 14].view(torch.int64).cpu().tolist()
         d = [(st[i + 1] - st[i]) for i in range(6) if st[i + 1] and st[i]]
-        print(f"B={B} prune={prune} stamps(delta, 100MHz ticks?):", d, "total", st[6] - st[0])
+        print(f"B={B} prune={prune} phase clocks:", d, "total", st[6] - st[0], f"= {(st[6] - st[0]) / 2500:.1f} us at 2.5 GHz")

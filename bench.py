@@ -206,9 +206,9 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
                         "token_type_ids": torch.zeros_like(ids).to(dev)})
     a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    model = quantize_model(fp, w_q, a_q).to(dev)
     TWC.task_type, TWC.model_type = "glue", "bert"
     mine = calibration.shard_batches(n_batches, rank, world)
+    model = None
 
     def sync():
         torch.cuda.synchronize()
@@ -216,6 +216,8 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
             dist.barrier()
 
     def run(search):
+        nonlocal model
+        model = quantize_model(fp, w_q, a_q).to(dev)      # deep copy of the FP model, as quant_model.py:44-48: fp stays pristine
         phases = {}
         sync()
         t_start = t0 = time.perf_counter()
@@ -250,9 +252,14 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         sync(); phases["learn_scale"] = time.perf_counter() - t0
         return time.perf_counter() - t_start, phases, ratio
 
+    # The whole calibration runs twice on fresh copies of the model: the first pass also pays the process's one-time
+    # costs (rocBLAS / hipBLASLt kernel loading and heuristics for forward and backward shapes, allocator growth,
+    # first RCCL collectives) and is reported separately; the second is the steady-state wall-clock.
+    first_wall, first_phases, _ = run(search)
     wall, phases, ratio = run(search)
     out = {"config": "configs[1]: BERT-base CoLA twc_fine_gamma W6A6, 256 samples (8 x [32,128]), random-init weights, synthetic ids",
            "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}, "best_percentile": ratio,
+           "first_run_wall_s": round(first_wall, 3), "first_run_phases_s": {k: round(v, 3) for k, v in first_phases.items()},
            "twc_candidates": 30,
            "search": ("cached per-token extrema + 1 re-threshold launch per candidate, sharded over ranks" if search == "cached"
                       else "literal reference order: 2 model passes per candidate"),

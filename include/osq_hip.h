@@ -258,6 +258,20 @@ int osq_observer_update(const float* cur_min, const float* cur_max, int64_t n,
                         int update_rule, int64_t cnt, float* min_val, float* max_val,
                         osq_stream stream);
 
+/* Replay of a whole [n_batches, n_quantizers, 2] table of per-batch (min, max) -- what sharded and cached
+ * calibration gather -- in ONE launch: quantizer q folds rows 0..n_batches-1 into its running statistic with
+ * rules[q] (OSQ_UPDATE_RUNNING / OSQ_UPDATE_AVERAGE, cnt0 = batches seen before row 0; fresh != 0: start from
+ * the untouched (+inf, -inf) state regardless of the buffers), stores it through min_ptrs[q] / max_ptrs[q]
+ * (device addresses of 1-element fp32 buffers), and, where scale_ptrs[q] != 0, writes
+ * calculate_qparams (observer.py:101-119) through scale_ptrs[q] / zp_ptrs[q] (zp_types[q]).  All arrays live
+ * on the device.  Equivalent to n_batches calls of osq_observer_update + n_quantizers of
+ * osq_calculate_qparams. */
+int osq_replay_statistics(const float* table, int n_batches, int n_quantizers, const int32_t* rules,
+                          int64_t cnt0, int fresh, const uint64_t* min_ptrs, const uint64_t* max_ptrs,
+                          const int32_t* quant_min, const int32_t* quant_max, const int32_t* symmetric,
+                          const uint64_t* scale_ptrs, const uint64_t* zp_ptrs, const int32_t* zp_types,
+                          osq_stream stream);
+
 /* ------------------------------------------------------------------ MSEFast (observer.py:412-567) */
 
 /* one_side: 0 = 'no', 1 = 'pos', 2 = 'neg' (observer.py:528-529, decided once by the caller on

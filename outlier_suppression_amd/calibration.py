@@ -69,38 +69,82 @@ class CaptureTable:
             q.observer._capture = None
 
 
-def replay(ordered, quantizers):
-    """Apply the gathered per-batch statistics in batch order with each observer's own rule, then
-    refresh scale / zero_point.  ``ordered``: [n_batches, Q, 2] on the device."""
-    n_batches, n_q = ordered.shape[0], ordered.shape[1]
-    if n_q == 0:
-        return
-    dev = ordered.device
-    by_rule = {}
-    for i, (_, q) in enumerate(quantizers):
-        by_rule.setdefault(q.observer.update_rule, []).append(i)
-    for rule, idx in by_rule.items():
-        sel = torch.tensor(idx, device=dev)
-        obs = [quantizers[i][1].observer for i in idx]
-        mn = torch.stack([o.min_val.reshape(()).to(dev) for o in obs]).contiguous()
-        mx = torch.stack([o.max_val.reshape(()).to(dev) for o in obs]).contiguous()
-        cnts = {getattr(o, "cnt", 0) for o in obs}
+class ReplayPlan:
+    """Device-side description of a set of quantizers for ``osq_replay_statistics``: per-quantizer update rule,
+    quantisation range and the ADDRESSES of its observer's min_val / max_val buffers and of its scale /
+    zero_point storage.  Built once; every replay is then one launch, with no per-quantizer tensor traffic.
+    The tensors behind the addresses are kept alive (and never reallocated) by the plan."""
+
+    def __init__(self, quantizers, device):
+        self.quantizers = quantizers
+        self.device = device
+        obs = [q.observer for _, q in quantizers]
+        for o in obs:
+            o._home(device)
+            if o.min_val.numel() != 1 or o.max_val.numel() != 1:
+                raise NotImplementedError("replay: per-tensor observers only")
+            if o.min_val.dim():                       # 0-dim buffers as the reference registers them
+                o.min_val = o.min_val.reshape(())
+                o.max_val = o.max_val.reshape(())
+        self._keep = []
+        i32 = lambda vals: torch.tensor(list(vals), dtype=torch.int32, device=device)
+        u64 = lambda vals: torch.tensor(list(vals), dtype=torch.int64, device=device)
+        scales, zps = [], []
+        for _, q in quantizers:
+            s, z = q._qparam_storage(device, 1)
+            scales.append(s)
+            zps.append(z)
+        self._keep += [o.min_val for o in obs] + [o.max_val for o in obs] + scales + zps
+        self.rules = i32(o.update_rule for o in obs)
+        self.min_ptrs = u64(o.min_val.data_ptr() for o in obs)
+        self.max_ptrs = u64(o.max_val.data_ptr() for o in obs)
+        self.qmin = i32(q.quant_min for _, q in quantizers)
+        self.qmax = i32(q.quant_max for _, q in quantizers)
+        self.sym = i32(int(bool(q.symmetric)) for _, q in quantizers)
+        self.scale_ptrs = u64(t.data_ptr() for t in scales)
+        self.zp_ptrs = u64(t.data_ptr() for t in zps)
+        self.zp_types = i32(ops._zp_type(t) for t in zps)
+        self._addresses = [(o.min_val.data_ptr(), o.max_val.data_ptr()) for o in obs]
+
+    def valid(self):
+        """False once somebody re-assigned an observer buffer (the plan's addresses would be stale)."""
+        return all((o.min_val.data_ptr(), o.max_val.data_ptr()) == adr
+                   for (_, q), adr in zip(self.quantizers, self._addresses) for o in (q.observer,))
+
+    def run(self, ordered, fresh=False):
+        """Fold ``ordered`` [n_batches, Q, 2] into every observer's running statistic, in batch order, and refresh
+        scale / zero_point.  ``fresh``: start from the untouched (+inf, -inf) state (what the reference gets by
+        ``cnt = 0`` on an observer whose first-batch test then fires, token_wise_clipping.py:17, observer.py:194)."""
+        n_batches, n_q = ordered.shape[0], ordered.shape[1]
+        if n_q == 0:
+            return
+        from . import _hip
+        obs = [q.observer for _, q in self.quantizers]
+        cnts = {0 if fresh else getattr(o, "cnt", 0) for o in obs}
         if len(cnts) != 1:
             raise RuntimeError("replay: observers disagree on their batch counter")
         cnt0 = cnts.pop()
-        cur = ordered.index_select(1, sel)                    # [n_batches, len(idx), 2]
-        for b in range(n_batches):
-            ops.observer_update(cur[b, :, 0].contiguous(), cur[b, :, 1].contiguous(), rule, cnt0 + b, mn, mx)
-        for k, o in enumerate(obs):
-            o.min_val = mn[k].clone()
-            o.max_val = mx[k].clone()
+        table = ordered.contiguous()
+        lib = _hip.load()
+        _hip.check(lib.osq_replay_statistics(table.data_ptr(), int(n_batches), int(n_q), self.rules.data_ptr(), int(cnt0),
+                                             1 if fresh else 0, self.min_ptrs.data_ptr(), self.max_ptrs.data_ptr(),
+                                             self.qmin.data_ptr(), self.qmax.data_ptr(), self.sym.data_ptr(),
+                                             self.scale_ptrs.data_ptr(), self.zp_ptrs.data_ptr(), self.zp_types.data_ptr(),
+                                             _hip.raw_stream(self.device)), "replay_statistics")
+        for o in obs:
             if hasattr(o, "cnt"):
-                o.cnt = cnt0 + n_batches
-    for _, q in quantizers:
-        o = q.observer
-        s, z = q._qparam_storage(dev, 1)
-        ops.calculate_qparams(o.min_val.reshape(1), o.max_val.reshape(1), q.quant_min, q.quant_max, q.symmetric,
-                              scale_out=s, zero_point_out=z)
+                object.__setattr__(o, "cnt", cnt0 + n_batches)
+
+
+def replay(ordered, quantizers, fresh=False, plan=None):
+    """Apply the gathered per-batch statistics in batch order with each observer's own rule, then
+    refresh scale / zero_point.  ``ordered``: [n_batches, Q, 2] on the device.  One launch."""
+    if ordered.shape[1] == 0:
+        return plan
+    if plan is None or not plan.valid():
+        plan = ReplayPlan(quantizers, ordered.device)
+    plan.run(ordered, fresh)
+    return plan
 
 
 @torch.no_grad()

@@ -103,6 +103,48 @@ __global__ void qparams_kernel(const float* __restrict__ mn, const float* __rest
     if (zp_out) store_zp(zp_out, zp_type, i, z);
 }
 
+// Replay of gathered per-batch statistics (sharded / cached calibration): quantizer q applies its update rule
+// to the rows of table[n_batches, n_q, 2] in batch order -- the reference's sequential running statistic,
+// observer.py:143-144 / 194-202 -- and refreshes its (scale, zero_point), all through per-quantizer pointers:
+// one launch instead of n_batches + n_q launches and as many tensor copies.
+struct ReplayArgs {
+    const float* table;
+    int n_batches, n_q;
+    const int32_t* rules;
+    int64_t cnt0;
+    int fresh;                         // 1: start from the untouched (+inf, -inf) state whatever the buffers hold
+    const uint64_t* min_ptrs;
+    const uint64_t* max_ptrs;
+    const int32_t* qmin;
+    const int32_t* qmax;
+    const int32_t* symmetric;
+    const uint64_t* scale_ptrs;
+    const uint64_t* zp_ptrs;
+    const int32_t* zp_types;
+};
+
+__global__ void replay_kernel(ReplayArgs a) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.n_q) return;
+    float* min_p = reinterpret_cast<float*>(a.min_ptrs[q]);
+    float* max_p = reinterpret_cast<float*>(a.max_ptrs[q]);
+    float mn = a.fresh ? __builtin_inff() : *min_p;
+    float mx = a.fresh ? -__builtin_inff() : *max_p;
+    const int rule = a.rules[q];
+    for (int b = 0; b < a.n_batches; ++b) {
+        const float* cur = a.table + (static_cast<int64_t>(b) * a.n_q + q) * 2;
+        apply_update(rule, a.cnt0 + b, cur[0], cur[1], &mn, &mx);
+    }
+    *min_p = mn;
+    *max_p = mx;
+    if (a.scale_ptrs && a.scale_ptrs[q]) {
+        float s, z;
+        qparams_from_range(mn, mx, a.qmin[q], a.qmax[q], a.symmetric[q], &s, &z);
+        *reinterpret_cast<float*>(a.scale_ptrs[q]) = s;
+        if (a.zp_ptrs[q]) store_zp(reinterpret_cast<void*>(a.zp_ptrs[q]), a.zp_types[q], 0, z);
+    }
+}
+
 __global__ void update_kernel(const float* __restrict__ cur_min, const float* __restrict__ cur_max, int64_t n, int rule,
                               int64_t cnt, float* __restrict__ min_val, float* __restrict__ max_val) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1212,6 +1254,23 @@ extern "C" int osq_observer_update(const float* cur_min, const float* cur_max, i
     hipLaunchKernelGGL(update_kernel, dim3(static_cast<unsigned>((n + block - 1) / block)), dim3(block), 0,
                        static_cast<hipStream_t>(stream), cur_min, cur_max, n, update_rule, cnt, min_val, max_val);
     return check_launch("observer_update");
+}
+
+extern "C" int osq_replay_statistics(const float* table, int n_batches, int n_quantizers, const int32_t* rules,
+                                     int64_t cnt0, int fresh, const uint64_t* min_ptrs, const uint64_t* max_ptrs,
+                                     const int32_t* quant_min, const int32_t* quant_max, const int32_t* symmetric,
+                                     const uint64_t* scale_ptrs, const uint64_t* zp_ptrs, const int32_t* zp_types,
+                                     osq_stream stream) {
+    OSQ_REQUIRE(n_batches >= 0 && n_quantizers >= 0, "replay_statistics: negative size");
+    if (n_quantizers == 0) return OSQ_OK;
+    OSQ_REQUIRE(table && rules && min_ptrs && max_ptrs, "replay_statistics: null pointer");
+    OSQ_REQUIRE(!scale_ptrs || (quant_min && quant_max && symmetric && zp_ptrs && zp_types),
+                "replay_statistics: scale pointers need the quantizer descriptions");
+    const ReplayArgs a{table, n_batches, n_quantizers, rules, cnt0, fresh, min_ptrs, max_ptrs, quant_min, quant_max,
+                       symmetric, scale_ptrs, zp_ptrs, zp_types};
+    hipLaunchKernelGGL(replay_kernel, dim3(static_cast<unsigned>((n_quantizers + 127) / 128)), dim3(128), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("replay_statistics");
 }
 
 extern "C" int osq_observe_flat(const float* x, int64_t n,

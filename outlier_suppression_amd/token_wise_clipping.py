@@ -276,20 +276,19 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
         q.observer._token_cache = None
         q.observer._capture = None
 
+    plan = calibration.ReplayPlan(qs, dev)
+
     def apply_ratio(ratio):
         """Statistics of every activation quantizer for this candidate (what calibrate() leaves behind)."""
         for _, q in qs:
-            q.observer.set_percentile(ratio)
-            q.observer.cnt = 0
-            q.observer.min_val = torch.full_like(q.observer.min_val, float("inf"))
-            q.observer.max_val = torch.full_like(q.observer.max_val, float("-inf"))
+            object.__setattr__(q.observer, "percentile", ratio)
         table = flat_table.clone()
         if n_tok:
             ops.token_range_finalize_batched(tok_min, tok_max, n_tok, rows, batch, tokens, lengths, prune_flags, ratio,
                                              cur_tok)
             table.index_copy_(1, col_index, cur_tok)
         ordered = calibration.gather_batch_table(table, n_batches, group)
-        calibration.replay(ordered, qs)
+        plan.run(ordered, fresh=True)       # one launch: running means from scratch + qparams of all quantizers
 
     # ---- per candidate: re-threshold (1 launch) + replay + quantized forward for the loss
     best, best_loss = 0, 10000000

@@ -314,9 +314,13 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
         ordered = calibration.gather_batch_table(table, n_batches, group)
         plan.run(ordered, fresh=True)       # one launch: running means from scratch + qparams of all quantizers
 
-    # ---- per candidate: re-threshold (1 launch) + replay + quantized forward for the loss
-    best, best_loss = 0, 10000000
+    # ---- per candidate: re-threshold (1 launch) + replay (1 launch) + quantized forward for the loss.
+    # Nothing in the loop reads a result back: the per-batch losses of every candidate stay on the device and
+    # are fetched ONCE after the last candidate, so the host keeps enqueueing while the GPU works (a .cpu() per
+    # candidate drained the pipeline 30 times).  The reference's log lines and its fp32 batch-order sum are
+    # produced afterwards from the same numbers.
     loss_rows = torch.zeros(rows, 1, dtype=torch.float32, device=dev)
+    loss_table = torch.zeros(param["iters"], n_batches, dtype=torch.float32, device=dev)
     for it in range(param["iters"]):
         ratio = 1.0 - param["step"] * it
         apply_ratio(ratio)
@@ -326,12 +330,14 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
         with torch.no_grad():
             for j, batch_in in enumerate(fp_input):
                 loss_rows[j, 0] = batch_loss(model(**batch_in), batch_in, fp_output[j])
-        per_batch = calibration.gather_batch_table(loss_rows, n_batches, group).reshape(-1).cpu().numpy()
+        loss_table[it] = calibration.gather_batch_table(loss_rows, n_batches, group).reshape(-1)
+    best, best_loss = 0, 10000000
+    for it, per_batch in enumerate(loss_table.cpu().numpy().astype(np.float32)):
         cur = np.float32(0)
-        for v in per_batch.astype(np.float32):      # the reference adds fp32 losses in batch order
+        for v in per_batch:              # the reference adds fp32 losses in batch order
             cur = np.float32(cur + v)
         cur = float(cur)
-        logger.info("the ratio is {}, the loss is {}".format(ratio, cur))
+        logger.info("the ratio is {}, the loss is {}".format(1.0 - param["step"] * it, cur))
         if best_loss > cur:
             best_loss, best = cur, it
     ratio = 1.0 - param["step"] * best

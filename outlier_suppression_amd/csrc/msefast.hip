@@ -300,8 +300,18 @@ __device__ __forceinline__ void block_sum_publish_finish(double part, double* pa
         publish_f64(&partials[blockIdx.x], a);
     }
     if (grid_last_block(counters, gridDim.x)) {
+        // all loads before any use (consumed one by one, the ordered agent-scope loads cost a memory round
+        // trip per iteration); same lane-strided summation order as a plain loop
+        constexpr int kPer = kMaxBlocks / kThreads;
+        double pa[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned int k = threadIdx.x + j * kThreads;
+            pa[j] = consume_f64(&partials[k < gridDim.x ? k : gridDim.x - 1]);
+        }
         double a = 0.0;
-        for (unsigned int k = threadIdx.x; k < gridDim.x; k += kThreads) a += consume_f64(&partials[k]);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) a += (threadIdx.x + j * kThreads < gridDim.x) ? pa[j] : 0.0;
         a = wave_sum(a);
         __syncthreads();
         if (lane == 0) sh[wv] = a;

@@ -450,6 +450,41 @@ def test_fused_residual_layernorm_fake_quant(dev):
         assert flips.float().mean().item() < 5e-3
 
 
+def test_quantized_operators_forward(eq32, dev):
+    """QLinear / QConv2d / QEmbedding (quantized_module.py:39-100): weight observed per output channel on the
+    first call, fake-quantised on every call, then the stock functional op -- against the oracle's weights."""
+    import torch.nn.functional as F
+    from outlier_suppression_amd.quantization import Quantizer
+    from oracle import observer_oracle as OB, fake_quant_oracle as FQ
+    torch.manual_seed(3)
+    cfg = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    mods = [(torch.nn.Linear(40, 12), torch.randn(5, 40)),
+            (torch.nn.Conv2d(3, 6, 3, padding=1), torch.randn(2, 3, 8, 8)),
+            (torch.nn.Embedding(50, 16, padding_idx=0), torch.randint(0, 50, (4, 7)))]
+    for fp_mod, inp in mods:
+        qm = Quantizer(fp_mod, cfg).to(dev)
+        wq = qm.weight_fake_quant
+        wq.enable_observer()
+        wq.enable_fake_quant()
+        with torch.no_grad():
+            out = qm(inp.to(dev))
+        W = fp_mod.weight.detach().numpy()
+        st = OB.ObserverState(bit=6, symmetric=True, ch_axis=0)
+        OB.observe_minmax(st, W)
+        scale, zp = st.qparams()
+        assert eq32(N(wq.scale), scale) and np.array_equal(N(wq.zero_point), zp)
+        _, Wq = FQ.fake_quantize_per_channel_affine(W, scale, zp, 0, -32, 31)
+        Wq_t = torch.from_numpy(Wq).to(dev)
+        with torch.no_grad():
+            if isinstance(fp_mod, torch.nn.Linear):
+                ref = F.linear(inp.to(dev), Wq_t, fp_mod.bias.to(dev))
+            elif isinstance(fp_mod, torch.nn.Conv2d):
+                ref = F.conv2d(inp.to(dev), Wq_t, fp_mod.bias.to(dev), padding=1)
+            else:
+                ref = F.embedding(inp.to(dev), Wq_t, padding_idx=0)
+        assert torch.equal(out, ref), type(fp_mod).__name__
+
+
 # ----------------------------------------------------------------------------------- full size, properties
 
 def test_full_size_properties(dev):

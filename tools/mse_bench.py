@@ -16,3 +16,14 @@ for sym in (True, False):
     ob(x, L, 1); torch.cuda.synchronize()
     t0 = time.perf_counter(); ob(x, L, 1); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"AvgMSEFast per-tensor 6-bit sym={sym} [32,128,768] masked: {dt*1e3:.2f} ms, nfev {int(ob.last_nfev.sum().item())}")
+from outlier_suppression_amd.quantization.quantized_module import ObserverDict
+for name, kw in (("AvgQuantileObserver", dict(bit=6, symmetric=True)), ("AvgMSEObserver", dict(bit=6, symmetric=False)),
+                 ("MSEObserver", dict(bit=6, symmetric=True)), ("LSQPlusObserver", dict(bit=6, symmetric=True))):
+    ob = ObserverDict[name](**kw).to(dev)
+    args = (x, L, 1) if name != "LSQPlusObserver" else (x,)
+    try:
+        ob(*args); torch.cuda.synchronize()
+        t0 = time.perf_counter(); ob(*args); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"{name} [32,128,768]: {dt*1e3:.2f} ms")
+    except Exception as e:
+        print(name, "failed:", type(e).__name__, e)

@@ -166,6 +166,19 @@ def kernel_table(dev, xs, lengths, reps=20):
             ev.append((e0, e1))
         torch.cuda.synchronize()
         seq_us = sum(a.elapsed_time(b) for a, b in ev[3:]) / reps * 1e3
+        # BASELINE.md section 4 secondary slices: one calibration site of BERT-base at batch 32 (launch-latency regime)
+        for shp, sp in (((32, 128, 768), 1), ((32, 12, 128, 128), 2), ((32, 128, 3072), 1), ((32, 384, 768), 1)):
+            xsite = torch.randn(*shp, device=dev)
+            lsite = torch.randint(8, shp[sp] + 1, (shp[0],), device=dev)
+            vsite = int(lsite.sum().item()) * (xsite.numel() // shp[0] // shp[sp])
+            tag = "x".join(str(d) for d in shp)
+            add(f"site {tag}: fake_quant_forward", timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(
+                xsite, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * xsite.numel())
+            add(f"site {tag}: token_minmax (masked)", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xsite, sp, lsite)), 4 * vsite)
+            tk = ops.token_minmax(xsite, sp, lsite)
+            add(f"site {tag}: token_select p=0.95", timed(_hip.TIME_TOKEN_SELECT, lambda i: ops.token_range_finalize(
+                tk[0], tk[1], tk[2], tk[3], tk[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
+                8 * shp[0] * shp[sp])
         rows["same site, eager sequence (gamma_residual, layer_norm, add, fake_quant)"] = {
             "avg_us": round(seq_us, 2), "algorithmic_MB": round(12 * n / 1e6, 1), "GBps": round(12 * n / seq_us / 1e3, 1),
             "frac_of_8TBps": round(12 * n / seq_us / 1e3 / HBM_PEAK_GBS, 3)}

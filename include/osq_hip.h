@@ -83,8 +83,13 @@ const char* osq_last_error(void);
 int         osq_abi_version(void);
 size_t      osq_workspace_bytes(void);
 
-/* Performance knobs (results never change): "fq_unroll" 2|4|8 independent 16-byte loads per lane,
- * "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 = non-temporal loads/stores of the dense fake-quant. */
+/* Performance / path-selection knobs (results never change):
+ *   "fq_unroll" 2|4|8 independent 16-byte loads per lane, "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 =
+ *   streaming loads/stores of the dense fake-quant; "bwd_blocks" grid cap of the dense LSQ backward;
+ *   "obs_blocks" grid cap of osq_observe_flat (768: power-of-two grids put a thread's strided loads on the
+ *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
+ *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
+ *   threshold pass (the last two exist so that tests can drive every implementation). */
 int osq_set_tuning(const char* key, int value);
 
 /* Measurement aid (bench.py).  The events given to osq_time_next_launch ride on the dispatch packet of the

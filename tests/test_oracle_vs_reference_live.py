@@ -1,0 +1,107 @@
+"""CPU, build container only: the NumPy oracle against the REFERENCE ITSELF on freshly drawn inputs.
+
+The committed goldens (tests/golden/*.npz) pin the oracle on fixed vectors; here the reference's own functions
+and observer classes are imported (two process-local shims: empty ``seaborn`` module, identity ``Tensor.cuda``)
+and run next to the oracle on seeded random cases that no fixture holds -- shapes, bit widths, masks, percentiles,
+one-sided ranges.  Bit-exact on everything.  Skipped where /root/reference is absent (the GPU box).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not available")
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from quant_transformer.quantization import observer, util_quant
+    torch.set_num_threads(1)
+    return observer, util_quant
+
+
+def _bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=F32)).view(np.uint32)
+
+
+def test_fake_quant_random_cases(ref):
+    _, U = ref
+    from oracle import fake_quant_oracle as FQ
+    gen = torch.Generator().manual_seed(20260930)
+    for trial in range(60):
+        bit = int(torch.randint(2, 9, (1,), generator=gen))
+        sym = bool(torch.randint(0, 2, (1,), generator=gen))
+        qmin, qmax = (-(1 << (bit - 1)), (1 << (bit - 1)) - 1) if sym else (0, (1 << bit) - 1)
+        shape = tuple(int(v) for v in torch.randint(1, 9, (int(torch.randint(1, 4, (1,), generator=gen)),), generator=gen))
+        x = torch.randn(*shape, generator=gen) * float(10 ** torch.empty(1).uniform_(-3, 2, generator=gen))
+        scale = float(torch.empty(1).uniform_(1e-4, 2.0, generator=gen))
+        zp = 0 if sym else int(torch.randint(qmin, qmax + 1, (1,), generator=gen))
+        want = U.fake_quantize_per_tensor_affine(x, scale, zp, qmin, qmax)
+        _, got = FQ.fake_quantize_per_tensor_affine(x.numpy(), F32(scale), F32(zp), qmin, qmax)
+        assert np.array_equal(_bits(got), _bits(want.numpy())), (trial, bit, sym, shape)
+        if x.dim() >= 2:
+            C = x.shape[0]
+            s = torch.empty(C).uniform_(1e-3, 1.0, generator=gen)
+            z = torch.zeros(C, dtype=torch.int32) if sym else torch.randint(qmin, qmax + 1, (C,), generator=gen).int()
+            want = U.fake_quantize_per_channel_affine(x, s, z, 0, qmin, qmax)
+            _, got = FQ.fake_quantize_per_channel_affine(x.numpy(), s.numpy(), z.numpy(), 0, qmin, qmax)
+            assert np.array_equal(_bits(got), _bits(want.numpy())), (trial, "per-channel")
+
+
+def test_observers_random_sequences(ref):
+    O, _ = ref
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(77001)
+    table = [("MinMaxObserver", OB.observe_minmax), ("AvgMinMaxObserver", OB.observe_avg_minmax),
+             ("AvgPruneMinMaxObserver", OB.observe_avg_prune_minmax)]
+    for trial in range(45):
+        cls_name, fn = table[trial % 3]
+        bit = int(torch.randint(3, 9, (1,), generator=gen))
+        sym = bool(torch.randint(0, 2, (1,), generator=gen))
+        B, T, H = (int(torch.randint(lo, hi, (1,), generator=gen)) for lo, hi in ((1, 7), (2, 12), (2, 10)))
+        layout = trial % 4
+        ob = getattr(O, cls_name)(bit=bit, symmetric=sym, ch_axis=-1)
+        name = "m.attention_probs_x" if trial % 9 == 8 else "m.x_post_act_fake_quantize"
+        ob.set_name(name)
+        st = OB.ObserverState(bit=bit, symmetric=sym, name=name)
+        pct = float(torch.empty(1).uniform_(0.05, 1.0, generator=gen))
+        if cls_name == "AvgPruneMinMaxObserver":
+            ob.set_percentile(pct)
+            st.percentile = pct
+        for it in range(3):
+            shift = float(torch.empty(1).uniform_(-3, 3, generator=gen)) if trial % 5 == 0 else 0.0
+            if layout == 0:
+                x, sp = torch.randn(B, T, H, generator=gen) + shift, 1
+            elif layout == 1:
+                x, sp = torch.randn(B, 2, T, H, generator=gen) + shift, 2
+            elif layout == 2:
+                x, sp = (torch.randn(B, T, 2, H, generator=gen) + shift).permute(0, 2, 3, 1), 3
+            else:
+                x, sp = torch.randn(B, T, H, generator=gen).abs() + 0.1, 1       # one-sided range
+            L = torch.randint(1, T + 1, (B,), generator=gen)
+            masked = trial % 7 != 6
+            if masked:
+                ob(x, L, sp)
+                fn(st, x.numpy(), L.numpy(), sp)
+            elif cls_name == "AvgPruneMinMaxObserver":
+                ob(x, None, sp)                      # no mask, seq_pos given: reshape_batch_embedding path
+                fn(st, x.numpy(), None, sp)
+            else:
+                ob(x)
+                fn(st, x.numpy())
+            assert np.array_equal(_bits(st.min_val), _bits(ob.min_val.numpy())), (trial, cls_name, it)
+            assert np.array_equal(_bits(st.max_val), _bits(ob.max_val.numpy())), (trial, cls_name, it)
+            s_ref, z_ref = ob.calculate_qparams(ob.min_val, ob.max_val)
+            s_or, z_or = st.qparams()
+            assert np.array_equal(_bits(s_or), _bits(s_ref.numpy())), (trial, "scale")
+            assert np.array_equal(np.asarray(z_or, dtype=np.float64).reshape(-1),
+                                  z_ref.numpy().astype(np.float64).reshape(-1)), (trial, "zero_point")

@@ -105,3 +105,27 @@ def test_observers_random_sequences(ref):
             assert np.array_equal(_bits(s_or), _bits(s_ref.numpy())), (trial, "scale")
             assert np.array_equal(np.asarray(z_or, dtype=np.float64).reshape(-1),
                                   z_ref.numpy().astype(np.float64).reshape(-1)), (trial, "zero_point")
+
+
+def test_lsqplus_forward_backward_random_cases(ref):
+    """util_quant.py:48-55 with autograd against the oracle's closed-form forward / backward."""
+    _, U = ref
+    from oracle import fake_quant_oracle as FQ
+    gen = torch.Generator().manual_seed(424242)
+    for trial in range(40):
+        bit = int(torch.randint(3, 9, (1,), generator=gen))
+        qmin, qmax = 0, (1 << bit) - 1
+        shape = (int(torch.randint(1, 6, (1,), generator=gen)), int(torch.randint(1, 40, (1,), generator=gen)))
+        x = (torch.randn(*shape, generator=gen) * 2).requires_grad_(True)
+        scale = torch.empty(1).uniform_(0.01, 0.5, generator=gen).requires_grad_(True)
+        zp = torch.empty(1).uniform_(qmin, qmax, generator=gen).requires_grad_(True)
+        g = float(FQ.lsqplus_grad_factor(x.numel(), qmax))
+        y = U.fake_quantize_learnableplus_per_tensor_affine_training(x, scale, zp, qmin, qmax, g)
+        gy = torch.randn(*shape, generator=gen)
+        y.backward(gy)
+        _, y_o = FQ.fake_quantize_learnableplus_per_tensor(x.detach().numpy(), F32(scale.item()), F32(zp.item()), qmin, qmax, g)
+        assert np.array_equal(_bits(y_o), _bits(y.detach().numpy())), (trial, "y")
+        dx, ds, dz = FQ.lsqplus_backward_per_tensor(x.detach().numpy(), gy.numpy(), F32(scale.item()), F32(zp.item()), qmin, qmax, g)
+        assert np.array_equal(_bits(dx), _bits(x.grad.numpy())), (trial, "dx")
+        np.testing.assert_allclose(ds, scale.grad.item(), rtol=3e-5, atol=1e-7)
+        np.testing.assert_allclose(dz, zp.grad.item(), rtol=3e-5, atol=1e-7)

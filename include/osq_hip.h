@@ -122,6 +122,15 @@ int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t 
                               int mode, float grad_factor, int quant_min, int quant_max,
                               osq_stream stream);
 
+/* The intermediate-activation site of a transformer block in one pass (model/quant_bert.py:277-280,
+ * quant_bart.py:347-348: fc1 / dense -> GELU -> *_act_fn_post_act_fake_quantize): y = fake_quantize(gelu(x))
+ * with torch's exact (erf) GELU, bit-identical to F.gelu followed by osq_fake_quant_per_tensor.  x, y: n
+ * contiguous fp32, 16-byte aligned (else OSQ_ERR_UNSUPPORTED).  Inference only. */
+int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t n,
+                                   const float* scale, const void* zero_point, int zp_type,
+                                   int mode, float grad_factor, int quant_min, int quant_max,
+                                   osq_stream stream);
+
 /* Same arithmetic for a non-dense tensor of up to 4 dims (e.g. hidden_states[:, 0],
  * quant_bert.py:445): explicit sizes and element strides for input and output. */
 int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,

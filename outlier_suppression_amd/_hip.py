@@ -45,6 +45,7 @@ SIGNATURES = {
     "osq_time_next_launch": (_I, [_I, _P, _P]),
     "osq_timing_elapsed_us": (_I, [_P, _P, ctypes.POINTER(_F)]),
     "osq_fake_quant_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_gelu_fake_quant_per_tensor": (_I, [_P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
                                                _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),

@@ -36,7 +36,15 @@ __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float
 
 // ---------------------------------------------------------------- per-tensor, dense
 
-template <bool WRITE_Q, int UNROLL, int NT>
+// torch's exact GELU (aten GeluCUDAKernelImpl, approximate='none'): x * 0.5 * (1 + erf(x * M_SQRT1_2)), fp32,
+// same operation order; erff is the ocml routine torch's HIP build calls too, so the fused activation is
+// bit-identical to F.gelu on the device (tests/test_gpu_parity.py::test_gelu_fake_quant_fused).
+__device__ __forceinline__ float gelu_erf(float x) {
+    constexpr float kAlpha = 0.70710678118654752440f;
+    return (x * 0.5f) * (1.0f + erff(x * kAlpha));
+}
+
+template <bool WRITE_Q, int UNROLL, int NT, bool GELU = false>
 __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float4* __restrict__ x, float4* __restrict__ y, float4* __restrict__ xq, int64_t n4,
     const float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ xqt, int tail,
@@ -54,19 +62,21 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             float4 o, q;
+            if (GELU) v[u] = make_float4(gelu_erf(v[u].x), gelu_erf(v[u].y), gelu_erf(v[u].z), gelu_erf(v[u].w));
             fq4<WRITE_Q>(v[u], o, q, s, z, qmin, qmax);
             if (NT & 2) store_stream(&y[i + u * stride], o); else y[i + u * stride] = o;
             if (WRITE_Q) { if (NT & 2) store_stream(&xq[i + u * stride], q); else xq[i + u * stride] = q; }
         }
     }
     for (; i < n4; i += stride) {
-        float4 o, q;
-        fq4<WRITE_Q>(x[i], o, q, s, z, qmin, qmax);
+        float4 o, q, v = x[i];
+        if (GELU) v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+        fq4<WRITE_Q>(v, o, q, s, z, qmin, qmax);
         y[i] = o;
         if (WRITE_Q) xq[i] = q;
     }
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) {
-        const float q = quantize_value(xt[threadIdx.x], s, z, qmin, qmax);
+        const float q = quantize_value(GELU ? gelu_erf(xt[threadIdx.x]) : xt[threadIdx.x], s, z, qmin, qmax);
         yt[threadIdx.x] = dequantize_value(q, s, z);
         if (WRITE_Q) xqt[threadIdx.x] = q;
     }
@@ -389,6 +399,30 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
                                zero_point, zp_type, mode, grad_factor, qmin, qmax);
     }
     return check_launch("fake_quant_per_tensor");
+}
+
+/* y = fake_quantize(gelu(x)): the intermediate-activation site of a transformer block
+ * (model/quant_bert.py:277-280: dense -> GELU -> intermediate_act_fn_post_act_fake_quantize) in one pass. */
+extern "C" int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t n,
+                                              const float* scale, const void* zero_point, int zp_type,
+                                              int mode, float grad_factor, int quant_min, int quant_max,
+                                              osq_stream stream) {
+    OSQ_REQUIRE(n >= 0 && (n == 0 || (x && y)) && scale && zero_point, "gelu_fake_quant_per_tensor: null pointer or n < 0");
+    OSQ_REQUIRE((mode & ~(OSQ_PARAM_MODE_MASK | OSQ_PARAM_SANITIZE)) == 0 && (mode & OSQ_PARAM_MODE_MASK) <= OSQ_PARAM_LSQPLUS,
+                "gelu_fake_quant_per_tensor: bad mode");
+    if (n == 0) return OSQ_OK;
+    if (!aligned16(x) || !aligned16(y)) {
+        osq::set_error("gelu_fake_quant_per_tensor: needs 16-byte aligned tensors");
+        return OSQ_ERR_UNSUPPORTED;
+    }
+    const int64_t n4 = n / 4;
+    const int tail = static_cast<int>(n - n4 * 4);
+    const int grid = grid_for(n4 > 0 ? n4 : 1, kThreads * 2, g_fq_max_blocks);
+    hipLaunchKernelGGL((fq_tensor_vec_kernel<false, 2, 3, true>), dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), static_cast<float4*>(nullptr), n4,
+                       x + n4 * 4, y + n4 * 4, static_cast<float*>(nullptr), tail, scale, zero_point, zp_type, mode,
+                       grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max));
+    return check_launch("gelu_fake_quant_per_tensor");
 }
 
 extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm, residual_layernorm
+from ..util_layernorm import GammaResidual, QuantizedLayerNorm, activation_fake_quant, residual_layernorm
 
 
 def shift_tokens_right(input_ids, pad_token_id, decoder_start_token_id):
@@ -158,8 +158,11 @@ class QuantizedBartEncoderLayer(QuantizedModule):
                        self.dropout)
         h = residual_layernorm(self.before_self_attn_layer_norm_residual, self.self_attn_layer_norm, residual, h, observation_mask)
         residual = h
-        h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
-        h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
+        if self.training and self.activation_dropout > 0:
+            h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
+            h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
+        else:
+            h = activation_fake_quant(self.activation_fn, self.fc1_act_fn_post_act_fake_quantize, self.fc1(h), observation_mask)
         h = self._drop(self.fc2(h), self.dropout)
         return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 
@@ -204,8 +207,11 @@ class QuantizedBartDecoderLayer(QuantizedModule):
                            self.dropout)
             h = residual_layernorm(self.before_encoder_attn_layer_norm_residual, self.encoder_attn_layer_norm, residual, h, observation_mask)
         residual = h
-        h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
-        h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
+        if self.training and self.activation_dropout > 0:
+            h = self._drop(self.activation_fn(self.fc1(h)), self.activation_dropout)
+            h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
+        else:
+            h = activation_fake_quant(self.activation_fn, self.fc1_act_fn_post_act_fake_quantize, self.fc1(h), observation_mask)
         h = self._drop(self.fc2(h), self.dropout)
         return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 

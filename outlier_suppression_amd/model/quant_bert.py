@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm, residual_layernorm
+from ..util_layernorm import GammaResidual, QuantizedLayerNorm, activation_fake_quant, residual_layernorm
 
 
 class QuantizedBertEmbeddings(QuantizedModule):
@@ -133,10 +133,9 @@ class QuantizedBertIntermediate(QuantizedModule):
             self.intermediate_act_fn_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def forward(self, hidden_states, observation_mask=None):
-        hidden_states = self.intermediate_act_fn(self.dense(hidden_states))
-        if self.qoutput:
-            hidden_states = self.intermediate_act_fn_post_act_fake_quantize(hidden_states, observation_mask, 1)
-        return hidden_states
+        return activation_fake_quant(self.intermediate_act_fn,
+                                     self.intermediate_act_fn_post_act_fake_quantize if self.qoutput else None,
+                                     self.dense(hidden_states), observation_mask)
 
 
 class QuantizedBertLayer(QuantizedModule):

@@ -674,3 +674,33 @@ def residual_layernorm_fake_quant(x, hidden, gamma, weight, bias, eps, quant=Non
                                                      z_type, int(mode), float(gf), int(qmin), int(qmax),
                                                      _hip.raw_stream(x.device)), "residual_layernorm_fake_quant")
     return y
+
+
+# ---------------------------------------------------------------------------------------
+# GELU + fake-quant in one pass (the intermediate-activation site)
+# ---------------------------------------------------------------------------------------
+
+def is_exact_gelu(fn):
+    """True for the callables HF models use for hidden_act='gelu' (erf form)."""
+    import torch.nn.functional as F
+    if fn is F.gelu:
+        return True
+    if isinstance(fn, torch.nn.GELU):
+        return getattr(fn, "approximate", "none") == "none"
+    inner = getattr(fn, "act", None)            # transformers.activations.GELUActivation(use_gelu_python=False)
+    return type(fn).__name__ == "GELUActivation" and inner is F.gelu
+
+
+def gelu_fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode=PARAM_FIXED, grad_factor=1.0):
+    """fake_quant(F.gelu(x)) in ONE launch; x dense fp32 on the device."""
+    lib = _hip.load()
+    _hip.require_device(x, scale, zero_point)
+    _check_f32(x, scale)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    y = torch.empty_like(x)
+    _hip.check(lib.osq_gelu_fake_quant_per_tensor(x.data_ptr(), y.data_ptr(), x.numel(), scale.data_ptr(),
+                                                  zero_point.data_ptr(), _zp_type(zero_point), int(mode),
+                                                  float(grad_factor), int(quant_min), int(quant_max),
+                                                  _hip.raw_stream(x.device)), "gelu_fake_quant_per_tensor")
+    return y

@@ -131,3 +131,25 @@ class GammaResidual(nn.Module):
         if self.mul_gamma:
             input = input * self.gamma
         return input + hidden_states
+
+
+def activation_fake_quant(act_fn, quantizer, hidden_states, observation_mask=None):
+    """``quantizer(act_fn(hidden_states), observation_mask, 1)`` -- the intermediate-activation site
+    (quant_bert.py:277-280, quant_bart.py:347-348).  With autograd off, an exact GELU and the quantizer in its plain
+    quantising state this is ONE launch (``ops.gelu_fake_quant_per_tensor``: bit-identical to the two-step form,
+    half the traffic on the largest activation of the block); otherwise the two steps."""
+    q = quantizer
+    if (FUSE_LAYERNORM and q is not None and not torch.is_grad_enabled() and q.fake_quant_enabled == 1
+            and q.observer_enabled != 1 and q.ch_axis == -1 and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+            and hidden_states.is_contiguous() and hidden_states.numel() and hidden_states.data_ptr() % 16 == 0
+            and q.scale.is_cuda and ops.is_exact_gelu(act_fn)):
+        mode = q.param_mode
+        if isinstance(q, _LearnableFakeQuantize):
+            mode |= ops.PARAM_SANITIZE
+        gf = q._grad_factor(hidden_states) if q.param_mode != ops.PARAM_FIXED else 1.0
+        return ops.gelu_fake_quant_per_tensor(hidden_states, q.scale.data, q.zero_point.data, q.quant_min, q.quant_max,
+                                              mode, gf)
+    hidden_states = act_fn(hidden_states)
+    if q is not None:
+        hidden_states = q(hidden_states, observation_mask, 1)
+    return hidden_states

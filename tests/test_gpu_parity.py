@@ -485,6 +485,45 @@ def test_quantized_operators_forward(eq32, dev):
         assert torch.equal(out, ref), type(fp_mod).__name__
 
 
+def test_gelu_fake_quant_fused(dev):
+    """One launch for GELU + fake-quant must equal F.gelu followed by the fake-quant launch bit for bit (the GELU is
+    torch's own erf form in the same operation order), for Fixed and LSQ+ parameters, sizes with a scalar tail."""
+    import torch.nn.functional as F
+    from outlier_suppression_amd import ops, util_layernorm as UL
+    from outlier_suppression_amd.quantization import Quantizer
+    gen = torch.Generator().manual_seed(17)
+    s = torch.tensor([0.037], device=dev)
+    for shape in ((32, 128, 3072), (7, 13), (5,), (4, 1024, 4096)[:2]):
+        x = (torch.randn(*shape, generator=gen) * 3).to(dev)
+        x.view(-1)[:3] = torch.tensor([0.0, -0.0, 40.0], device=dev)[: min(3, x.numel())]
+        g = F.gelu(x)
+        for zp, mode, gf in ((torch.tensor([17], dtype=torch.int32, device=dev), ops.PARAM_FIXED, 1.0),
+                             (torch.tensor([16.6], device=dev), ops.PARAM_LSQPLUS, 3e-4)):
+            want = ops.fake_quant_per_tensor(g, s, zp, 0, 63, mode, gf)
+            got = ops.gelu_fake_quant_per_tensor(x, s, zp, 0, 63, mode, gf)
+            assert torch.equal(got, want), (shape, mode)
+    # module-level helper: fused == two-step, also the LSQ+ parameter repair; falls back for other activations
+    from transformers.activations import ACT2FN
+    cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    q = Quantizer(None, cfg).to(dev)
+    q.enable_fake_quant()
+    x = (torch.randn(4, 9, 64, generator=gen) * 2).to(dev)
+    outs = []
+    for fuse in (True, False):
+        UL.FUSE_LAYERNORM = fuse
+        try:
+            q.scale.data.fill_(-0.05)
+            q.zero_point.data.fill_(80.0)
+            with torch.no_grad():
+                outs.append((UL.activation_fake_quant(ACT2FN["gelu"], q, x, None).clone(), q.scale.item(), q.zero_point.item()))
+        finally:
+            UL.FUSE_LAYERNORM = True
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:] and abs(outs[0][1] - 0.05) < 1e-9 and outs[0][2] == 63.0
+    with torch.no_grad():
+        r = UL.activation_fake_quant(torch.relu, q, x, None)
+    assert torch.equal(r, q(torch.relu(x)))
+
+
 # ----------------------------------------------------------------------------------- full size, properties
 
 def test_full_size_properties(dev):

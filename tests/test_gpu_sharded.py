@@ -1,4 +1,4 @@
-"""Sharded calibration end to end with TWO ranks sharing the one test GPU (gloo rendezvous, tables
+"""Sharded calibration end to end with TWO and with FOUR ranks sharing the one test GPU (gloo rendezvous, tables
 staged through the host): each rank observes half of the batches, the per-batch statistics and
 losses are all-gathered and replayed in global batch order -- percentile, per-candidate losses and
 every scale / zero-point must equal the single-process run bit for bit.  On the 8-GPU node the same
@@ -88,9 +88,10 @@ def test_two_ranks_equal_one(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_run, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
     mp.spawn(_run, args=(2, 29731, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_run, args=(4, 29733, str(tmp_path)), nprocs=4, join=True)     # one batch, one sample of every batch per rank
     one = np.load(tmp_path / "w1_r0.npz")
-    for r in (0, 1):
-        two = np.load(tmp_path / f"w2_r{r}.npz")
+    for world, r in ((2, 0), (2, 1), (4, 0), (4, 3)):
+        two = np.load(tmp_path / f"w{world}_r{r}.npz")
         assert float(two["ratio"]) == float(one["ratio"])
         assert np.array_equal(two["losses"], one["losses"])
         assert np.array_equal(two["scale"], one["scale"]) and np.array_equal(two["zp"], one["zp"])
@@ -101,6 +102,9 @@ def test_two_ranks_equal_one(tmp_path):
     l1 = np.load(tmp_path / "learn_w1_r0.npz")
     l2 = [np.load(tmp_path / f"learn_w2_r{r}.npz") for r in (0, 1)]
     assert np.array_equal(l2[0]["scale"], l2[1]["scale"]) and np.array_equal(l2[0]["zp"], l2[1]["zp"])
+    l4 = [np.load(tmp_path / f"learn_w4_r{r}.npz") for r in range(4)]
+    assert all(np.array_equal(l4[0]["scale"], l["scale"]) and np.array_equal(l4[0]["zp"], l["zp"]) for l in l4[1:])
+    np.testing.assert_allclose(l4[0]["scale"], l1["scale"], rtol=5e-5, atol=0)
     assert not np.array_equal(l1["scale"], base["scale"])          # the parameters did move
     np.testing.assert_allclose(l2[0]["scale"], l1["scale"], rtol=2e-5, atol=0)
     np.testing.assert_allclose(l2[0]["zp"], l1["zp"], rtol=2e-5, atol=2e-5)

@@ -125,6 +125,33 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_strided_kernel(
     }
 }
 
+// Same, 16 bytes per lane, for layouts whose innermost axis is contiguous on both sides (sizes[3] % 4 == 0, every
+// other stride a multiple of 4, aligned bases): the head-split views of attention -- [B,h,T,d] seen through
+// [B,T,h,d] memory (model/quant_bert.py:128-150) -- read in 256-byte runs and written densely, so that the
+// fake-quant also delivers the contiguous operand the following batched matmul would otherwise copy out.
+struct Strided4v {
+    unsigned int size1, size2, size3v;      // sizes of axes 1, 2 and axis 3 in float4 units (axis 0 is implied)
+    int64_t xs[3], ys[3];                   // strides of axes 0..2 in float4 units
+};
+
+__global__ __launch_bounds__(kThreads) void fq_tensor_strided_vec_kernel(
+    const float4* __restrict__ x, float4* __restrict__ y, Strided4v d, int64_t n4,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax) {
+    const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
+        const unsigned int iu = static_cast<unsigned int>(i);          // n4 < 2^31 checked by the launcher
+        const unsigned int r2 = iu / d.size3v, c3 = iu - r2 * d.size3v;
+        const unsigned int r1 = r2 / d.size2, c2 = r2 - r1 * d.size2;
+        const unsigned int c0 = r1 / d.size1, c1 = r1 - c0 * d.size1;
+        const float4 v = load_stream(&x[c0 * d.xs[0] + c1 * d.xs[1] + c2 * d.xs[2] + c3]);
+        float4 o, q;
+        fq4<false>(v, o, q, p.scale, p.zp, qmin, qmax);
+        store_stream(&y[c0 * d.ys[0] + c1 * d.ys[1] + c2 * d.ys[2] + c3], o);
+    }
+}
+
 // ---------------------------------------------------------------- per-channel
 
 // [rows = outer*channels, inner] with inner % 4 == 0: one wave walks whole rows, the
@@ -443,6 +470,21 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
     OSQ_REQUIRE(x && y, "fake_quant_per_tensor_strided: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
+    const bool vec = !x_quant && x_strides[3] == 1 && y_strides[3] == 1 && sizes[3] % 4 == 0 && aligned16(x) && aligned16(y) &&
+                     n / 4 < (1ll << 31) && sizes[1] < (1ll << 31) && sizes[2] < (1ll << 31) &&
+                     x_strides[0] % 4 == 0 && x_strides[1] % 4 == 0 && x_strides[2] % 4 == 0 &&
+                     y_strides[0] % 4 == 0 && y_strides[1] % 4 == 0 && y_strides[2] % 4 == 0;
+    if (vec) {
+        Strided4v dv;
+        dv.size1 = static_cast<unsigned int>(sizes[1]);
+        dv.size2 = static_cast<unsigned int>(sizes[2]);
+        dv.size3v = static_cast<unsigned int>(sizes[3] / 4);
+        for (int k = 0; k < 3; ++k) { dv.xs[k] = x_strides[k] / 4; dv.ys[k] = y_strides[k] / 4; }
+        const int vgrid = grid_for(n / 4, kThreads, g_fq_max_blocks);
+        hipLaunchKernelGGL(fq_tensor_strided_vec_kernel, dim3(vgrid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<float4*>(y), dv, n / 4, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        return check_launch("fake_quant_per_tensor_strided(vec)");
+    }
     const int grid = grid_for(n, kThreads, kMaxBlocks);
     if (x_quant)
         hipLaunchKernelGGL(fq_tensor_strided_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, d, n, scale,

@@ -64,6 +64,19 @@ def fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode=PARAM
     _hip.require_device(x, scale, zero_point)
     _check_f32(x, scale)
     st = _hip.stream_ptr(x.device)
+    if (x.dim() == 4 and not return_quantized and not x.is_contiguous() and x.numel()
+            and (x.stride(-1) == 1 or x.stride(-2) == 1)):
+        # Head-split views of attention ([B,h,T,d] / [B,h,d,T] seen through [B,T,h,d] memory): quantise into the
+        # layout the batched matmul that follows wants -- contiguous, or the transpose of a contiguous tensor for the
+        # key -- instead of x's own strides, which torch.matmul would first copy out (reshape of a permuted view).
+        xt = x if x.stride(-1) == 1 else x.transpose(-1, -2)
+        if xt.shape[-1] % 4 == 0 and all(sv % 4 == 0 for sv in xt.stride()[:3]) and xt.data_ptr() % 16 == 0:
+            yt = torch.empty(xt.shape, dtype=x.dtype, device=x.device)
+            _hip.check(lib.osq_fake_quant_per_tensor_strided(
+                xt.data_ptr(), yt.data_ptr(), None, _i64x4(xt.shape), _pad4_strides(xt), _pad4_strides(yt),
+                _hip.ptr(scale), _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                int(quant_min), int(quant_max), st), "fake_quant_per_tensor_strided")
+            return yt if xt is x else yt.transpose(-1, -2)
     if is_dense(x):
         y = torch.empty_like(x)
         xq = torch.empty_like(x) if return_quantized else None

@@ -72,6 +72,23 @@ def test_per_tensor_layouts(eq32, dev):
         assert y.shape == xv.shape
         _, want = FQ.fake_quantize_per_tensor_affine(view(base).numpy(), F32(0.11), 29, 0, 63)
         assert eq32(N(y), want)
+    # head-split views come back in the layout the following batched matmul wants: contiguous, or (key) the
+    # transpose of a contiguous tensor -- so torch.matmul does not have to copy them out first
+    big = (torch.randn(8, 32, 12, 64, generator=gen) * 3).to(dev)
+    q_view = big.permute(0, 2, 1, 3)                       # [B, h, T, d] through [B, T, h, d] memory
+    yq = ops.fake_quant_per_tensor(q_view, s, z, 0, 63)
+    assert yq.is_contiguous()
+    yk = ops.fake_quant_per_tensor(q_view.transpose(-1, -2), s, z, 0, 63)
+    assert yk.shape == (8, 12, 64, 32) and yk.transpose(-1, -2).is_contiguous()
+    _, want = FQ.fake_quantize_per_tensor_affine(q_view.cpu().numpy(), F32(0.11), 29, 0, 63)
+    assert eq32(N(yq), want) and eq32(N(yk.transpose(-1, -2)), want)
+    # under autograd the gradient still comes back in x's own layout
+    xg = q_view.clone().requires_grad_(True)
+    sp = torch.nn.Parameter(torch.tensor([0.11], device=dev))
+    zp = torch.nn.Parameter(torch.tensor([29.0], device=dev))
+    out = ops.fake_quant(xg.transpose(-1, -2), sp, zp, -1, 0, 63, ops.PARAM_LSQPLUS, 1e-3)
+    out.backward(torch.ones_like(out))
+    assert xg.grad.shape == xg.shape and torch.isfinite(xg.grad).all() and sp.grad is not None
 
 
 def test_per_channel_golden(golden, eq32, dev):

@@ -290,8 +290,9 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)     # 2000 x 63 us = 126 ms: a host hiccup of a few ms no longer shows
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--buffers", type=int, default=4, help="distinct input tensors cycled through (4 x 96 MiB > 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -336,6 +337,15 @@ def main():
         return q(xs[i % len(xs)], lengths, 1)
 
     with torch.no_grad():
+        # settle (untimed, before the W warm-up steps): on a freshly started box the first seconds of any Python process
+        # are slowed by the image still paging in, and the GPU clocks ramp; the loop is host-sensitive (33 us of host
+        # work against 63 us of GPU work per step)
+        t_settle = time.perf_counter()
+        i = 0
+        while time.perf_counter() - t_settle < args.settle:
+            step(i)
+            i += 1
+        torch.cuda.synchronize()
         for i in range(args.warmup):
             step(i)
     # per-batch statistics table for the sharded-calibration exchange (N > 1)
@@ -359,6 +369,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()
+    gc.disable()                               # no collector pauses inside the timed region
     barrier()
     t0 = time.perf_counter()
     with torch.no_grad():                      # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
@@ -376,6 +389,7 @@ def main():
         calibration.gather_batch_table(table, args.steps * world)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     del y
     if world > 1:
         t = torch.tensor([dt], device=dev)

@@ -11,7 +11,7 @@ tag=${1:-r01}
 out=$PWD/gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-cmd="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-calib --no-kernel-table"
+cmd="python bench.py --steps 50 --warmup 10 --settle 0 --no-cpu-baseline --no-calib --no-kernel-table"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o r -- $cmd > "$out/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $cmd > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $cmd > "$out/pmc_write.log" 2>&1

@@ -42,7 +42,7 @@ def pmc_rows(db, counter):
 def main(out, tag):
     stats, avg_us = kernel_table(find_db(os.path.join(out, "trace")))
     open(os.path.join(out, f"{tag}_bench_kernel_stats.md"), "w").write(
-        f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-calib\n\n" + stats)
+        f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --settle 0 --no-cpu-baseline --no-calib --no-kernel-table\n\n" + stats)
     fetch = pmc_rows(find_db(os.path.join(out, "pmc_fetch")), "FETCH_SIZE")
     write = pmc_rows(find_db(os.path.join(out, "pmc_write")), "WRITE_SIZE")
     lines = [f"# {tag} PMC counters (rocprofv3 --pmc, separate passes), bench.py [256,128,768]", "",

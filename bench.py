@@ -377,10 +377,10 @@ def main():
     with torch.no_grad():                      # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
         for i in range(args.steps):
             x = xs[i % len(xs)]
-            # same three launches as q(x, lengths, 1); split here only to hang the timing events on the dominant kernel
-            q._observe(x, lengths, 1)
+            # the module call itself: three launches behind one call of the binding; the timing events ride on the
+            # fake-quant dispatch (the hook is consumed inside the library)
             lib.osq_time_next_launch(_hip.TIME_FAKE_QUANT, *pairs[i])
-            y = q._quantize(x)
+            y = q(x, lengths, 1)
     host_dt = time.perf_counter() - t0         # enqueue time: if this is close to dt the loop is host-bound
     if world > 1:
         # the path's one real exchange: per-batch statistics, gathered once and replayed in batch order

@@ -247,6 +247,19 @@ int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t
                        float* scale_out, void* zero_point_out, int zp_type,
                        void* workspace, void* list_scratch, osq_stream stream);
 
+/* QuantizeBase.forward with observer AND fake-quant enabled (the calibrate-and-quantize state,
+ * state.py:22-38; fake_quant.py:107-126 / 178-208) on a masked per-tensor activation, behind one call of the
+ * host binding: osq_observe_tokens writing (scale, zero_point), then osq_fake_quant_per_tensor of the same
+ * dense x[n] into y with those parameters.  Three launches, no host sync. */
+int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,
+                                  float* token_min, float* token_max,
+                                  int prune, double percentile,
+                                  int update_rule, int64_t cnt, float* min_val, float* max_val,
+                                  int quant_min, int quant_max, int symmetric,
+                                  float* scale, void* zero_point, int zp_type,
+                                  float* y, int64_t n, int mode, float grad_factor,
+                                  void* workspace, void* list_scratch, osq_stream stream);
+
 int osq_set_wide_min_slots(int64_t slots);
 
 /* Grid-search form of the same step (token_wise_clipping.py:50-66 calls the observer pass once per

@@ -58,6 +58,8 @@ SIGNATURES = {
     "osq_token_minmax": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
     "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I,
+                                           _P, _L, _I, _F, _P, _P, _P]),
     "osq_set_wide_min_slots": (_I, [_L]),
     "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _P, _D, _P, _P, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),

@@ -1422,6 +1422,27 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
                                     scale_out, zero_point_out, zp_type, workspace, list_scratch, stream);
 }
 
+// A whole quantizer call in the calibrate-and-quantize state (fake_quant.py:107-126 / 178-208 with both flags on)
+// for a masked per-tensor activation: observe (two launches) then fake-quant with the refreshed parameters.
+extern "C" int osq_fake_quant_per_tensor(const float*, float*, float*, int64_t, const float*, const void*, int, int, float,
+                                         int, int, osq_stream);
+extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,
+                                             float* token_min, float* token_max,
+                                             int prune, double percentile,
+                                             int update_rule, int64_t cnt, float* min_val, float* max_val,
+                                             int quant_min, int quant_max, int symmetric,
+                                             float* scale, void* zero_point, int zp_type,
+                                             float* y, int64_t n, int mode, float grad_factor,
+                                             void* workspace, void* list_scratch, osq_stream stream) {
+    OSQ_REQUIRE(scale && zero_point && y, "observe_tokens_fake_quant: null pointer");
+    const int rc = osq_observe_tokens(x, view, lengths, token_min, token_max, prune, percentile, update_rule, cnt, min_val,
+                                      max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type, workspace,
+                                      list_scratch, stream);
+    if (rc != OSQ_OK) return rc;
+    return osq_fake_quant_per_tensor(x, y, nullptr, n, scale, zero_point, zp_type, mode, grad_factor, quant_min, quant_max,
+                                     stream);
+}
+
 extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,
                                                 int n_quantizers, int n_batches, int64_t batch, int64_t tokens,
                                                 const int64_t* lengths, const int32_t* prune_flags, double percentile,

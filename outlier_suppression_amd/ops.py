@@ -421,6 +421,29 @@ def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, m
     return view.batch, view.tokens, lengths
 
 
+def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, max_val, quant_min, quant_max,
+                              symmetric, scale, zero_point, mode, grad_factor):
+    """A whole quantizer call (observe the masked activation, refresh scale / zero_point, fake-quantise) behind ONE
+    call of the binding.  x: dense fp32 on the device.  Returns (y, batch, tokens, lengths_int64)."""
+    lib = _hip._lib or _hip.load()
+    if lengths.dtype != torch.int64:
+        lengths = lengths.to(torch.int64)
+    view = token_view(x, seq_pos, lengths.numel())
+    dev = x.device
+    n = view.batch * view.tokens
+    tmin, tmax, lst = _scratch(dev, n)
+    y = torch.empty_like(x)
+    rc = lib.osq_observe_tokens_fake_quant(x.data_ptr(), ctypes.byref(view), lengths.data_ptr(), tmin.data_ptr(), tmax.data_ptr(),
+                                           1 if prune else 0, float(percentile) if prune else 1.0, rule, cnt,
+                                           min_val.data_ptr(), max_val.data_ptr(), quant_min, quant_max, 1 if symmetric else 0,
+                                           scale.data_ptr(), zero_point.data_ptr(), _zp_type(zero_point), y.data_ptr(), x.numel(),
+                                           mode, grad_factor, _hip.workspace(dev).data_ptr(),
+                                           lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))
+    if rc != 0:
+        _hip.check(rc, "observe_tokens_fake_quant")
+    return y, view.batch, view.tokens, lengths
+
+
 def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, batch, tokens, lengths, prune_flags,
                                  percentile, cur_table):
     """Re-threshold the cached per-token extrema of every (quantizer, batch) pair in ONE launch.

@@ -87,6 +87,30 @@ class QuantizeBase(nn.Module):
             ops.calculate_qparams(obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric,
                                   scale_out=scale, zero_point_out=zero_point)
 
+    def _observe_and_quantize(self, X, observation_mask, seq_pos):
+        """Both flags on, masked per-tensor activation, no gradient wanted: the whole call (per-token extrema, range
+        selection, running statistic, qparams, fake-quant) is ONE call of the binding.  Returns None when the
+        general two-step path has to run."""
+        obs = self.observer
+        if (observation_mask is None or self.ch_axis != -1 or not X.is_cuda or X.dtype != torch.float32
+                or not X.is_contiguous() or X.numel() == 0 or X.dim() not in (3, 4)
+                or getattr(obs, "_capture", True) is not None or obs._token_cache is not None or obs.ch_axis != -1):
+            return None
+        if torch.is_grad_enabled() and (X.requires_grad or self.scale.requires_grad):
+            return None
+        prune = obs.token_path_prune()
+        if prune is None:
+            return None
+        scale, zero_point = self._qparam_storage(X.device, 1)
+        obs._home(X.device)
+        gf = self._grad_factor(X) if self.param_mode != PARAM_FIXED else 1.0
+        y, batch, tokens, lengths = ops.observe_tokens_fake_quant(
+            X, seq_pos, observation_mask, prune, getattr(obs, "percentile", 1.0), obs.update_rule, obs._counter(),
+            obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric, scale, zero_point, self.param_mode, gf)
+        object.__setattr__(obs, "_last_site", ("tokens", batch, tokens, lengths))
+        obs._bump()
+        return y
+
     def _grad_factor(self, X):
         """fake_quant.py:157-166 / 195-204."""
         if not getattr(self, "use_grad_scaling", False):
@@ -141,6 +165,10 @@ class FixedFakeQuantize(QuantizeBase):
         self.register_buffer("zero_point", torch.tensor([0], dtype=torch.int))
 
     def forward(self, X, observation_mask=None, seq_pos=-1):
+        if self.observer_enabled == 1 and self.fake_quant_enabled == 1:
+            y = self._observe_and_quantize(X, observation_mask, seq_pos)
+            if y is not None:
+                return y
         if self.observer_enabled == 1:
             self._observe(X, observation_mask, seq_pos)
         if self.fake_quant_enabled == 1:
@@ -166,6 +194,10 @@ class _LearnableFakeQuantize(QuantizeBase):
 
     def forward(self, X, observation_mask=None, seq_pos=-1):
         flags = 0
+        if self.observer_enabled == 1 and self.fake_quant_enabled == 1:
+            y = self._observe_and_quantize(X, observation_mask, seq_pos)
+            if y is not None:
+                return y
         if self.observer_enabled == 1:
             self._observe(X, observation_mask, seq_pos)
         elif self.fake_quant_enabled == 1 and self.ch_axis == -1 and self.scale.is_cuda and X.numel() > 0:

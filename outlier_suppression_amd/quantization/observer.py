@@ -87,6 +87,10 @@ class ObserverBase(nn.Module):
                                                     self.quant_min, self.quant_max, self.symmetric, sink, cur)
         object.__setattr__(self, "_last_site", ("tokens", batch, tokens, lengths))
 
+    def token_path_prune(self):
+        """None if this observer's masked-activation path is not the standard per-token one; else whether it prunes."""
+        return None
+
     def _observe_flat(self, x, sink):
         object.__setattr__(self, "_last_site", ("flat",))
         self._home(x.device)
@@ -116,6 +120,9 @@ class ObserverBase(nn.Module):
 class MinMaxObserver(ObserverBase):
     """observer.py:122-145: running min / max over the calibration set; per-tensor or per-channel."""
 
+    def token_path_prune(self):
+        return False
+
     def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
         if observation_mask is not None:
             assert self.ch_axis == -1
@@ -134,6 +141,9 @@ class AvgMinMaxObserver(ObserverBase):
     def __init__(self, bit=8, symmetric=False, ch_axis=-1):
         super().__init__(bit=bit, symmetric=symmetric, ch_axis=ch_axis)
         self.cnt = 0
+
+    def token_path_prune(self):
+        return False
 
     def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
         assert self.ch_axis == -1
@@ -163,6 +173,9 @@ class AvgPruneMinMaxObserver(ObserverBase):
             raise AttributeError("AvgPruneMinMaxObserver: call set_percentile() before observing "
                                  "(token_wise_clipping.set_ratio does)")
         return True
+
+    def token_path_prune(self):
+        return self._prunes()
 
     def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
         assert self.ch_axis == -1

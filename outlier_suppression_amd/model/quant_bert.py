@@ -74,9 +74,16 @@ class QuantizedBertSelfAttention(QuantizedModule):
         v = self._heads(self.value(hidden_states))
         q = self.query_permute_post_act_fake_quantize(q, observation_mask, 2)
         kt = self.key_transpose_post_act_fake_quantize(k.transpose(-1, -2), observation_mask, 3)
-        scores = torch.matmul(q, kt) / math.sqrt(self.attention_head_size)
-        if attention_mask is not None:
-            scores = scores + attention_mask
+        scores = torch.matmul(q, kt)
+        root = math.sqrt(self.attention_head_size)
+        if attention_mask is not None and root == 2.0 ** round(math.log2(root)) and not torch.is_grad_enabled():
+            # head sizes 16 / 64 / 256: dividing by sqrt(d) is an exact multiplication by a power of two, so
+            # mask + scores * (1/sqrt(d)) in ONE stock kernel has the bits of the reference's two (quant_bert.py:172-176)
+            scores = torch.add(attention_mask, scores, alpha=1.0 / root)
+        else:
+            scores = scores / root
+            if attention_mask is not None:
+                scores = scores + attention_mask
         probs = self.dropout(nn.functional.softmax(scores, dim=-1))
         probs = self.attention_probs_post_act_fake_quantize(probs, observation_mask, 2)
         v = self.value_permute_post_act_fake_quantize(v, observation_mask, 2)

@@ -103,7 +103,8 @@ typedef enum osq_timed_kernel {
     OSQ_TIME_OBSERVE_FLAT = 3,   /* osq_observe_flat (aligned input)                     */
     OSQ_TIME_TOKEN_MINMAX = 4,   /* osq_token_minmax / first launch of osq_observe_tokens */
     OSQ_TIME_TOKEN_SELECT = 5,   /* two-workgroup launch of osq_token_range_finalize      */
-    OSQ_TIME_LAYERNORM = 6       /* osq_residual_layernorm_fake_quant                     */
+    OSQ_TIME_LAYERNORM = 6,      /* osq_residual_layernorm_fake_quant                     */
+    OSQ_TIME_FUSED_STEP = 7      /* one-launch form of osq_observe_tokens_fake_quant      */
 } osq_timed_kernel;
 int osq_timing_events_create(void** start, void** stop);
 int osq_timing_events_destroy(void* start, void* stop);
@@ -250,7 +251,12 @@ int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t
 /* QuantizeBase.forward with observer AND fake-quant enabled (the calibrate-and-quantize state,
  * state.py:22-38; fake_quant.py:107-126 / 178-208) on a masked per-tensor activation, behind one call of the
  * host binding: osq_observe_tokens writing (scale, zero_point), then osq_fake_quant_per_tensor of the same
- * dense x[n] into y with those parameters.  Three launches, no host sync. */
+ * dense x[n] into y with those parameters.  No host sync.  A dense row-major [batch, tokens, features] view
+ * with features a multiple of 256 (768, 1024, 3072, 4096), batch <= 1024 and 16-byte aligned buffers runs as ONE
+ * persistent launch that keeps the tensor in registers between the reduction and the quantisation (x read from
+ * HBM once, fused_step.h; token_min / token_max then hold the extrema in valid-token order); anything else, or
+ * osq_set_tuning("fused_step", 0), is three launches.  osq_fused_step_status reads (and clears) the sticky
+ * time-out flags of the one-launch form: 0 = every launch on this workspace completed normally. */
 int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,
                                   float* token_min, float* token_max,
                                   int prune, double percentile,
@@ -259,6 +265,8 @@ int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, co
                                   float* scale, void* zero_point, int zp_type,
                                   float* y, int64_t n, int mode, float grad_factor,
                                   void* workspace, void* list_scratch, osq_stream stream);
+
+int osq_fused_step_status(void* workspace, int* status_out, osq_stream stream);
 
 int osq_set_wide_min_slots(int64_t slots);
 

@@ -18,7 +18,7 @@ ZP_INT32, ZP_FLOAT32 = 0, 1
 PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
 PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
-TIME_LAYERNORM = 6
+TIME_LAYERNORM, TIME_FUSED_STEP = 6, 7
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 
 _P = ctypes.c_void_p
@@ -60,6 +60,7 @@ SIGNATURES = {
     "osq_observe_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I,
                                            _P, _L, _I, _F, _P, _P, _P]),
+    "osq_fused_step_status": (_I, [_P, ctypes.POINTER(_I), _P]),
     "osq_set_wide_min_slots": (_I, [_L]),
     "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _P, _D, _P, _P, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),

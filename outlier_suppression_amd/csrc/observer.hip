@@ -771,6 +771,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 }  // namespace osq
 
 #include "token_select.h"   // two-workgroup fast path (one per side), used whenever its layout rules hold
+#include "fused_step.h"     // one persistent launch for observe + fake-quant of a dense [B, T, H] activation
 
 namespace osq {
 
@@ -801,6 +802,9 @@ static int g_obs_blocks = 768;
 static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
+static int g_fused_step = 1;          // osq_set_tuning("fused_step", 0): observe + fake-quant as three launches
+static int g_fused_gate = 1;          // osq_set_tuning("fused_gate", 0): padded tokens are loaded without waiting for the last arrival
+static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
 constexpr int kCoarseShift = 20;
@@ -1206,6 +1210,9 @@ static inline bool select_fast_ok(const float* tmin, const float* tmax, int64_t 
 bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
+    if (k == "fused_step") { g_fused_step = value != 0; return true; }
+    if (k == "fused_gate") { g_fused_gate = value != 0; return true; }
+    if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
@@ -1423,9 +1430,47 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
 }
 
 // A whole quantizer call in the calibrate-and-quantize state (fake_quant.py:107-126 / 178-208 with both flags on)
-// for a masked per-tensor activation: observe (two launches) then fake-quant with the refreshed parameters.
+// for a masked per-tensor activation.  Dense [B, T, H] rows: ONE persistent launch (fused_step.h); otherwise
+// observe (two launches) then fake-quant with the refreshed parameters.
 extern "C" int osq_fake_quant_per_tensor(const float*, float*, float*, int64_t, const float*, const void*, int, int, float,
                                          int, int, osq_stream);
+
+namespace osq {
+
+// Workgroups that can be resident together: the fused kernel spins across workgroups, so the grid must not
+// exceed what the device holds at once.  One 1024-thread workgroup per CU (its 16 waves own the CU's register file).
+static int fused_grid_for(const void* kernel) {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev] = n > 0 ? n : -1;
+    }
+    if (cus[dev] < 3) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFusedThreads, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int grid = cus[dev];
+    if (g_fused_grid >= 3 && g_fused_grid < grid) grid = g_fused_grid;
+    return grid;
+}
+
+template <int NV>
+static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) {
+    static int grid = -1;       // per process; devices of one node are identical
+    if (grid < 0 || g_fused_grid) grid = fused_grid_for(reinterpret_cast<const void*>(&observe_fq_fused_kernel<NV>));
+    if (grid < 3) return false;
+    const TimingHook th = take_timing_hook(OSQ_TIME_FUSED_STEP);
+    hipExtLaunchKernelGGL(observe_fq_fused_kernel<NV>, dim3(grid), dim3(kFusedThreads), 0, st, th.start, th.stop, 0, a, fin);
+    return true;
+}
+
+}  // namespace osq
+
 extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,
                                              float* token_min, float* token_max,
                                              int prune, double percentile,
@@ -1434,13 +1479,53 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
                                              float* scale, void* zero_point, int zp_type,
                                              float* y, int64_t n, int mode, float grad_factor,
                                              void* workspace, void* list_scratch, osq_stream stream) {
-    OSQ_REQUIRE(scale && zero_point && y, "observe_tokens_fake_quant: null pointer");
+    OSQ_REQUIRE(x && view && scale && zero_point && y, "observe_tokens_fake_quant: null pointer");
+    const osq_token_view v = *view;
+    const int64_t slots = v.batch * v.tokens;
+    const bool dense_rows = v.feat_outer == 1 && v.stride_inner == 1 && v.stride_token == v.feat_inner &&
+                            v.stride_batch == v.tokens * v.feat_inner && n == slots * v.feat_inner;
+    const int64_t nv = v.feat_inner / 256;
+    if (g_fused_step && workspace && token_min && token_max && dense_rows && v.feat_inner % 256 == 0 &&
+        (nv == 3 || nv == 4 || nv == 12 || nv == 16) && v.batch >= 1 && v.batch <= kFusedMaxBatch && v.tokens >= 1 &&
+        (slots & 3) == 0 && slots <= 4 * 8 * kSelThreads && n * 4 < (1ll << 32) && aligned16(x) && aligned16(y) && aligned16(token_min) && aligned16(token_max)) {
+        const char* why = "";
+        OSQ_REQUIRE(!prune || (percentile >= 0.0 && percentile <= 1.0), "observe_tokens_fake_quant: percentile outside [0, 1]");
+        OSQ_REQUIRE(check_finish_args(update_rule, min_val, max_val, &why), why);
+        OSQ_REQUIRE(quant_max > quant_min, "observe_tokens_fake_quant: quant_max must exceed quant_min");
+        const Finish fin{update_rule, cnt, min_val, max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
+        const FusedArgs a{x, y, v.batch, v.tokens, lengths, token_min, token_max, prune, static_cast<float>(percentile),
+                          g_select_shortcut, static_cast<FusedState*>(Workspace(workspace).fused()), scale, zero_point,
+                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate};
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        bool launched = false;
+        switch (nv) {
+            case 3: launched = launch_fused<3>(st, a, fin); break;
+            case 4: launched = launch_fused<4>(st, a, fin); break;
+            case 12: launched = launch_fused<12>(st, a, fin); break;
+            default: launched = launch_fused<16>(st, a, fin); break;
+        }
+        if (launched) return check_launch("observe_tokens_fake_quant(fused)");
+    }
     const int rc = osq_observe_tokens(x, view, lengths, token_min, token_max, prune, percentile, update_rule, cnt, min_val,
                                       max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type, workspace,
                                       list_scratch, stream);
     if (rc != OSQ_OK) return rc;
     return osq_fake_quant_per_tensor(x, y, nullptr, n, scale, zero_point, zp_type, mode, grad_factor, quant_min, quant_max,
                                      stream);
+}
+
+extern "C" int osq_fused_step_status(void* workspace, int* status_out, osq_stream stream) {
+    OSQ_REQUIRE(workspace && status_out, "fused_step_status: null pointer");
+    FusedState* fs = static_cast<FusedState*>(Workspace(workspace).fused());
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned int v = 0u;
+    if (hipMemcpyAsync(&v, &fs->status, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemsetAsync(&fs->status, 0, sizeof(v), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("fused_step_status: copy failed");
+        return OSQ_ERR_HIP;
+    }
+    *status_out = static_cast<int>(v);
+    return OSQ_OK;
 }
 
 extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,

@@ -84,6 +84,18 @@ __device__ __forceinline__ float quantize_value(float x, float scale, float zp, 
 // util_quant.py:14
 __device__ __forceinline__ float dequantize_value(float q, float scale, float zp) { return (q - zp) * scale; }
 
+// four elements of the scale-clip-round-dequant chain (util_quant.py:12-14)
+__device__ __forceinline__ void fq4_plain(const float4& v, float4& y, float4& q, float s, float z, float qmin, float qmax) {
+    q.x = quantize_value(v.x, s, z, qmin, qmax);
+    q.y = quantize_value(v.y, s, z, qmin, qmax);
+    q.z = quantize_value(v.z, s, z, qmin, qmax);
+    q.w = quantize_value(v.w, s, z, qmin, qmax);
+    y.x = dequantize_value(q.x, s, z);
+    y.y = dequantize_value(q.y, s, z);
+    y.z = dequantize_value(q.z, s, z);
+    y.w = dequantize_value(q.w, s, z);
+}
+
 // observer.py:101-119 for one entry (fp32)
 __device__ __forceinline__ void qparams_from_range(float mn, float mx, int quant_min, int quant_max, int symmetric,
                                                    float* scale_out, float* zp_out) {

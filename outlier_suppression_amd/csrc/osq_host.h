@@ -13,6 +13,7 @@ constexpr size_t kWsHeaderBytes = 4096;   // ticket counters, one 64-byte line e
 constexpr size_t kWsScratchBytes = 64 * 1024;
 constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
 constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of token_select_kernel (8 B per problem)
+constexpr size_t kWsFusedBytes = 1024;               // FusedState of the one-launch observe + fake-quant (fused_step.h)
 
 void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
@@ -43,7 +44,8 @@ static inline int check_launch(const char* what) {
     return OSQ_OK;
 }
 
-// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state][64 KiB rendezvous words].  Counters are zero between
+// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state][64 KiB rendezvous words]
+// [1 KiB state of the fused observe + fake-quant launch].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
@@ -55,6 +57,7 @@ struct Workspace {
     unsigned long long* meet() const {
         return reinterpret_cast<unsigned long long*>(base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes);
     }
+    void* fused() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes; }
 };
 
 }  // namespace osq

@@ -39,7 +39,7 @@ struct SelectArgs {
 };
 
 #ifdef OSQ_FINAL_TIMING
-#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && fin.cur) reinterpret_cast<long long*>(fin.cur + 2)[k] = __builtin_readcyclecounter(); } while (0)
+#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0 && stamps) stamps[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define OSQ_SSTAMP(k) do { } while (0)
 #endif
@@ -49,57 +49,68 @@ struct SelectArgs {
 // (validity as one compare against a per-group count, NaN poisoning as one select, range through
 // float min/max of |v| with source modifiers, the NaN flag as a scalar lane-mask OR).
 // R4 = 16-byte groups per thread; group g = tid + 1024*j covers slots 4g .. 4g+3.
-template <int R4>
-__global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a, Finish fin, FinalBatch fb) {
+//
+// select_side: one side's statistic, computed by the calling 1024-thread workgroup (every thread gets the
+// result).  COMPACT = false: slots b*T + t, valid iff t < lengths[b] (plain loads: the arrays were written by an
+// earlier launch).  COMPACT = true: the first `compact_n` slots of the array are the valid ones (the fused
+// observe + fake-quant launch writes per-token extrema in valid-token order) and the loads are sc1 buffer loads,
+// because the producers are other workgroups of the SAME launch (cdna_hip_programming.md G16: write-through
+// stores on the producer side, sc1 loads on the consumer side).
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+
+struct SelShared {            // LDS of one selecting workgroup
+    unsigned int hist[kSelBins];
+    unsigned int list[kListCap];
+    SelState sel;
+    unsigned int s_n, s_bad, s_kmin, s_kmax, s_plain, s_fill, s_next, s_found[2], s_sel, s_pos;
+    unsigned int s_wtot[kSelWaves];
+};
+
+struct SideResult {
+    float value;      // max(v[v <= quantile(|v|, p)]) of this side's v (or its plain maximum)
+    bool bad;         // a NaN among the valid tokens
+    bool empty;       // no valid token at all
+};
+
+template <int R4, bool COMPACT>
+__device__ __forceinline__ SideResult select_side(const float* src, const int side, const int64_t aB, const int64_t aT,
+                                                  const int64_t* lengths, const unsigned int compact_n, const int prune,
+                                                  const float aq, const int use_shortcut, SelShared& S, long long* stamps) {
     constexpr int R = 4 * R4;
-    const int side = blockIdx.x;
-    const int64_t p = blockIdx.y;
-    const float* src = side ? a.tok_min : a.tok_max;
-    const int64_t* lengths = a.lengths;
-    int prune = a.prune;
-    if (fb.n_batches > 0) {
-        const int64_t qi = p / fb.n_batches, bi = p - qi * fb.n_batches;
-        src += p * fb.problem_stride;
-        if (lengths) lengths += bi * a.B;
-        prune = fb.prune_flags ? fb.prune_flags[qi] : prune;
-        fin.cur += 2 * (bi * fb.n_quantizers + qi);
-    }
-    __shared__ unsigned int hist[kSelBins];
-    __shared__ unsigned int list[kListCap];
-    __shared__ SelState sel;
-    __shared__ unsigned int s_n, s_bad, s_kmin, s_kmax, s_plain, s_fill, s_next, s_found[2], s_sel, s_pos;
-    __shared__ unsigned int s_wtot[kSelWaves];
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
-    const unsigned int Tu = static_cast<unsigned int>(a.T);
-    const unsigned int groups = static_cast<unsigned int>((a.B * a.T) >> 2);
-    const unsigned int Bm1 = static_cast<unsigned int>(a.B) - 1u;
-    const bool straddle = (Tu & 3u) != 0u;          // T % 4 == 0: the four slots of a group share their sample
+    const unsigned int Tu = static_cast<unsigned int>(aT);
+    const unsigned int groups = static_cast<unsigned int>((aB * aT) >> 2);
+    const unsigned int Bm1 = static_cast<unsigned int>(aB) - 1u;
+    const bool straddle = !COMPACT && (Tu & 3u) != 0u;     // T % 4 == 0: the four slots of a group share their sample
     const unsigned int flip = side ? 0x80000000u : 0u;     // side 1 works on -token_min
-
-    // running state for the finish step, fetched now so that the second arriver's tail has no dependent load
-    float st_min = 0.f, st_max = 0.f;
-    const bool have_state = fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val;
-    if (tid == 0 && have_state) { st_min = fin.min_val[0]; st_max = fin.max_val[0]; }
 
     OSQ_SSTAMP(0);
     // ---- lengths first (L2 hits, needed before the data), then every data load, all unconditional.
     // Slot k of a group is valid iff k < rem_a (same sample as slot 0) or, behind the sample boundary
-    // k >= wrap (T % 4 != 0 only), iff k < rem_b.
+    // k >= wrap (T % 4 != 0 only), iff k < rem_b.  COMPACT: slot s is valid iff s < compact_n.
     int rem_a[R4], rem_b[R4], wrap[R4];
-    {
+    if (COMPACT) {
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            const unsigned int g = static_cast<unsigned int>(tid) + static_cast<unsigned int>(j) * kSelThreads;
+            rem_a[j] = g < groups ? static_cast<int>(compact_n) - static_cast<int>(4u * g) : 0;
+            rem_b[j] = 0;
+            wrap[j] = 4;
+        }
+    } else {
         const unsigned int step_b = (4u * kSelThreads) / Tu, step_t = 4u * kSelThreads - step_b * Tu;
         unsigned int bb = (4u * static_cast<unsigned int>(tid)) / Tu, tt = 4u * static_cast<unsigned int>(tid) - bb * Tu;
 #pragma unroll
         for (int j = 0; j < R4; ++j) {
             const unsigned int g = static_cast<unsigned int>(tid) + static_cast<unsigned int>(j) * kSelThreads;
-            int64_t la = a.T, lb = a.T;
+            int64_t la = aT, lb = aT;
             if (lengths) {
                 la = lengths[bb < Bm1 ? bb : Bm1];
                 lb = straddle ? lengths[bb + 1u < Bm1 ? bb + 1u : Bm1] : la;
             }
-            const int ia = la > a.T ? static_cast<int>(a.T) : (la < 0 ? 0 : static_cast<int>(la));
-            const int ib = lb > a.T ? static_cast<int>(a.T) : (lb < 0 ? 0 : static_cast<int>(lb));
+            const int ia = la > aT ? static_cast<int>(aT) : (la < 0 ? 0 : static_cast<int>(la));
+            const int ib = lb > aT ? static_cast<int>(aT) : (lb < 0 ? 0 : static_cast<int>(lb));
             const int to_end = static_cast<int>(Tu - tt);           // slots left in this sample, >= 1
             wrap[j] = to_end;
             rem_a[j] = g < groups ? ia - static_cast<int>(tt) : 0;
@@ -110,7 +121,16 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         }
     }
     float4 raw[R4];
-    {
+    if (COMPACT) {
+        // producers are workgroups of this launch (write-through stores): read around this CU's L1 with sc1 loads
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, static_cast<int>(groups * 16u), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            const unsigned int g = static_cast<unsigned int>(tid) + static_cast<unsigned int>(j) * kSelThreads;
+            const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (g < groups ? g : groups - 1u) * 16u, 0, 16);
+            raw[j] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+        }
+    } else {
         const float4* src4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
         for (int j = 0; j < R4; ++j) {
@@ -119,10 +139,10 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         }
     }
     // LDS set-up overlaps the loads
-    for (int k = tid; k < kSelBins; k += kSelThreads) hist[k] = 0u;
+    for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
     if (tid == 0) {
-        s_n = 0u; s_bad = 0u; s_kmin = 0xffffffffu; s_kmax = 0u; s_plain = 0u; s_fill = 0u;
-        s_next = 0xffffffffu; s_found[0] = s_found[1] = 0xffffffffu; s_sel = 0u; s_pos = 0u;
+        S.s_n = 0u; S.s_bad = 0u; S.s_kmin = 0xffffffffu; S.s_kmax = 0u; S.s_plain = 0u; S.s_fill = 0u;
+        S.s_next = 0xffffffffu; S.s_found[0] = S.s_found[1] = 0xffffffffu; S.s_sel = 0u; S.s_pos = 0u;
     }
     OSQ_SSTAMP(1);
 
@@ -165,47 +185,47 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         const bool wbad = wave_any(bad);
         n = wave_inclusive_scan_u32(n);
         __syncthreads();                       // LDS initialisation above is complete
-        if (lane == OSQ_WAVE - 1) atomicAdd(&s_n, n);
+        if (lane == OSQ_WAVE - 1) atomicAdd(&S.s_n, n);
         if (lane == 0) {
-            if (wbad) atomicOr(&s_bad, 1u);
-            atomicMin(&s_kmin, __float_as_uint(amin));       // non-negative floats order like their bit patterns
-            atomicMax(&s_kmax, __float_as_uint(amax));
-            atomicMax(&s_plain, ordered_bits(plain));
+            if (wbad) atomicOr(&S.s_bad, 1u);
+            atomicMin(&S.s_kmin, __float_as_uint(amin));       // non-negative floats order like their bit patterns
+            atomicMax(&S.s_kmax, __float_as_uint(amax));
+            atomicMax(&S.s_plain, ordered_bits(plain));
         }
     }
     __syncthreads();
     OSQ_SSTAMP(2);
-    const unsigned int N = s_n;
-    if (N == 0u) return;                       // both sides agree: nothing observed, nothing updated
-    const bool any_bad = s_bad != 0u;
-    float result = from_ordered_bits(s_plain);
+    const unsigned int N = S.s_n;
+    if (N == 0u) return SideResult{0.0f, false, true};     // both sides agree: nothing observed
+    const bool any_bad = S.s_bad != 0u;
+    float result = from_ordered_bits(S.s_plain);
 
     if (prune && !any_bad) {
-        const float rank = a.q * static_cast<float>(N - 1u);
+        const float rank = aq * static_cast<float>(N - 1u);
         const float rlo = floorf(rank);
         const unsigned int k_lo = static_cast<unsigned int>(rlo);
         const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
         const float w = rank - rlo;
         if (tid == 0) {
-            sel.lo = s_kmin;
-            sel.width = s_kmax - s_kmin + 1u;
-            sel.rank = k_lo;
-            sel.shift = level_shift(sel.width);
-            sel.le = 0u;
-            sel.done = 0u;
-            sel.count = N;
+            S.sel.lo = S.s_kmin;
+            S.sel.width = S.s_kmax - S.s_kmin + 1u;
+            S.sel.rank = k_lo;
+            S.sel.shift = level_shift(S.sel.width);
+            S.sel.le = 0u;
+            S.sel.done = 0u;
+            S.sel.count = N;
         }
         __syncthreads();
-        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the list
+        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
         bool listed = false;
         for (int level = 0; level < 3; ++level) {
-            if (sel.done) break;
+            if (S.sel.done) break;
             if (level > 0) {
-                if (sel.count <= kListCap) { listed = true; break; }
-                for (int k = tid; k < kSelBins; k += kSelThreads) hist[k] = 0u;
+                if (S.sel.count <= kListCap) { listed = true; break; }
+                for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
                 __syncthreads();
             }
-            const unsigned int lo = uniform(sel.lo), wd = uniform(sel.width), sh = uniform(sel.shift);
+            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width), sh = uniform(S.sel.shift);
             // The range check also keeps poisoned slots (key 0x7fc00000) out.  Measured alternatives: all of them
             // into ONE trash bin is 5x slower (same-address LDS atomics serialise); one trash bin per lane with a
             // v_min instead of the compare + exec masking is no faster (6.6k vs 6.4k cycles at 32768 slots) --
@@ -213,37 +233,37 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const unsigned int d = abs_key(v[i]) - lo;
-                if (d < wd) atomicAdd(&hist[d >> sh], 1u);
+                if (d < wd) atomicAdd(&S.hist[d >> sh], 1u);
             }
             __syncthreads();
             // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank narrows
-            const unsigned int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+            const unsigned int h0 = S.hist[2 * tid], h1 = S.hist[2 * tid + 1];
             const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
-            if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl_w;
+            if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
             __syncthreads();
             unsigned int base = 0u;
 #pragma unroll
-            for (int k = 0; k < kSelWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
+            for (int k = 0; k < kSelWaves; ++k) base += (k < wv) ? S.s_wtot[k] : 0u;
             const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
-            const unsigned int want = sel.rank;
+            const unsigned int want = S.sel.rank;
             __syncthreads();
             if (want >= excl && want < incl) {     // exactly one thread
                 const bool second = want >= excl + h0;
                 const unsigned int below = second ? excl + h0 : excl;
                 const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
-                const unsigned int shv = sel.shift, off = bin << shv;
-                sel.lo += off;
-                sel.count = cnt;
+                const unsigned int shv = S.sel.shift, off = bin << shv;
+                S.sel.lo += off;
+                S.sel.count = cnt;
                 if (shv == 0u) {                   // single-key bins: found
-                    sel.le += below + cnt;
-                    sel.width = 0u;
-                    sel.done = 1u;
+                    S.sel.le += below + cnt;
+                    S.sel.width = 0u;
+                    S.sel.done = 1u;
                 } else {
-                    const unsigned int rest = sel.width - off, cap = 1u << shv;
-                    sel.le += below;
-                    sel.rank = want - below;
-                    sel.width = rest < cap ? rest : cap;
-                    sel.shift = level_shift(sel.width);
+                    const unsigned int rest = S.sel.width - off, cap = 1u << shv;
+                    S.sel.le += below;
+                    S.sel.rank = want - below;
+                    S.sel.width = rest < cap ? rest : cap;
+                    S.sel.shift = level_shift(S.sel.width);
                 }
             }
             __syncthreads();
@@ -251,14 +271,14 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
         OSQ_SSTAMP(3);
         unsigned int v_lo, v_hi;     // keys at floor(rank) / ceil(rank)
         bool shortcut_done = false;  // uniform
-        if (!sel.done && listed) {
+        if (!S.sel.done && listed) {
             // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
-            const unsigned int lo = uniform(sel.lo), wd = uniform(sel.width);
-            const bool need_next = (k_hi != k_lo) && (uniform(sel.rank) + 1u >= uniform(sel.count));
+            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width);
+            const bool need_next = (k_hi != k_lo) && (uniform(S.sel.rank) + 1u >= uniform(S.sel.count));
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const unsigned int key = abs_key(v[i]);
-                if (key - lo < wd) list[atomicAdd(&s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
+                if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
             }
             if (need_next) {
                 // smallest key at or above the bin's end: keys below it wrap to huge values under the
@@ -268,40 +288,40 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #pragma unroll
                 for (int i = 0; i < R; ++i) nx = min(nx, abs_key(v[i]) - edge);
                 nx = wave_min_u32(nx);
-                if (lane == 0 && nx < 0x80000000u) atomicMin(&s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
+                if (lane == 0 && nx < 0x80000000u) atomicMin(&S.s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
             }
             __syncthreads();
-            const unsigned int cnt = s_fill, want = sel.rank;
+            const unsigned int cnt = S.s_fill, want = S.sel.rank;
             if (static_cast<unsigned int>(tid) < cnt) {     // rank by counting, ties broken by position
-                const unsigned int mine = list[tid] & 0x7fffffffu;
+                const unsigned int mine = S.list[tid] & 0x7fffffffu;
                 unsigned int r = 0u;
                 for (unsigned int j = 0; j < cnt; ++j) {
-                    const unsigned int o = list[j] & 0x7fffffffu;
+                    const unsigned int o = S.list[j] & 0x7fffffffu;
                     r += (o < mine || (o == mine && j < static_cast<unsigned int>(tid))) ? 1u : 0u;
                 }
-                if (r == want) s_found[0] = mine;
-                if (r == want + 1u) s_found[1] = mine;
+                if (r == want) S.s_found[0] = mine;
+                if (r == want + 1u) S.s_found[1] = mine;
             }
             __syncthreads();
-            v_lo = s_found[0];
-            const bool hi_listed = s_found[1] != 0xffffffffu;
-            v_hi = hi_listed ? s_found[1] : s_next;
+            v_lo = S.s_found[0];
+            const bool hi_listed = S.s_found[1] != 0xffffffffu;
+            v_hi = hi_listed ? S.s_found[1] : S.s_next;
             // Shortcut for the threshold pass.  The keys at ranks floor/ceil are neighbours in sorted order, so
             // no key lies strictly between them, thr lies in [lo_v, hi_v], and every value with a larger key
             // is either negative or above thr.  If some element with key lo_v is non-negative, then
             // max(v[v <= thr]) is lo_v -- or hi_v when thr reaches it and a non-negative element has that
-            // key.  Both facts are in the list (it holds every element of the bin, with sign) as long as the
+            // key.  Both facts are in the S.list (it holds every element of the bin, with sign) as long as the
             // upper key is listed or not reached; otherwise the register pass below decides.
-            if (a.shortcut) {
+            if (use_shortcut) {
                 if (static_cast<unsigned int>(tid) < cnt) {
-                    const unsigned int e = list[tid];
+                    const unsigned int e = S.list[tid];
                     if (!(e >> 31)) {
-                        if (e == v_lo) atomicOr(&s_pos, 1u);
-                        if (e == v_hi) atomicOr(&s_pos, 2u);
+                        if (e == v_lo) atomicOr(&S.s_pos, 1u);
+                        if (e == v_hi) atomicOr(&S.s_pos, 2u);
                     }
                 }
                 __syncthreads();
-                const unsigned int pos = s_pos;
+                const unsigned int pos = S.s_pos;
                 const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
                 const float d = hi_f - lo_f;
                 const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
@@ -312,9 +332,9 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
                 }
             }
         } else {
-            // every level ran (massive duplicates): sel.lo is the key at rank k_lo, sel.le = #keys <= it
-            v_lo = uniform(sel.lo);
-            if (k_hi != k_lo && sel.le <= k_hi) {           // rank k_hi is the smallest key above
+            // every level ran (massive duplicates): S.sel.lo is the key at rank k_lo, S.sel.le = #keys <= it
+            v_lo = uniform(S.sel.lo);
+            if (k_hi != k_lo && S.sel.le <= k_hi) {           // rank k_hi is the smallest key above
                 unsigned int nx = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -322,9 +342,9 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
                     if (key > v_lo) nx = min(nx, key);
                 }
                 nx = wave_min_u32(nx);
-                if (lane == 0) atomicMin(&s_next, nx);
+                if (lane == 0) atomicMin(&S.s_next, nx);
                 __syncthreads();
-                v_hi = s_next;
+                v_hi = S.s_next;
             } else {
                 v_hi = v_lo;
             }
@@ -340,30 +360,70 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #pragma unroll
             for (int i = 0; i < R; ++i) best = (v[i] <= thr) ? fmaxf(best, v[i]) : best;
             best = wave_max(best);
-            if (lane == 0) atomicMax(&s_sel, ordered_bits(best));
+            if (lane == 0) atomicMax(&S.s_sel, ordered_bits(best));
             __syncthreads();
-            result = from_ordered_bits(s_sel);
+            result = from_ordered_bits(S.s_sel);
         }
     }
     OSQ_SSTAMP(5);
-    // ---- rendezvous of the two sides: first arriver leaves {value, present | bad}, second finishes
-    if (tid == 0) {
-        const unsigned long long mine = (static_cast<unsigned long long>(0x80000000u | (any_bad ? 1u : 0u)) << 32) |
-                                        __float_as_uint(result);
-        const unsigned long long other = __hip_atomic_exchange(&a.meet[p], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (other >> 63) {
-            __hip_atomic_store(&a.meet[p], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float theirs = __uint_as_float(static_cast<unsigned int>(other & 0xffffffffull));
-            const bool poisoned = any_bad || ((other >> 32) & 1ull);
-            const float up = side ? theirs : result;
-            const float lo = -(side ? result : theirs);
-            float cur_min = (lo > up) ? up : lo;          // aminmax(clip(value, lo, up)), observer.py:68,227
-            float cur_max = up;
-            if (poisoned) { cur_min = __builtin_nanf(""); cur_max = cur_min; }
-            finish_entry(fin, 0, cur_min, cur_max, have_state, st_min, st_max);
-        }
+    return SideResult{result, any_bad, false};
+}
+
+// Rendezvous of the two sides (thread 0 of each side's workgroup): the first arriver leaves
+// {value, present | bad} in the zero-idle word, the second takes it, puts the word back to zero and returns true
+// with the batch's (cur_min, cur_max): the reference's clip rule aminmax(clip(value, lo, up)), observer.py:68,227.
+__device__ __forceinline__ bool meet_sides(unsigned long long* word, const int side, const SideResult& r,
+                                           float* cur_min, float* cur_max) {
+    const unsigned long long mine = (static_cast<unsigned long long>(0x80000000u | (r.bad ? 1u : 0u)) << 32) |
+                                    __float_as_uint(r.value);
+    const unsigned long long other = __hip_atomic_exchange(word, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(other >> 63)) return false;
+    __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float theirs = __uint_as_float(static_cast<unsigned int>(other & 0xffffffffull));
+    const bool poisoned = r.bad || ((other >> 32) & 1ull);
+    const float up = side ? theirs : r.value;
+    const float lo = -(side ? r.value : theirs);
+    *cur_min = (lo > up) ? up : lo;
+    *cur_max = up;
+    if (poisoned) { *cur_min = __builtin_nanf(""); *cur_max = *cur_min; }
+    return true;
+}
+
+// Stand-alone launch: TWO workgroups per problem (blockIdx.x = side, blockIdx.y = problem).
+template <int R4>
+__global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a, Finish fin, FinalBatch fb) {
+    const int side = blockIdx.x;
+    const int64_t p = blockIdx.y;
+    const float* src = side ? a.tok_min : a.tok_max;
+    const int64_t* lengths = a.lengths;
+    int prune = a.prune;
+    if (fb.n_batches > 0) {
+        const int64_t qi = p / fb.n_batches, bi = p - qi * fb.n_batches;
+        src += p * fb.problem_stride;
+        if (lengths) lengths += bi * a.B;
+        prune = fb.prune_flags ? fb.prune_flags[qi] : prune;
+        fin.cur += 2 * (bi * fb.n_quantizers + qi);
     }
-    OSQ_SSTAMP(6);
+    __shared__ SelShared S;
+    // running state for the finish step, fetched now so that the second arriver's tail has no dependent load
+    float st_min = 0.f, st_max = 0.f;
+    const bool have_state = fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val;
+    if (threadIdx.x == 0 && have_state) { st_min = fin.min_val[0]; st_max = fin.max_val[0]; }
+#ifdef OSQ_FINAL_TIMING
+    long long* stamps = (blockIdx.x == 0 && fin.cur) ? reinterpret_cast<long long*>(fin.cur + 2) : nullptr;
+#else
+    long long* stamps = nullptr;
+#endif
+    const SideResult r = select_side<R4, false>(src, side, a.B, a.T, lengths, 0u, prune, a.q, a.shortcut, S, stamps);
+    if (r.empty) return;                       // nothing observed, nothing updated
+    if (threadIdx.x == 0) {
+        float cur_min, cur_max;
+        if (meet_sides(&a.meet[p], side, r, &cur_min, &cur_max))
+            finish_entry(fin, 0, cur_min, cur_max, have_state, st_min, st_max);
+    }
+#ifdef OSQ_FINAL_TIMING
+    if (threadIdx.x == 0 && stamps) stamps[6] = __builtin_readcyclecounter();
+#endif
 }
 
 }  // namespace osq

@@ -1,0 +1,34 @@
+"""Development aid: wall-clock stamps (100 MHz) of the fused observe + fake-quant launch.  `make -C outlier_suppression_amd/csrc dbg` first.
+Streaming workgroups: 0 start, 1 prefix sums + row map done, 2 valid tokens reduced + published (wave 0), 3 arrived,
+4 scale seen by the poller, 5 after the barrier, 6 end.  Selectors: 0 start, 1 all arrived, 2 side selected, 3 end."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from outlier_suppression_amd import _hip, ops
+_hip.LIB_PATH = _hip.LIB_PATH.replace("libosq_hip.so", "libosq_hip_dbg.so")
+from tools.fused_check import mk, dev
+lib = _hip.load()
+lib.osq_debug_buffer.argtypes = [ctypes.c_void_p]
+shape = (256, 128, 768)
+g = torch.Generator().manual_seed(1234)
+full = len(sys.argv) > 1 and sys.argv[1] == "full"
+lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, 129, (shape[0],), generator=g)).to(dev)
+xs = [torch.randn(*shape, device=dev) for _ in range(4)]
+dbg = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
+assert lib.osq_debug_buffer(dbg.data_ptr()) == 0
+q = mk()
+with torch.no_grad():
+    for i in range(10):
+        q(xs[i % 4], lengths, 1)
+    torch.cuda.synchronize()
+    dbg.zero_()
+    q(xs[2], lengths, 1)
+    torch.cuda.synchronize()
+d = dbg.view(256, 8).cpu()
+t0 = int(d[:, 0][d[:, 0] > 0].min())
+us = lambda v: (v.double() - t0) / 100.0
+print("selectors (us since first start): ", [[round(float(x), 2) for x in us(d[b, :4])] for b in range(2)])
+s = d[2:]
+for k, name in enumerate(["start", "mapped", "A1 done (wave 0)", "arrived", "scale seen", "after barrier", "end"]):
+    v = us(s[:, k])
+    print(f"streaming {name:>18}: min {float(v.min()):7.2f}  median {float(v.median()):7.2f}  max {float(v.max()):7.2f}")

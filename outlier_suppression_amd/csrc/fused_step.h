@@ -43,10 +43,9 @@ constexpr unsigned int kFusedSpinLimit = 1u << 21;
 struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch
     unsigned int arrive[kFusedShards][16];    // one 64-byte line per counter; zero between launches
     unsigned int epoch, pad0[15];             // launches completed on this workspace
-    unsigned long long result[2], pad1[6];    // {tag << 32 | scale bits}, {tag << 32 | zero_point bits (as fp32)}
-    unsigned long long meet, pad2[7];         // rendezvous word of the two selectors, zero when idle
+    unsigned long long side[2][8];            // one granule per selector: tag30 << 34 | empty << 33 | bad << 32 | value bits
     unsigned int status, pad3[15];            // sticky: 1 = a selector timed out, 2 = a streaming workgroup timed out
-    unsigned int go, pad4[15];                // = tag once every streaming workgroup has arrived
+    unsigned int go[2][16];                   // = tag once selector `side` has pulled the per-token extrema into its registers
 };
 
 struct FusedArgs {
@@ -72,6 +71,19 @@ __device__ __forceinline__ unsigned long long peek64(const unsigned long long* p
 }
 __device__ __forceinline__ unsigned int peek32(const unsigned int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ unsigned long long side_granule(unsigned int tag, const SideResult& r) {
+    return (static_cast<unsigned long long>(tag & 0x3fffffffu) << 34) | (r.empty ? (1ull << 33) : 0ull) | (r.bad ? (1ull << 32) : 0ull) |
+           __float_as_uint(r.value);
+}
+
+// one selection per call site keeps the code size (and the build time) of the four kernel instantiations down
+template <int R4>
+__device__ __attribute__((noinline)) SideResult select_side_compact(const float* src, int side, int64_t cap, unsigned int n_valid,
+                                                                   int prune, float q, int shortcut, SelShared& S, long long* stamps,
+                                                                   unsigned int* loaded_flag, unsigned int loaded_tag) {
+    return select_side<R4, true>(src, side, 1, cap, nullptr, n_valid, prune, q, shortcut, S, stamps, loaded_flag, loaded_tag);
 }
 
 // streaming workgroups whose arrival lands on shard s (blockIdx % 8 == s, blockIdx >= 2)
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     v4u32* const keep = lds.keep;
     __shared__ unsigned int pre[kFusedMaxBatch + 1];
     __shared__ unsigned int s_wtot[kFusedWaves];
-    __shared__ unsigned int s_word[4];
+    __shared__ unsigned int s_word[8];
+    __shared__ unsigned int rows[kFusedWaves * 24];
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / OSQ_WAVE);      // wave-uniform, and the compiler knows it
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
         __syncthreads();
     }
+    OSQ_FSTAMP(7);
     const unsigned int tag = s_word[0] + 1u;
     const unsigned int V = pre[Bu];                       // valid tokens
     const unsigned int total = Bu * Tu;
@@ -155,13 +169,6 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     if (blockIdx.x < 2u) {
         // =========================================================== selector (one side)
         const int side = blockIdx.x;
-        float st_min = 0.f, st_max = 0.f, old_s = 0.f, old_z = 0.f;
-        const bool have_state = fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val;
-        if (tid == 0) {
-            if (have_state) { st_min = fin.min_val[0]; st_max = fin.max_val[0]; }
-            old_s = a.scale_p[0];
-            old_z = load_zp(a.zp_p, a.zp_type);
-        }
         if (wv == 0) {                                     // lanes 0..7 watch one arrival counter each
             const unsigned int s = lane < kFusedShards ? lane : 0;
             const unsigned int want = fused_members(gridDim.x, s);
@@ -171,62 +178,52 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
-            if (lane == 0) {
-                s_word[1] = __all(ok) ? 1u : 0u;
-                if (side == 0) __hip_atomic_store(&st->go, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (lane == 0) s_word[1] = __all(ok) ? 1u : 0u;
         }
         __syncthreads();
         OSQ_FSTAMP(1);
         const bool arrived = s_word[1] != 0u;
-        SideResult r{0.0f, false, true};
+        SideResult r{__builtin_nanf(""), true, false};     // timed out: poison the call instead of hanging
+#ifdef OSQ_FINAL_TIMING
+        long long* sstamps = g_osq_dbg ? g_osq_dbg + 8 * 256 + 8 * side : nullptr;
+#else
+        long long* sstamps = nullptr;
+#endif
         if (arrived) {
             const float* src = side ? a.tok_min : a.tok_max;
             const int64_t cap = (static_cast<int64_t>(total) + 3) & ~int64_t(3);
             const unsigned int g4 = (V + 3u) >> 2;         // 16-byte groups that hold valid slots
-            if (g4 <= 1u * kSelThreads) r = select_side<1, true>(src, side, 1, cap, nullptr, V, a.prune, a.q, a.shortcut, sel_lds, nullptr);
-            else if (g4 <= 2u * kSelThreads) r = select_side<2, true>(src, side, 1, cap, nullptr, V, a.prune, a.q, a.shortcut, sel_lds, nullptr);
-            else if (g4 <= 4u * kSelThreads) r = select_side<4, true>(src, side, 1, cap, nullptr, V, a.prune, a.q, a.shortcut, sel_lds, nullptr);
-            else r = select_side<8, true>(src, side, 1, cap, nullptr, V, a.prune, a.q, a.shortcut, sel_lds, nullptr);
+            unsigned int* const go = &st->go[side][0];
+#define OSQ_FUSED_SELECT(R4) r = select_side_compact<R4>(src, side, cap, V, a.prune, a.q, a.shortcut, sel_lds, sstamps, go, tag)
+            if (g4 <= 1u * kSelThreads) OSQ_FUSED_SELECT(1);
+            else if (g4 <= 2u * kSelThreads) OSQ_FUSED_SELECT(2);
+            else if (g4 <= 3u * kSelThreads) OSQ_FUSED_SELECT(3);
+            else if (g4 <= 4u * kSelThreads) OSQ_FUSED_SELECT(4);
+            else if (g4 <= 5u * kSelThreads) OSQ_FUSED_SELECT(5);
+            else if (g4 <= 6u * kSelThreads) OSQ_FUSED_SELECT(6);
+            else OSQ_FUSED_SELECT(8);
+#undef OSQ_FUSED_SELECT
+        } else if (tid == 0) {
+            __hip_atomic_fetch_or(&st->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->go[side][0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         OSQ_FSTAMP(2);
-        if (tid == 0) {
-            float cur_min, cur_max;
-            if (meet_sides(&st->meet, side, r, &cur_min, &cur_max)) {
-                float s = old_s, z = old_z;
-                if (!r.empty) {                            // both sides saw the same N
-                    float mn = cur_min, mx = cur_max;
-                    if (have_state) {
-                        mn = st_min;
-                        mx = st_max;
-                        apply_update(fin.rule, fin.cnt, cur_min, cur_max, &mn, &mx);
-                        fin.min_val[0] = mn;
-                        fin.max_val[0] = mx;
-                    }
-                    qparams_from_range(mn, mx, fin.quant_min, fin.quant_max, fin.symmetric, &s, &z);
-                    fin.scale_out[0] = s;
-                    store_zp(fin.zp_out, fin.zp_type, 0, z);
-                    if (fin.zp_type != OSQ_ZP_FLOAT32) z = static_cast<float>(static_cast<int32_t>(z));   // what a reader of the int32 buffer sees
-                }
-                if (!arrived) {                            // timed out: poison the call instead of hanging
-                    s = z = __builtin_nanf("");
-                    __hip_atomic_fetch_or(&st->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(&st->result[0], (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(s),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&st->result[1], (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(z),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int k = 0; k < kFusedShards; ++k)
-                    __hip_atomic_store(&st->arrive[k][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (tid == 0)
+            __hip_atomic_store(&st->side[side][0], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         OSQ_FSTAMP(3);
         return;
     }
 
     // =============================================================== streaming workgroup
     const unsigned int nwv = (gridDim.x - 2u) * kFusedWaves;                        // streaming waves
+    // what the finishing arithmetic needs, fetched now by the thread that will do it
+    float st_min = 0.f, st_max = 0.f, old_s = 0.f, old_z = 0.f;
+    const bool have_state = fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val;
+    if (tid == 0) {
+        if (have_state) { st_min = fin.min_val[0]; st_max = fin.max_val[0]; }
+        old_s = a.scale_p[0];
+        old_z = load_zp(a.zp_p, a.zp_type);
+    }
     const unsigned int gw = (blockIdx.x - 2u) * kFusedWaves + static_cast<unsigned int>(wv);
     // Rows are addressed as buffer base (SGPR descriptor) + wave-uniform row offset (SGPR) + lane * 16 (one VGPR for
     // every access): no 64-bit address pair per token in flight -- the lanes' registers are for data.
@@ -240,40 +237,31 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     v4u32* const keep_w = keep + static_cast<unsigned int>(wv) * (SL * NV * OSQ_WAVE) + lane;
 
     // token j of the enumeration -> row b*T + t.  Valid tokens of sample b are j in [pre[b], pre[b+1]); padded ones
-    // follow: j - V in [b*T - pre[b], (b+1)*T - pre[b+1]).  b = number of prefix entries (i = 1..B) at or below j,
-    // counted 64 entries at a time with a ballot.
-    unsigned int row[S];
-    {
-        unsigned int cnt_v[S], cnt_p[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) cnt_v[k] = cnt_p[k] = 0u;
-        for (unsigned int c = 0; c < Bu; c += OSQ_WAVE) {
-            const unsigned int i = c + static_cast<unsigned int>(lane) + 1u;
-            const bool in = i <= Bu;
-            const unsigned int p = pre[in ? i : Bu];
-            const unsigned int pp = i * Tu - p;
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
-                cnt_v[k] += static_cast<unsigned int>(__builtin_popcountll(__ballot(in && p <= j)));
-                cnt_p[k] += static_cast<unsigned int>(__builtin_popcountll(__ballot(in && j >= V && pp <= j - V)));
+    // follow: j - V in [b*T - pre[b], (b+1)*T - pre[b+1]).  b = number of prefix entries (i = 1..B) at or below j:
+    // thread (k, w) of the first 16*S threads finds it for slot k of wave w by bisection and leaves the row in LDS.
+    // (All sixteen waves counting with ballots, 64 entries at a time, took 3 us: the CU's issue slots, not latency.)
+    if (tid < kFusedWaves * S) {
+        const unsigned int k = static_cast<unsigned int>(tid) / kFusedWaves, w = static_cast<unsigned int>(tid) % kFusedWaves;
+        const unsigned int j = (blockIdx.x - 2u) * kFusedWaves + w + k * nwv;
+        unsigned int r = 0u;
+        if (j < total) {
+            const bool valid = j < V;
+            const unsigned int key = valid ? j : j - V;
+            unsigned int lo = 0u, hi = Bu;                 // invariant f(lo) <= key < f(hi), f(i) = tokens of this kind before sample i
+            while (lo + 1u < hi) {
+                const unsigned int mid = (lo + hi) >> 1;   // f(mid) <= key  ->  b >= mid
+                const unsigned int f = valid ? pre[mid] : mid * Tu - pre[mid];
+                if (f <= key) lo = mid; else hi = mid;
             }
+            const unsigned int b = lo;                     // f(b) <= key < f(b + 1); f is monotone, so b is the count
+            r = valid ? b * Tu + (key - pre[b]) : b * Tu + (pre[b + 1u] - pre[b]) + (key - (b * Tu - pre[b]));
         }
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
-            unsigned int r = 0u;
-            if (j < V) {
-                const unsigned int b = cnt_v[k];
-                r = b * Tu + (j - pre[b]);
-            } else if (j < total) {
-                const unsigned int b = cnt_p[k];
-                const unsigned int len = pre[b + 1u] - pre[b];
-                r = b * Tu + len + ((j - V) - (b * Tu - pre[b]));
-            }
-            row[k] = uniform(r);
-        }
+        rows[tid] = r;
     }
+    __syncthreads();
+    unsigned int row[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) row[k] = uniform(rows[k * kFusedWaves + wv]);
     OSQ_FSTAMP(1);
 
     // ---- phase A1: valid tokens -> registers (slots 0..SR-1) / LDS (slots SR..S-1), per-token extrema -> compact arrays
@@ -346,12 +334,12 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     OSQ_FSTAMP(3);
 
     // ---- phase A2: this wave's padded tokens -> registers / LDS, while the selectors work.  Not before every workgroup
-    // has arrived (the selectors raise `go`): padded loads issued earlier take bandwidth from the workgroups still in
-    // A1, and the last arrival is what the selection waits for.
+    // has arrived and the selectors hold the extrema (they raise `go`): padded loads issued earlier take bandwidth from the workgroups still in
+    // A1 and from the selectors' own loads, and both are what the scale waits for.
     if (a.gate) {
         if (tid == 0) {
             for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
-                if (peek32(&st->go) == tag) break;
+                if (peek32(&st->go[0][0]) == tag && peek32(&st->go[1][0]) == tag) break;
                 __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -376,23 +364,51 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     }
     asm volatile("" ::: "memory");
 
-    // ---- wait for (scale, zero_point)
+    // ---- wait for the two sides; every workgroup finishes the statistic itself (clip rule, running statistic,
+    // calculate_qparams: a few dozen scalar operations) instead of waiting for one finisher to do it and publish again
     if (tid == 0) {
-        unsigned long long r0 = 0ull, r1 = 0ull;
+        unsigned long long g0 = 0ull, g1 = 0ull;
         bool ok = false;
+        const unsigned long long want = static_cast<unsigned long long>(tag & 0x3fffffffu);
         for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
-            r0 = peek64(&st->result[0]);
-            r1 = peek64(&st->result[1]);
-            ok = static_cast<unsigned int>(r0 >> 32) == tag && static_cast<unsigned int>(r1 >> 32) == tag;
+            g0 = peek64(&st->side[0][0]);
+            g1 = peek64(&st->side[1][0]);
+            ok = (g0 >> 34) == want && (g1 >> 34) == want;
             if (ok) break;
             __builtin_amdgcn_s_sleep(8);
         }
+        float s = __builtin_nanf(""), z = s;
         if (!ok) {
             __hip_atomic_fetch_or(&st->status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r0 = r1 = 0x7fc00000ull;
+        } else if ((g0 >> 33) & 1ull) {                    // nothing observed (both sides agree): parameters as they are
+            s = old_s;
+            z = old_z;
+        } else {
+            const float up = __uint_as_float(static_cast<unsigned int>(g0)), lo = -__uint_as_float(static_cast<unsigned int>(g1));
+            float cur_min = (lo > up) ? up : lo;           // aminmax(clip(value, lo, up)), observer.py:68,227
+            float cur_max = up;
+            if (((g0 | g1) >> 32) & 1ull) { cur_min = __builtin_nanf(""); cur_max = cur_min; }
+            float mn = cur_min, mx = cur_max;
+            if (have_state) {
+                mn = st_min;
+                mx = st_max;
+                apply_update(fin.rule, fin.cnt, cur_min, cur_max, &mn, &mx);
+            }
+            qparams_from_range(mn, mx, fin.quant_min, fin.quant_max, fin.symmetric, &s, &z);
+            if (blockIdx.x == 2u) {                        // ONE workgroup writes the module's buffers
+                if (have_state) { fin.min_val[0] = mn; fin.max_val[0] = mx; }
+                fin.scale_out[0] = s;
+                store_zp(fin.zp_out, fin.zp_type, 0, z);
+            }
+            if (fin.zp_type != OSQ_ZP_FLOAT32) z = static_cast<float>(static_cast<int32_t>(z));   // what a reader of the int32 buffer sees
         }
-        s_word[2] = static_cast<unsigned int>(r0);
-        s_word[3] = static_cast<unsigned int>(r1);
+        if (blockIdx.x == 2u) {                            // ... and closes the launch's bookkeeping: every workgroup has
+            for (int k = 0; k < kFusedShards; ++k)         // arrived (the selectors saw it), so nobody adds or reads the epoch any more
+                __hip_atomic_store(&st->arrive[k][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_word[2] = __float_as_uint(s);
+        s_word[3] = __float_as_uint(z);
         OSQ_FSTAMP(4);
     }
     __syncthreads();

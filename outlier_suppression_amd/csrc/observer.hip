@@ -6,6 +6,8 @@
 // Wave64 shuffle reductions, LDS across waves, and a last-workgroup finaliser so
 // that a whole observer call (reduce -> running statistic -> scale/zero_point) is
 // one launch for flat / per-channel tensors and two for masked activations.
+#include <cstdlib>
+#include <mutex>
 #include <string>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
@@ -802,7 +804,8 @@ static int g_obs_blocks = 768;
 static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
-static int g_fused_step = 1;          // osq_set_tuning("fused_step", 0): observe + fake-quant as three launches
+// osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
+static int g_fused_step = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_fused_gate = 1;          // osq_set_tuning("fused_gate", 0): padded tokens are loaded without waiting for the last arrival
 static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
@@ -1459,11 +1462,42 @@ static int fused_grid_for(const void* kernel) {
     return grid;
 }
 
+// Two fused launches must never be in flight together on one device: each wants every CU, and two half-resident
+// grids would spin on each other until their time-outs.  Launches of one stream are ordered anyway; when the stream
+// changes, the new stream first waits for everything the previous one has been given (one event, only at the switch).
+// Other PROCESSES sharing the GPU cannot be ordered from here: set OSQ_FUSED_STEP=0 there.
+static bool fused_serialize(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t last[64];
+    static hipEvent_t ev[64];
+    static bool used[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (used[dev] && last[dev] != st) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        hipStreamCaptureStatus co = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(last[dev], &co);
+        if (cs == hipStreamCaptureStatusNone && co == hipStreamCaptureStatusNone) {
+            if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventRecord(ev[dev], last[dev]) != hipSuccess || hipStreamWaitEvent(st, ev[dev], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+        }
+    }
+    used[dev] = true;
+    last[dev] = st;
+    return true;
+}
+
 template <int NV>
 static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) {
     static int grid = -1;       // per process; devices of one node are identical
     if (grid < 0 || g_fused_grid) grid = fused_grid_for(reinterpret_cast<const void*>(&observe_fq_fused_kernel<NV>));
     if (grid < 3) return false;
+    if (!fused_serialize(st)) return false;
     const TimingHook th = take_timing_hook(OSQ_TIME_FUSED_STEP);
     hipExtLaunchKernelGGL(observe_fq_fused_kernel<NV>, dim3(grid), dim3(kFusedThreads), 0, st, th.start, th.stop, 0, a, fin);
     return true;

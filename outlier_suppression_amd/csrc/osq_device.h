@@ -96,22 +96,27 @@ __device__ __forceinline__ void fq4_plain(const float4& v, float4& y, float4& q,
     y.w = dequantize_value(q.w, s, z);
 }
 
-// observer.py:101-119 for one entry (fp32)
+// torch.min / torch.max / torch.clamp propagate NaN; fminf / fmaxf drop it
+__device__ __forceinline__ float min_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b); }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+
+// observer.py:101-119 for one entry (fp32).  A NaN statistic (a NaN among the observed values) yields NaN
+// parameters, as in the reference: every step there is a NaN-propagating torch op.
 __device__ __forceinline__ void qparams_from_range(float mn, float mx, int quant_min, int quant_max, int symmetric,
                                                    float* scale_out, float* zp_out) {
-    const float min_neg = fminf(mn, 0.0f);
-    const float max_pos = fmaxf(mx, 0.0f);
+    const float min_neg = min_nan(mn, 0.0f);
+    const float max_pos = max_nan(mx, 0.0f);
     const float eps = 1e-8f;
     float scale, zp;
     if (symmetric) {
-        const float m = fmaxf(-min_neg, max_pos);
+        const float m = max_nan(-min_neg, max_pos);
         const float half = static_cast<float>(static_cast<double>(quant_max - quant_min) / 2.0);
-        scale = fmaxf(m / half, eps);
+        scale = max_nan(m / half, eps);
         zp = 0.0f;
     } else {
-        scale = fmaxf((max_pos - min_neg) / static_cast<float>(quant_max - quant_min), eps);
+        scale = max_nan((max_pos - min_neg) / static_cast<float>(quant_max - quant_min), eps);
         zp = static_cast<float>(quant_min) - rintf(min_neg / scale);
-        zp = fminf(fmaxf(zp, static_cast<float>(quant_min)), static_cast<float>(quant_max));
+        zp = min_nan(max_nan(zp, static_cast<float>(quant_min)), static_cast<float>(quant_max));
     }
     *scale_out = scale;
     *zp_out = zp;

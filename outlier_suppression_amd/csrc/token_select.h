@@ -39,7 +39,7 @@ struct SelectArgs {
 };
 
 #ifdef OSQ_FINAL_TIMING
-#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0 && stamps) stamps[k] = __builtin_readcyclecounter(); } while (0)
+#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0 && stamps) stamps[k] = wall_clock64(); } while (0)
 #else
 #define OSQ_SSTAMP(k) do { } while (0)
 #endif
@@ -75,7 +75,8 @@ struct SideResult {
 template <int R4, bool COMPACT>
 __device__ __forceinline__ SideResult select_side(const float* src, const int side, const int64_t aB, const int64_t aT,
                                                   const int64_t* lengths, const unsigned int compact_n, const int prune,
-                                                  const float aq, const int use_shortcut, SelShared& S, long long* stamps) {
+                                                  const float aq, const int use_shortcut, SelShared& S, long long* stamps,
+                                                  unsigned int* loaded_flag = nullptr, const unsigned int loaded_tag = 0u) {
     constexpr int R = 4 * R4;
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
@@ -195,6 +196,8 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
     }
     __syncthreads();
     OSQ_SSTAMP(2);
+    // every thread's loads have returned: the fused launch lets its streaming workgroups use the memory system again
+    if (loaded_flag && tid == 0) __hip_atomic_store(loaded_flag, loaded_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int N = S.s_n;
     if (N == 0u) return SideResult{0.0f, false, true};     // both sides agree: nothing observed
     const bool any_bad = S.s_bad != 0u;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
             finish_entry(fin, 0, cur_min, cur_max, have_state, st_min, st_max);
     }
 #ifdef OSQ_FINAL_TIMING
-    if (threadIdx.x == 0 && stamps) stamps[6] = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && stamps) stamps[6] = wall_clock64();
 #endif
 }
 

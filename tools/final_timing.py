@@ -1,4 +1,4 @@
-"""Development aid: phase timestamps (shader clocks, ~2.5 GHz) of the token finaliser, taken by thread 0 of the
+"""Development aid: phase timestamps (100 MHz wall clock) of the token finaliser, taken by thread 0 of the
 side-0 workgroup of token_select_kernel: [issue, loads + pass 0, histogram + scan, list + ranking, threshold,
 exchange + finish].  Needs the -DOSQ_FINAL_TIMING build: `make -C outlier_suppression_amd/csrc dbg`."""
 import ctypes, os, sys
@@ -20,4 +20,4 @@ for B in (32, 256):
             torch.cuda.synchronize()
         st = cur[2:2 + 14].view(torch.int64).cpu().tolist()
         d = [(st[i + 1] - st[i]) for i in range(6) if st[i + 1] and st[i]]
-        print(f"B={B} prune={prune} phase clocks:", d, "total", st[6] - st[0], f"= {(st[6] - st[0]) / 2500:.1f} us at 2.5 GHz")
+        print(f"B={B} prune={prune} phase us:", [x / 100 for x in d], "total", (st[6] - st[0]) / 100, "us")

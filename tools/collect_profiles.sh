@@ -7,7 +7,7 @@
 # Raw databases stay under gpurun_out/ (scratch); the summaries are written to gpurun_out/<tag>/ and
 # copied into profiles/ by hand (tracked).
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=$PWD/gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp

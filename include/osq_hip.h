@@ -328,10 +328,14 @@ int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int quant_min, 
  * each one launch that also advances the state machine; launches after convergence are no-ops.
  * done: copy the converged flag to done_out (device int32).  commit: running min/max
  * (observer.py:535-536) or running mean (observer.py:559-567) of the float64 statistics, then
- * calculate_qparams in float64 into scale_out / zero_point_out (nullable). */
+ * calculate_qparams in float64 into scale_out / zero_point_out (nullable).
+ * float64_input: the reference casts x to min_val's dtype (observer.py:524,549), and a per-tensor observer's min_val is
+ * float64 after its first call (observer.py:481,494) -- so from the second call on its whole search runs on a float64
+ * copy of x (float64 fake-quant, float64 mean, np.float64 function values).  1 selects that arithmetic; x stays the
+ * fp32 tensor, the kernels widen as they read. */
 size_t osq_msefast_state_bytes(void);
 int osq_msefast_tensor_begin(void* state, const float* cur_minmax, int quant_min, int quant_max,
-                             int symmetric, int one_side, int two_d, osq_stream stream);
+                             int symmetric, int one_side, int two_d, int float64_input, osq_stream stream);
 int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_t n, int n_evals,
                                   void* workspace, osq_stream stream);
 int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token_view* view,

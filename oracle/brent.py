@@ -20,9 +20,13 @@ _SQRT_EPS = math.sqrt(2.2e-16)
 class BoundedBrent:
     """Ask/tell form: ``x = b.start(); while not b.done: x = b.tell(f(x))``."""
 
-    def __init__(self, lo, hi, xatol=1e-5, maxiter=500):
+    def __init__(self, lo, hi, xatol=1e-5, maxiter=500, f32_values=False):
+        """f32_values: the objective returns np.float32 (the reference's loss_fx does, observer.py:431-432).  scipy then
+        forms ``fx - ffulc`` / ``fx - fnfc`` as float32 subtractions (numpy scalar arithmetic) before multiplying
+        by the float64 abscissa differences; everything else is float64 either way."""
         self.a, self.b = float(lo), float(hi)
         self.xatol, self.maxfun = xatol, maxiter
+        self.f32_values = f32_values
         self.done = False
         self.nfev = 0
 
@@ -47,8 +51,13 @@ class BoundedBrent:
         use_golden = True
         if abs(self.e) > tol1:
             use_golden = False
-            r = (xf - self.w) * (self.fx - self.fv)
-            q = (xf - self.v) * (self.fx - self.fw)
+            if self.f32_values:
+                import numpy as np
+                r = (xf - self.w) * float(np.float32(self.fx) - np.float32(self.fv))
+                q = (xf - self.v) * float(np.float32(self.fx) - np.float32(self.fw))
+            else:
+                r = (xf - self.w) * (self.fx - self.fv)
+                q = (xf - self.v) * (self.fx - self.fw)
             p = (xf - self.v) * q - (xf - self.w) * r
             q = 2.0 * (q - r)
             if q > 0.0:
@@ -114,9 +123,9 @@ class BoundedBrent:
         return self.fx
 
 
-def minimize_bounded(func, lo, hi, xatol=1e-5, maxiter=500):
+def minimize_bounded(func, lo, hi, xatol=1e-5, maxiter=500, f32_values=False):
     """Convenience driver.  Returns (x, f(x), nfev)."""
-    st = BoundedBrent(lo, hi, xatol, maxiter)
+    st = BoundedBrent(lo, hi, xatol, maxiter, f32_values)
     x = st.start()
     while x is not None:
         x = st.tell(func(x))

@@ -262,19 +262,39 @@ def observe_avg_prune_minmax(st, x, lengths=None, seq_pos=-1):
 # MSEFast (observer.py:412-567)
 # ---------------------------------------------------------------------------
 
+# How the squared errors are averaged.  The reference's ``.pow(2).mean()`` is torch's sum, whose order depends on the
+# build's vector width (ATen cascade_sum) -- not part of the algorithm.  Default: exact (float64) sum, rounded to the
+# tensor's dtype once; the device kernels do the same, so kernel and oracle agree bit for bit.  Tests that compare with
+# the reference RUN ON THE SAME MACHINE set ``MEAN_LIKE_TORCH = lambda sq: torch.from_numpy(sq).mean().numpy()`` to show
+# that the summation order is the only difference (tests/test_oracle_vs_reference_live.py).
+MEAN_LIKE_TORCH = None
+
+
 def mse_loss(x, new_min, new_max, quant_min, quant_max, symmetric):
     """observer.py:423-432 ``loss_fx`` + ``lp_loss`` (p=2).
 
-    ``new_min/new_max`` arrive as float64 (scipy), so qparams are float64; the
-    scale reaches the fake-quant as a Python float and is applied in fp32; the
-    zero-point is truncated with ``int()``.  Loss is the fp32 mean of squared
-    error (accumulated here in float64 and rounded once; torch's fp32 summation
-    order is not part of the reference).
+    ``new_min/new_max`` arrive as float64 (scipy), so qparams are float64; the scale reaches the fake-quant as a
+    Python float and the zero-point is truncated with ``int()``.  x is fp32 -- scale applied in fp32, np.float32
+    loss, which scipy's bounded minimiser then subtracts in float32 -- or float64: a per-tensor observer casts x to
+    ``min_val``'s dtype (observer.py:524,549), and ``min_val`` is float64 after the first call (observer.py:481,494),
+    so from the second call on the reference does all of this in float64.
     """
-    x = np.asarray(x, dtype=F32)
+    x = np.asarray(x)
     scale, zp = calculate_qparams(np.float64(new_min), np.float64(new_max), quant_min, quant_max, symmetric)
+    if x.dtype == np.float64:
+        s, z = np.float64(float(scale)), np.float64(int(zp))
+        with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+            u = x / s
+            x_int = ((np.round(u) - u) + u) + z
+            y = (np.clip(x_int, np.float64(quant_min), np.float64(quant_max)) - z) * s
+            d = np.abs(y - x)
+            sq = d * d
+        return np.float64(MEAN_LIKE_TORCH(sq)) if MEAN_LIKE_TORCH is not None else np.float64(sq.mean())
+    x = x.astype(F32, copy=False)
     _, y = fake_quantize_per_tensor_affine(x, F32(float(scale)), F32(int(zp)), quant_min, quant_max)
     d = np.abs(y - x)
+    if MEAN_LIKE_TORCH is not None:
+        return F32(MEAN_LIKE_TORCH(d * d))
     return F32((d * d).astype(np.float64).mean())
 
 
@@ -323,7 +343,8 @@ def msefast_search_2d(x, x_min, x_max, st, counter=None):
     def range_loss(xr):
         return minimize_scalar(shift_loss, args=(xr,), bounds=shift_bounds(xr), method="Bounded").fun
 
-    xr0 = float(F32(x_max) - F32(x_min))  # fp32 subtraction of the observed extrema (observer.py:459)
+    # observer.py:459: x_max - x_min in the tensor's dtype (fp32 extrema; float64 from a per-tensor observer's second call on)
+    xr0 = float(x_max - x_min) if np.asarray(x).dtype == np.float64 else float(F32(x_max) - F32(x_min))
     res = minimize_scalar(range_loss, bounds=(min(0.1, 0.01 * xr0), xr0), method="Bounded")
     final_range = res.x
     sub = minimize_scalar(shift_loss, args=(final_range,), bounds=shift_bounds(final_range), method="Bounded")
@@ -342,6 +363,8 @@ def observe_msefast(st, x, lengths=None, seq_pos=-1, average=False, counter=None
     if x.size == 0:
         return
     x = _prepare(x, lengths, seq_pos)
+    if np.asarray(st.min_val).dtype == np.float64:     # observer.py:524 / 549: x.to(self.min_val.dtype)
+        x = x.astype(np.float64)
     if st.one_side_dist is None:
         st.one_side_dist = one_side_dist(x)
     search = msefast_search_1d if (st.one_side_dist != "no" or st.symmetric) else msefast_search_2d

@@ -67,7 +67,7 @@ SIGNATURES = {
     "osq_replay_statistics": (_I, [_P, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "osq_msefast_rows": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "osq_msefast_state_bytes": (ctypes.c_size_t, []),
-    "osq_msefast_tensor_begin": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "osq_msefast_tensor_begin": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "osq_msefast_tensor_evals_flat": (_I, [_P, _P, _L, _I, _P, _P]),
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),

@@ -13,8 +13,9 @@
 //     loss to the state machine and publishes the next candidate.  Launches are enqueued in
 //     chunks; a finished search turns the remaining launches of a chunk into no-ops.
 // Numerics follow the reference: candidates and qparams in float64 (scipy hands float64,
-// observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error and
-// its mean in fp32 (partial sums combined in float64).
+// observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error in
+// fp32, summed in float64 from the first addition on, the mean rounded to fp32 once (the
+// reference's torch mean is an fp32 sum whose order depends on the machine's vector width).
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -28,6 +29,7 @@ constexpr int kWavesPerBlock = kThreads / OSQ_WAVE;
 struct Brent {
     double a, b, v, w, xf, d, e, fx, fv, fw, xm, tol1, tol2, pending;
     int nfev, done, first;
+    int f32_values;      // the objective returns np.float32 (fp32 tensors): scipy subtracts such values in float32
 
     __device__ double start(double lo, double hi) {
         const double gold = 0.5 * (3.0 - 2.23606797749978969641);   // 0.5*(3 - sqrt(5))
@@ -50,8 +52,12 @@ struct Brent {
         bool golden = true;
         if (fabs(e) > tol1) {
             golden = false;
-            double r = (xf - w) * (fx - fv);
-            double q = (xf - v) * (fx - fw);
+            // The function values are fp32 numbers (np.float32 from loss_fx, observer.py:431-432), so scipy's
+            // `fx - ffulc` is an fp32 subtraction -- rounded when the two differ by more than a factor of two -- and
+            // only its product with the float64 abscissa difference is float64.  (float64 tensors -- the reference's
+            // per-tensor observers from their second call on, see Search::f64 -- give np.float64 values: plain float64.)
+            double r = (xf - w) * (f32_values ? static_cast<double>(static_cast<float>(fx) - static_cast<float>(fv)) : fx - fv);
+            double q = (xf - v) * (f32_values ? static_cast<double>(static_cast<float>(fx) - static_cast<float>(fw)) : fx - fw);
             double p = (xf - v) * q - (xf - w) * r;
             q = 2.0 * (q - r);
             if (q > 0.0) p = -p;
@@ -118,6 +124,11 @@ struct Search {
     double cand_min, cand_max;  // candidate range whose loss is wanted next
     double cur_range, best_min, best_max;
     int quant_min, quant_max, symmetric, side, two_d, phase, done, nfev;
+    // MSEFastObserver.forward casts its input to min_val's dtype (observer.py:524 / 549), and after the first
+    // per-tensor call min_val is the float64 tensor scipy's result was wrapped in (observer.py:481,494): from the
+    // second call on the reference runs the whole search on a float64 copy of x -- float64 fake-quant, float64 mean,
+    // np.float64 function values, float64 range x_max - x_min.  f64 = 1 selects that arithmetic.
+    int f64;
 
     __device__ void shift_bounds(double r, double* lo, double* hi) const {
         const double delta = r / static_cast<double>(quant_max - quant_min);
@@ -139,9 +150,11 @@ struct Search {
         shift_bounds(r, &lo, &hi);
         candidate_2d(inner.start(lo, hi));
     }
-    __device__ void init(float xmin_f, float xmax_f, int qmin, int qmax, int sym, int side_, int two_d_) {
+    __device__ void init(float xmin_f, float xmax_f, int qmin, int qmax, int sym, int side_, int two_d_, int f64_ = 0) {
         x_min = xmin_f; x_max = xmax_f;
         quant_min = qmin; quant_max = qmax; symmetric = sym; side = side_; two_d = two_d_;
+        f64 = f64_;
+        outer.f32_values = inner.f32_values = f64_ ? 0 : 1;
         phase = 0; done = 0; nfev = 0;
         best_min = x_min; best_max = x_max;
         if (!two_d) {
@@ -150,14 +163,13 @@ struct Search {
             const double lo = 0.01 * xr < 0.1 ? 0.01 * xr : 0.1;
             candidate_1d(outer.start(lo, xr));
         } else {
-            const float xr_f = xmax_f - xmin_f;                        // fp32 subtraction (observer.py:459)
-            const double xr = xr_f;
+            const float xr_f = xmax_f - xmin_f;                        // fp32 subtraction (observer.py:459) of fp32 extrema
+            const double xr = f64_ ? static_cast<double>(xmax_f) - static_cast<double>(xmin_f) : static_cast<double>(xr_f);
             const double lo = 0.01 * xr < 0.1 ? 0.01 * xr : 0.1;
             begin_inner(outer.start(lo, xr));
         }
     }
-    __device__ void tell(float loss_f) {
-        const double f = loss_f;
+    __device__ void tell(double f) {       // f: the loss as the reference's objective returns it (an fp32 value unless f64)
         ++nfev;
         if (!two_d) {
             const double r = outer.tell(f);
@@ -187,7 +199,8 @@ struct Search {
 };
 
 // observer.py:101-119 in float64, then what loss_fx hands to the fake-quant (observer.py:426-429)
-__device__ __forceinline__ void loss_qparams(double mn, double mx, int qmin, int qmax, int sym, float* scale_f, float* zp_f) {
+__device__ __forceinline__ void loss_qparams(double mn, double mx, int qmin, int qmax, int sym, float* scale_f, float* zp_f,
+                                             double* scale_d = nullptr) {
     const double min_neg = mn < 0.0 ? mn : 0.0, max_pos = mx > 0.0 ? mx : 0.0;
     const double eps = static_cast<double>(1e-8f);
     double scale, zp = 0.0;
@@ -203,12 +216,37 @@ __device__ __forceinline__ void loss_qparams(double mn, double mx, int qmin, int
     }
     *scale_f = static_cast<float>(scale);
     *zp_f = static_cast<float>(static_cast<int>(zp));
+    if (scale_d) *scale_d = scale;        // scale.item() applied to a float64 tensor stays float64
 }
 
 __device__ __forceinline__ float sq_err(float x, float s, float z, float qmin, float qmax) {
     const float y = dequantize_value(quantize_value(x, s, z, qmin, qmax), s, z);
     const float d = fabsf(y - x);
     return d * d;
+}
+
+// the same chain on a float64 copy of x (util_quant.py:11-15 with float64 operands)
+__device__ __forceinline__ double sq_err_f64(float xf, double s, double z, double qmin, double qmax) {
+    const double x = xf;
+    const double u = x / s;
+    const double r = rint(u);
+    const double x_int = ((r - u) + u) + z;
+    double q = x_int;
+    q = (x_int < qmin) ? qmin : q;
+    q = (x_int > qmax) ? qmax : q;
+    const double y = (q - z) * s;
+    const double d = fabs(y - x);
+    return d * d;
+}
+__device__ __forceinline__ double sq_err4_f64(const float4& a, double s, double z, double qmin, double qmax) {
+    return (sq_err_f64(a.x, s, z, qmin, qmax) + sq_err_f64(a.y, s, z, qmin, qmax)) +
+           (sq_err_f64(a.z, s, z, qmin, qmax) + sq_err_f64(a.w, s, z, qmin, qmax));
+}
+
+// four squared errors, summed in float64 (see msefast_rows_kernel on why every addition is a float64 one)
+__device__ __forceinline__ double sq_err4(const float4& a, float s, float z, float qmin, float qmax) {
+    return (static_cast<double>(sq_err(a.x, s, z, qmin, qmax)) + static_cast<double>(sq_err(a.y, s, z, qmin, qmax))) +
+           (static_cast<double>(sq_err(a.z, s, z, qmin, qmax)) + static_cast<double>(sq_err(a.w, s, z, qmin, qmax)));
 }
 
 // ---------------------------------------------------------------- per-channel: one wave per row
@@ -243,18 +281,21 @@ __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __r
     while (!S.done) {
         float s, z;
         loss_qparams(S.cand_min, S.cand_max, quant_min, quant_max, symmetric, &s, &z);
-        float part = 0.0f;
+        // every squared error (an fp32 value) is added in float64 from the first addition on: the total is then the
+        // exact sum to ~1e-16 whatever the order, and its fp32-rounded mean is THE correctly rounded loss -- the same
+        // number oracle/observer_oracle.py::mse_loss computes, so the search is iterate-for-iterate the oracle's
+        double part = 0.0;
         if (MAXV > 0) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int j = lane + k * OSQ_WAVE;
-                if (j < cols) part += sq_err(cache[k], s, z, qmin_f, qmax_f);
+                if (j < cols) part += static_cast<double>(sq_err(cache[k], s, z, qmin_f, qmax_f));
             }
         } else {
-            for (int j = lane; j < cols; j += OSQ_WAVE) part += sq_err(xr[j], s, z, qmin_f, qmax_f);
+            for (int j = lane; j < cols; j += OSQ_WAVE) part += static_cast<double>(sq_err(xr[j], s, z, qmin_f, qmax_f));
         }
-        const double tot = wave_sum(static_cast<double>(part));
-        S.tell(static_cast<float>(tot / static_cast<double>(cols)));
+        const double tot = wave_sum(part);
+        S.tell(static_cast<double>(static_cast<float>(tot / static_cast<double>(cols))));
     }
     if (lane == 0) {
         best_min[row] = static_cast<float>(S.best_min);    // assignment into fp32 tensors (observer.py:504,516)
@@ -270,21 +311,24 @@ struct TensorSearch {
     float scale, zp;          // fake-quant parameters of the pending candidate
     int evals_launched;
     int pad;
+    double scale_d;           // the same scale before its fp32 rounding (float64 arithmetic, Search::f64)
 };
 
 __global__ void msefast_tensor_init_kernel(TensorSearch* __restrict__ ts, const float* __restrict__ cur_minmax,
-                                           int quant_min, int quant_max, int symmetric, int side, int two_d) {
+                                           int quant_min, int quant_max, int symmetric, int side, int two_d, int f64) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ts->S.init(cur_minmax[0], cur_minmax[1], quant_min, quant_max, symmetric, side, two_d);
-    loss_qparams(ts->S.cand_min, ts->S.cand_max, quant_min, quant_max, symmetric, &ts->scale, &ts->zp);
+    ts->S.init(cur_minmax[0], cur_minmax[1], quant_min, quant_max, symmetric, side, two_d, f64);
+    loss_qparams(ts->S.cand_min, ts->S.cand_max, quant_min, quant_max, symmetric, &ts->scale, &ts->zp, &ts->scale_d);
     ts->evals_launched = 0;
 }
 
 // last workgroup: loss -> state machine -> next candidate
 __device__ __forceinline__ void tensor_search_advance(TensorSearch* ts, double total, double count) {
-    ts->S.tell(static_cast<float>(total / count));
+    const double mean = total / count;
+    ts->S.tell(ts->S.f64 ? mean : static_cast<double>(static_cast<float>(mean)));
     if (!ts->S.done)
-        loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp);
+        loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
+                     &ts->scale_d);
 }
 
 __device__ __forceinline__ void block_sum_publish_finish(double part, double* partials, unsigned int* counters,
@@ -332,6 +376,8 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
                                                                      unsigned int* __restrict__ counters) {
     if (ts->S.done) return;                       // uniform: state only changes between launches
     const float s = ts->scale, z = ts->zp;
+    const double sd = ts->scale_d;
+    const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     double acc = 0.0;
@@ -339,14 +385,16 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
         const float4 a = x[i];
         const bool two = (i + stride) < n4;
         const float4 b = two ? x[i + stride] : a;
-        float p = sq_err(a.x, s, z, qmin, qmax) + sq_err(a.y, s, z, qmin, qmax) + sq_err(a.z, s, z, qmin, qmax) +
-                  sq_err(a.w, s, z, qmin, qmax);
-        if (two)
-            p += sq_err(b.x, s, z, qmin, qmax) + sq_err(b.y, s, z, qmin, qmax) + sq_err(b.z, s, z, qmin, qmax) +
-                 sq_err(b.w, s, z, qmin, qmax);
-        acc += static_cast<double>(p);
+        if (f64) {
+            acc += sq_err4_f64(a, sd, z, qmin, qmax);
+            if (two) acc += sq_err4_f64(b, sd, z, qmin, qmax);
+        } else {
+            acc += sq_err4(a, s, z, qmin, qmax);
+            if (two) acc += sq_err4(b, s, z, qmin, qmax);
+        }
     }
-    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) acc += static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax));
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail)
+        acc += f64 ? sq_err_f64(xt[threadIdx.x], sd, z, qmin, qmax) : static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax));
     block_sum_publish_finish(acc, partials, counters, ts, static_cast<double>(n));
 }
 
@@ -359,6 +407,8 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
                                                                       const double* __restrict__ valid_count) {
     if (ts->S.done) return;
     const float s = ts->scale, z = ts->zp;
+    const double sd = ts->scale_d;
+    const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     const int64_t ntok = v.batch * v.tokens;
@@ -370,23 +420,23 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
         const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
         if (lengths && t >= lengths[b]) continue;
         const float* base = x + b * v.stride_batch + t * v.stride_token;
-        float p = 0.0f;
+        double p = 0.0;
         if (vec) {           // feat_inner contiguous, 16-byte aligned segments
             const int inner4 = static_cast<int>(v.feat_inner / 4);
             const int64_t F4 = v.feat_outer * inner4;
             for (int64_t j = lane; j < F4; j += OSQ_WAVE) {
                 const int64_t o = j / inner4, i = j - o * inner4;
                 const float4 a = reinterpret_cast<const float4*>(base + o * v.stride_outer)[i];
-                p += sq_err(a.x, s, z, qmin, qmax) + sq_err(a.y, s, z, qmin, qmax) + sq_err(a.z, s, z, qmin, qmax) +
-                     sq_err(a.w, s, z, qmin, qmax);
+                p += f64 ? sq_err4_f64(a, sd, z, qmin, qmax) : sq_err4(a, s, z, qmin, qmax);
             }
         } else {
             for (int64_t j = lane; j < F; j += OSQ_WAVE) {
                 const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
-                p += sq_err(base[o * v.stride_outer + i * v.stride_inner], s, z, qmin, qmax);
+                const float xv = base[o * v.stride_outer + i * v.stride_inner];
+                p += f64 ? sq_err_f64(xv, sd, z, qmin, qmax) : static_cast<double>(sq_err(xv, s, z, qmin, qmax));
             }
         }
-        acc += static_cast<double>(p);
+        acc += p;
     }
     block_sum_publish_finish(acc, partials, counters, ts, valid_count[0]);
 }
@@ -482,10 +532,11 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
 }
 
 extern "C" int osq_msefast_tensor_begin(void* state, const float* cur_minmax, int quant_min, int quant_max,
-                                        int symmetric, int one_side, int two_d, osq_stream stream) {
+                                        int symmetric, int one_side, int two_d, int float64_input, osq_stream stream) {
     OSQ_REQUIRE(state && cur_minmax, "msefast_tensor_begin: null pointer");
     hipLaunchKernelGGL(msefast_tensor_init_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       static_cast<TensorSearch*>(state), cur_minmax, quant_min, quant_max, symmetric, one_side, two_d);
+                       static_cast<TensorSearch*>(state), cur_minmax, quant_min, quant_max, symmetric, one_side, two_d,
+                       float64_input ? 1 : 0);
     return check_launch("msefast_tensor_begin");
 }
 

@@ -509,7 +509,7 @@ def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
 
 
 def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
-                   rule, cnt, min_val, max_val, sink=None, chunk=None):
+                   rule, cnt, min_val, max_val, sink=None, chunk=None, float64_input=False):
     """Per-tensor search (observer.py:497-499): loss launches are enqueued in chunks and the converged
     flag is read back once per chunk (the reference syncs on every evaluation).  min_val/max_val: float64."""
     lib = _hip.load()
@@ -518,7 +518,8 @@ def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symm
     state = torch.zeros(int(lib.osq_msefast_state_bytes()), dtype=torch.uint8, device=dev)
     ws = _hip.workspace(dev)
     _hip.check(lib.osq_msefast_tensor_begin(_hip.ptr(state), _hip.ptr(cur), int(quant_min), int(quant_max),
-                                            int(bool(symmetric)), SIDE[one_side], int(bool(two_d)), st), "msefast_begin")
+                                            int(bool(symmetric)), SIDE[one_side], int(bool(two_d)), int(bool(float64_input)), st),
+               "msefast_begin")
     if observation_mask is not None or not is_dense(x):
         lengths = observation_mask
         if lengths is not None and lengths.dtype != torch.int64:

@@ -218,12 +218,16 @@ class MSEFastObserver(ObserverBase):
         self._decide_side(cur)
         two_d = not (self.one_side_dist != "no" or self.symmetric)
         if self.ch_axis == -1:
+            # observer.py:524 / 549: x is cast to min_val's dtype, and min_val is float64 once a per-tensor search has
+            # stored its (float64) result -- from the second call on the reference searches on a float64 copy of x
+            float64_input = self.min_val.dtype == torch.float64
             if self.min_val.dtype != torch.float64 or self.min_val.device != x.device:
                 self.min_val = self.min_val.to(device=x.device, dtype=torch.float64)
                 self.max_val = self.max_val.to(device=x.device, dtype=torch.float64)
             self.last_nfev = ops.msefast_tensor(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
                                                 self.symmetric, self.one_side_dist, two_d, self.update_rule,
-                                                self._counter(), self.min_val, self.max_val, sink)
+                                                self._counter(), self.min_val, self.max_val, sink,
+                                                float64_input=float64_input)
         else:
             bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
                                                           self.symmetric, self.one_side_dist, two_d)

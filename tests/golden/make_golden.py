@@ -298,6 +298,37 @@ def gen_msefast():
     save("msefast", **out)
 
 
+MSEFAST_ROW_CASES = (("w768", 901, 2048, 768, 4), ("w3072", 902, 2048, 3072, 4), ("w768_6bit", 903, 1024, 768, 6))
+
+
+def msefast_row_weights(seed, rows, cols):
+    """The seeded weight matrix of a MSEFAST_ROW_CASES entry (the tests rebuild it from the seed: only the
+    reference's per-row results are stored)."""
+    return torch.randn(rows, cols, generator=torch.Generator().manual_seed(seed)) * 0.05
+
+
+def gen_msefast_rows():
+    """BERT-base row sizes (768 / 3072 columns), thousands of rows, per-channel symmetric MSEFastObserver: the
+    reference's own per-row (min, max) for the deviation statistics of tests/test_gpu_parity.py
+    ::test_msefast_rows_against_reference and tests/test_oracle_golden.py (observer.py:496-517)."""
+    out = {}
+    for name, seed, rows, cols, bit in MSEFAST_ROW_CASES:
+        w = msefast_row_weights(seed, rows, cols)
+        ob = O.MSEFastObserver(bit=bit, symmetric=True, ch_axis=0)
+        nfev = [0]
+        orig = ob.loss_fx
+
+        def counted(*a, _orig=orig, **kw):
+            nfev[0] += 1
+            return _orig(*a, **kw)
+        ob.loss_fx = counted
+        ob(w)
+        out[name + "_min"], out[name + "_max"] = ob.min_val.numpy().copy(), ob.max_val.numpy().copy()
+        out[name + "_info"] = np.array([seed, rows, cols, bit, nfev[0]])
+        print(name, "nfev", nfev[0])
+    save("msefast_rows", **out)
+
+
 # ---------------------------------------------------------------------------
 # A7/A8/A17/A18: module-level traces through Quantizer / state togglers
 # ---------------------------------------------------------------------------
@@ -442,11 +473,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "other":
         gen_other_observers()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "msefast_rows":
+        gen_msefast_rows()
+        sys.exit(0)
     gen_fake_quant()
     gen_lsqplus()
     gen_qparams()
     gen_observers()
     gen_msefast()
+    gen_msefast_rows()
     gen_modules()
     gen_gamma()
     gen_other_observers()

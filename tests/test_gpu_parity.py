@@ -594,10 +594,10 @@ def test_empty_and_errors(dev):
 # ----------------------------------------------------------------------------------- MSEFast
 
 def test_msefast_golden(golden, dev):
-    """Device-side bounded Brent against the reference's scipy-driven search.  The search compares
-    fp32 losses whose summation order differs (torch CPU vs wave-parallel), so iterates part ways
-    late: ranges agree to <5e-4 relative (the NumPy oracle itself is 6e-5 from the reference),
-    evaluation counts to ~35 %."""
+    """Device-side bounded Brent against the reference's scipy-driven search on the reference-generated fixture.
+    The one difference left is the order of the fp32 sum inside the loss's mean (torch's is the build machine's,
+    the kernels sum exactly and round once, like the oracle): ranges within 5e-4, evaluation counts within 35 %.
+    Against the ORACLE the kernels are exact: test_msefast_equals_oracle."""
     from outlier_suppression_amd.quantization.quantized_module import ObserverDict
     g = golden("msefast")
     for k in range(int(g["n"])):
@@ -617,36 +617,108 @@ def test_msefast_golden(golden, dev):
         assert abs(total - nfev) <= max(6, 0.35 * nfev), (cls, total, nfev)
 
 
-def test_msefast_loss_is_not_worse_than_oracle(dev):
-    """At the returned range the quantisation MSE must match the oracle's optimum (the quantity the
-    observer minimises), for weights of BERT-base row lengths and a masked activation."""
+def test_msefast_equals_oracle(dev):
+    """Iterate for iterate: per-channel rows of BERT-base lengths (768, 3072), short and ragged rows, a row longer than
+    the register cache; per-tensor 1-D and nested 2-D searches over a masked activation, two batches each (the
+    second one runs on a float64 copy of x in the reference, observer.py:524,549).  Ranges bit-equal, evaluation
+    counts equal."""
     from outlier_suppression_amd.quantization.observer import MSEFastObserver, AvgMSEFastObserver
     from oracle import observer_oracle as OB
     gen = torch.Generator().manual_seed(8)
-    for cols, bit in ((768, 4), (3072, 4), (200, 6), (3100, 4)):
-        w = torch.randn(6, cols, generator=gen) * 0.05
+    for cols, bit, rows in ((768, 4, 48), (3072, 4, 24), (200, 6, 24), (3100, 4, 6), (96, 4, 24), (768, 6, 16)):
+        w = torch.randn(rows, cols, generator=gen) * 0.05
         ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
         ob(w.to(dev))
         st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
-        OB.observe_msefast(st, w.numpy())
-        np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=5e-4)
-        np.testing.assert_allclose(N(ob.min_val), st.min_val, rtol=5e-4)
-        for c in range(6):
-            ours = OB.mse_loss(w[c].numpy(), N(ob.min_val)[c], N(ob.max_val)[c], st.quant_min, st.quant_max, True)
-            ref = OB.mse_loss(w[c].numpy(), st.min_val[c], st.max_val[c], st.quant_min, st.quant_max, True)
-            assert ours <= ref * (1 + 2e-3)
+        counter = [0]
+        OB.observe_msefast(st, w.numpy(), counter=counter)
+        assert np.array_equal(N(ob.max_val), st.max_val) and np.array_equal(N(ob.min_val), st.min_val), (cols, bit)
+        assert int(ob.last_nfev.sum().item()) == counter[0], (cols, bit)
+    # one-sided weights (post-ReLU style rows) and asymmetric per-channel (nested search per row)
+    w = torch.rand(12, 256, generator=gen) * 0.3
+    for sym, data in ((False, w), (False, -w), (False, torch.randn(8, 128, generator=gen) * 0.1)):
+        ob = MSEFastObserver(bit=4, symmetric=sym, ch_axis=0).to(dev)
+        ob(data.to(dev))
+        st = OB.ObserverState(bit=4, symmetric=sym, ch_axis=0)
+        OB.observe_msefast(st, data.numpy())
+        assert np.array_equal(N(ob.max_val), st.max_val) and np.array_equal(N(ob.min_val), st.min_val)
     x = torch.randn(8, 32, 96, generator=gen)
     x[..., 3] *= 12
     L = torch.randint(4, 33, (8,), generator=gen)
+    for cls, avg in ((AvgMSEFastObserver, True), (MSEFastObserver, False)):
+        for sym in (True, False):
+            for masked in (True, False):
+                ob = cls(bit=6, symmetric=sym).to(dev)
+                st = OB.ObserverState(bit=6, symmetric=sym)
+                for it in range(3):
+                    xi = x * (it + 1)
+                    counter = [0]
+                    if masked:
+                        ob(xi.to(dev), L.to(dev), 1)
+                        OB.observe_msefast(st, xi.numpy(), L.numpy(), 1, average=avg, counter=counter)
+                    else:
+                        ob(xi.to(dev))
+                        OB.observe_msefast(st, xi.numpy(), average=avg, counter=counter)
+                    if it == 0:      # fp32 arithmetic: exact
+                        assert float(N(ob.min_val)) == float(st.min_val) and float(N(ob.max_val)) == float(st.max_val)
+                        assert int(ob.last_nfev.sum().item()) == counter[0], (cls.__name__, sym, masked)
+                    else:
+                        # float64 arithmetic from the second call on (observer.py:524,549).  A float64 sum of float64
+                        # squares carries its order in its last bits, and near the minimum of a staircase loss
+                        # candidates tie to that precision: mostly 1e-12 apart, now and then a neighbouring step -- and
+                        # the nested 2-D search amplifies it.  Measured on these very inputs with the ORACLE alone,
+                        # summing the same squares pairwise (NumPy) / in torch's order / left to right / right to
+                        # left: up to 7e-4 between orders for the 1-D search, up to 1.3e-2 for the 2-D one.
+                        np.testing.assert_allclose(N(ob.min_val), st.min_val, rtol=2e-3 if sym else 3e-2)
+                        np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=2e-3 if sym else 3e-2)
+                assert (not avg) or ob.cnt == 3
+    # the float64 arithmetic on its own: observers whose statistics are float64 before their first call, fresh per batch,
+    # so that the search result itself (not a running statistic) is compared -- and, where a tie broke the other way,
+    # the objective: the kernel's range must be as good as the oracle's
     for sym in (True, False):
-        ob = AvgMSEFastObserver(bit=6, symmetric=sym).to(dev)
-        st = OB.ObserverState(bit=6, symmetric=sym)
-        for it in range(2):
-            ob(x.to(dev) * (it + 1), L.to(dev), 1)
-            OB.observe_msefast(st, x.numpy() * (it + 1), L.numpy(), 1, average=True)
-            np.testing.assert_allclose(N(ob.min_val), st.min_val, rtol=1e-3, atol=1e-5)
-            np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=1e-3, atol=1e-5)
-        assert ob.cnt == 2
+        for it in range(3):
+            xi = x * (1.0 + 0.37 * it)
+            ob = MSEFastObserver(bit=6, symmetric=sym).to(dev)
+            ob.min_val, ob.max_val = ob.min_val.double(), ob.max_val.double()
+            st = OB.ObserverState(bit=6, symmetric=sym)
+            st.min_val, st.max_val = np.asarray(np.float64(np.inf)), np.asarray(np.float64(-np.inf))
+            ob(xi.to(dev), L.to(dev), 1)
+            OB.observe_msefast(st, xi.numpy(), L.numpy(), 1)
+            v = OB.remove_padding(xi.numpy(), L.numpy(), 1).astype(np.float64)
+            ours = OB.mse_loss(v, float(N(ob.min_val)), float(N(ob.max_val)), st.quant_min, st.quant_max, sym)
+            ref = OB.mse_loss(v, float(st.min_val), float(st.max_val), st.quant_min, st.quant_max, sym)
+            assert ours <= ref * (1 + 1e-3), (sym, it, ours, ref)
+            np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=2e-3 if sym else 3e-2)
+
+
+@pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
+def test_msefast_rows_against_reference(golden, name, dev):
+    """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;
+    tests/golden/make_golden.py::gen_msefast_rows): how far the kernel's ranges are from the reference's, and what that
+    does to the integers.  Measured: median relative range error 2e-5, 99th percentile 2e-4, x_quant entries that
+    differ 1.5e-5 .. 4e-5 of all entries.  (The kernel equals the oracle exactly; the oracle equals the reference
+    exactly once its loss is summed in torch's order: tests/test_oracle_vs_reference_live.py.)"""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    from _msefast_rows import MSEFAST_ROW_BOUNDS, msefast_row_weights
+    g = golden("msefast_rows")
+    seed, rows, cols, bit, ref_nfev = (int(v) for v in g[name + "_info"])
+    w = torch.from_numpy(msefast_row_weights(seed, rows, cols)).to(dev)
+    ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
+    ob(w)
+    ref_min, ref_max = T(g[name + "_min"], dev), T(g[name + "_max"], dev)
+    rel = ((ob.max_val - ref_max).abs() / ref_max).cpu().numpy()
+    b = MSEFAST_ROW_BOUNDS
+    assert np.median(rel) <= b["median_rel"] and np.quantile(rel, 0.99) <= b["p99_rel"] and rel.max() <= b["max_rel"], \
+        (np.median(rel), np.quantile(rel, 0.99), rel.max())
+    qmin, qmax = ob.quant_min, ob.quant_max
+    s_a, z_a = ob.calculate_qparams(ob.min_val, ob.max_val)
+    s_b, z_b = ob.calculate_qparams(ref_min, ref_max)
+    _, xa = ops.fake_quant_per_channel(w, s_a, z_a, 0, qmin, qmax, return_quantized=True)
+    _, xb = ops.fake_quant_per_channel(w, s_b, z_b, 0, qmin, qmax, return_quantized=True)
+    mismatch = (xa != xb).float().mean().item()
+    assert mismatch <= b["xquant_mismatch"], mismatch
+    assert abs(int(ob.last_nfev.sum().item()) - ref_nfev) <= 0.02 * ref_nfev
 
 
 def test_msefast_through_quantizer(dev):
@@ -665,14 +737,7 @@ def test_msefast_through_quantizer(dev):
     st = OB.ObserverState(bit=4, symmetric=True, ch_axis=0)
     OB.observe_msefast(st, lin.weight.detach().numpy())
     s_o, _ = st.qparams()
-    # short rows have a staircase loss with several near-equal minima: a row may settle in a neighbouring
-    # one, so the bar is the objective itself (quantisation MSE at the returned range), not the range
-    w = lin.weight.detach().numpy()
-    for c in range(10):
-        ours = OB.mse_loss(w[c], N(fq.observer.min_val)[c], N(fq.observer.max_val)[c], -8, 7, True)
-        ref = OB.mse_loss(w[c], st.min_val[c], st.max_val[c], -8, 7, True)
-        assert ours <= ref * 1.01, (c, ours, ref)
-    assert np.mean(np.isclose(N(fq.scale), s_o, rtol=5e-4)) >= 0.8
+    assert np.array_equal(N(fq.observer.max_val), st.max_val) and np.array_equal(N(fq.scale), s_o)
     assert fq.scale.shape == (10,) and fq.zero_point.dtype == torch.int32
 
 

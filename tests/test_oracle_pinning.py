@@ -66,6 +66,28 @@ def test_bounded_brent_matches_scipy_iterates(idx):
     assert x == float(res.x) and fx == float(res.fun)
 
 
+@pytest.mark.parametrize("idx", range(len(FUNCS)))
+def test_bounded_brent_matches_scipy_with_float32_values(idx):
+    """The reference's objective returns np.float32 (observer.py:431-432): scipy then subtracts function values in
+    float32.  Offsets spread the values over more than a factor of two so that those subtractions do round."""
+    f, (lo, hi) = FUNCS[idx]
+    for offset in (0.0, 3.0, -7.5):
+        seen, mine = [], []
+
+        def wrapped(x):
+            seen.append(float(x))
+            return np.float32(f(x) + offset)
+        res = minimize_scalar(wrapped, bounds=(lo, hi), method="Bounded")
+
+        def wrapped2(x):
+            mine.append(float(x))
+            return np.float32(f(x) + offset)
+        x, fx, nfev = minimize_bounded(wrapped2, lo, hi, f32_values=True)
+        assert nfev == res.nfev
+        assert mine == seen
+        assert x == float(res.x) and fx == float(res.fun)
+
+
 def test_bounded_brent_ask_tell_and_maxiter():
     st = BoundedBrent(0.0, 1.0, maxiter=5)
     x = st.start()

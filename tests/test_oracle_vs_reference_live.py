@@ -129,3 +129,34 @@ def test_lsqplus_forward_backward_random_cases(ref):
         assert np.array_equal(_bits(dx), _bits(x.grad.numpy())), (trial, "dx")
         np.testing.assert_allclose(ds, scale.grad.item(), rtol=3e-5, atol=1e-7)
         np.testing.assert_allclose(dz, zp.grad.item(), rtol=3e-5, atol=1e-7)
+
+
+def test_msefast_equals_reference_when_the_loss_is_summed_like_torch(ref):
+    """MSEFast, per-channel and per-tensor (1-D and nested 2-D searches): with torch's own fp32 mean plugged into the
+    oracle's loss -- the one step whose order is the machine's, not the algorithm's -- the oracle reproduces the
+    reference's ranges bit for bit and spends the same number of loss evaluations.  Everything else (float64
+    qparams, fp32 fake-quant, np.float32 function values inside scipy's bounded minimiser) is restated exactly."""
+    O, _ = ref
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(77)
+    old = OB.MEAN_LIKE_TORCH
+    OB.MEAN_LIKE_TORCH = lambda sq: torch.from_numpy(np.ascontiguousarray(sq)).mean().numpy()
+    try:
+        for cols, bit in ((768, 4), (3072, 4), (96, 6)):
+            w = torch.randn(24, cols, generator=gen) * 0.05
+            ob = O.MSEFastObserver(bit=bit, symmetric=True, ch_axis=0)
+            ob(w)
+            st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
+            OB.observe_msefast(st, w.numpy())
+            assert np.array_equal(st.min_val, ob.min_val.numpy()) and np.array_equal(st.max_val, ob.max_val.numpy()), cols
+        for sym, shape in ((True, (4, 16, 32)), (False, (4, 16, 32)), (False, (2, 8, 64))):
+            x = torch.randn(*shape, generator=gen)
+            x[..., 1] *= 9.0
+            ob = O.AvgMSEFastObserver(bit=6, symmetric=sym, ch_axis=-1)
+            st = OB.ObserverState(bit=6, symmetric=sym)
+            for it in range(2):
+                ob(x * (it + 1))
+                OB.observe_msefast(st, x.numpy() * (it + 1), average=True)
+                assert float(st.min_val) == float(ob.min_val) and float(st.max_val) == float(ob.max_val), (sym, shape, it)
+    finally:
+        OB.MEAN_LIKE_TORCH = old

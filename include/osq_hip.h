@@ -307,6 +307,25 @@ int osq_replay_statistics(const float* table, int n_batches, int n_quantizers, c
                           const uint64_t* scale_ptrs, const uint64_t* zp_ptrs, const int32_t* zp_types,
                           osq_stream stream);
 
+/* Every weight of a model in ONE launch (quantized_module.py:71-72, 97-100 fake-quantise each weight in its own op on
+ * every forward).  descs / row_end: DEVICE arrays of n_tensors entries; tensor i is x[rows, inner] (row-major, inner % 4
+ * == 0, 16-byte aligned) -> y, quantised per row with scale[row % channels] / zero_point[row % channels] (channels == 1:
+ * per-tensor); row_end[i] = rows of tensors 0..i.  mode / grad_factor as in osq_fake_quant_per_channel (no
+ * OSQ_PARAM_SANITIZE).  Same arithmetic as the per-tensor calls: bit-identical outputs. */
+typedef struct osq_weight_desc {
+    const float* x;
+    float* y;
+    const float* scale;
+    const void* zero_point;
+    int64_t rows, channels, inner;
+    int32_t zp_type, mode;
+    float grad_factor;
+    int32_t quant_min, quant_max;
+    int32_t pad;
+} osq_weight_desc;
+int osq_fake_quant_weights_multi(const osq_weight_desc* descs, const int64_t* row_end, int n_tensors,
+                                 int64_t total_rows, osq_stream stream);
+
 /* ------------------------------------------------------------------ MSEFast (observer.py:412-567) */
 
 /* one_side: 0 = 'no', 1 = 'pos', 2 = 'neg' (observer.py:528-529, decided once by the caller on

@@ -34,6 +34,13 @@ class TokenView(ctypes.Structure):
                                   "stride_batch", "stride_token", "stride_outer", "stride_inner")]
 
 
+class WeightDesc(ctypes.Structure):
+    """``osq_weight_desc``: one entry of the table of osq_fake_quant_weights_multi."""
+    _fields_ = [("x", _P), ("y", _P), ("scale", _P), ("zero_point", _P), ("rows", _L), ("channels", _L), ("inner", _L),
+                ("zp_type", ctypes.c_int32), ("mode", ctypes.c_int32), ("grad_factor", _F), ("quant_min", ctypes.c_int32),
+                ("quant_max", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); one entry per symbol declared in include/osq_hip.h
 SIGNATURES = {
     "osq_last_error": (ctypes.c_char_p, []),
@@ -49,6 +56,7 @@ SIGNATURES = {
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
                                                _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_fake_quant_weights_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_lsq_backward_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P]),
     "osq_lsq_backward_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "osq_lsq_sanitize": (_I, [_P, _P, _L, _F, _I, _I, _P]),

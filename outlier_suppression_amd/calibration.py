@@ -53,10 +53,23 @@ def act_quantizers(model, select=lambda name: "act" in name):
     return [(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and select(n)]
 
 
+def _require_capture_support(quantizers, what):
+    """Sharded / cached calibration records each batch's (min, max) and replays the observers' update rules later.
+    Observers that keep their own state (MSEFast / MSE searches with float64 statistics, AvgQuantile, LSQPlusObserver)
+    neither fill the capture slot nor fit the fp32 replay: refuse instead of folding zeros into their statistics."""
+    for name, q in quantizers:
+        obs = q.observer
+        if not getattr(obs, "supports_capture", False) or obs.min_val.dtype != torch.float32 or obs.ch_axis != -1:
+            raise NotImplementedError(
+                f"{what}: {type(obs).__name__} at '{name}' cannot be recorded per batch and replayed "
+                "(per-tensor MinMax / AvgMinMax / AvgPruneMinMax observers only); calibrate it with the plain loop")
+
+
 class CaptureTable:
     """Per-batch (min, max) of every selected observer, recorded instead of being averaged."""
 
     def __init__(self, quantizers, rows, device):
+        _require_capture_support(quantizers, "sharded calibration")
         self.quantizers = quantizers
         self.table = torch.zeros(rows, len(quantizers), 2, dtype=torch.float32, device=device)
 
@@ -76,6 +89,7 @@ class ReplayPlan:
     The tensors behind the addresses are kept alive (and never reallocated) by the plan."""
 
     def __init__(self, quantizers, device):
+        _require_capture_support(quantizers, "statistics replay")
         self.quantizers = quantizers
         self.device = device
         obs = [q.observer for _, q in quantizers]
@@ -124,6 +138,8 @@ class ReplayPlan:
         if len(cnts) != 1:
             raise RuntimeError("replay: observers disagree on their batch counter")
         cnt0 = cnts.pop()
+        for _, q in self.quantizers:          # the launch writes scale / zero_point through raw pointers
+            q._touch_qparams()
         table = ordered.contiguous()
         lib = _hip.load()
         _hip.check(lib.osq_replay_statistics(table.data_ptr(), int(n_batches), int(n_q), self.rules.data_ptr(), int(cnt0),

@@ -5,6 +5,7 @@
 // elementwise passes.  Bandwidth-bound: 16-byte global loads/stores per lane,
 // four independent 16-byte loads in flight per lane before any arithmetic,
 // grid sized to a few waves per SIMD and grid-strided above that.
+#include <algorithm>
 #include <string>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
@@ -207,6 +208,53 @@ __global__ __launch_bounds__(kThreads) void fq_channel_generic_kernel(
         const float q = quantize_value(x[i], p.scale, p.zp, qmin, qmax);
         y[i] = dequantize_value(q, p.scale, p.zp);
         if (WRITE_Q) xq[i] = q;
+    }
+}
+
+// ---------------------------------------------------------------- many weights, one launch
+
+// The reference fake-quantises every weight of the model on every forward (quantized_module.py:71-72, 97-100:
+// 77 launches for BERT-base).  Here one launch serves a table of weights: wave = one row of one tensor, found by
+// bisection over the table's running row counts; per-row (scale, zero_point) as in fq_channel_rows_kernel
+// (channels == 1: the per-tensor form).  The host keeps the result while weight and parameters are unchanged
+// (quantization/weight_cache.py), so a frozen model pays this launch once, not per forward.
+__global__ __launch_bounds__(kThreads) void fq_weights_multi_kernel(const osq_weight_desc* __restrict__ descs,
+                                                                    const int64_t* __restrict__ row_end, int n,
+                                                                    int64_t total_rows) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kThreads / OSQ_WAVE);
+    for (int64_t g = wave; g < total_rows; g += nwaves) {
+        int lo = 0, hi = n - 1;                       // first tensor whose row_end exceeds g
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (row_end[mid] > g) hi = mid; else lo = mid + 1;
+        }
+        const osq_weight_desc d = descs[lo];
+        const int64_t r = g - (lo ? row_end[lo - 1] : 0);
+        const int64_t c = d.channels == 1 ? 0 : r % d.channels;
+        const QParams p = effective_params(d.scale[c], load_zp(d.zero_point, d.zp_type, c), d.mode, d.grad_factor);
+        const float qmin = static_cast<float>(d.quant_min), qmax = static_cast<float>(d.quant_max);
+        const int inner4 = static_cast<int>(d.inner / 4);
+        const float4* xr = reinterpret_cast<const float4*>(d.x) + r * inner4;
+        float4* yr = reinterpret_cast<float4*>(d.y) + r * inner4;
+        int j = lane;
+        for (; j + (kUnroll - 1) * OSQ_WAVE < inner4; j += kUnroll * OSQ_WAVE) {
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = xr[j + u * OSQ_WAVE];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                float4 o, q;
+                fq4<false>(v[u], o, q, p.scale, p.zp, qmin, qmax);
+                yr[j + u * OSQ_WAVE] = o;
+            }
+        }
+        for (; j < inner4; j += OSQ_WAVE) {
+            float4 o, q;
+            fq4<false>(xr[j], o, q, p.scale, p.zp, qmin, qmax);
+            yr[j] = o;
+        }
     }
 }
 
@@ -578,6 +626,17 @@ extern "C" int osq_lsq_sanitize(float* scale, float* zero_point, int64_t n, floa
                        static_cast<hipStream_t>(stream), scale, zero_point, n, eps, static_cast<float>(quant_min),
                        static_cast<float>(quant_max));
     return check_launch("lsq_sanitize");
+}
+
+extern "C" int osq_fake_quant_weights_multi(const osq_weight_desc* descs, const int64_t* row_end, int n_tensors,
+                                            int64_t total_rows, osq_stream stream) {
+    OSQ_REQUIRE(n_tensors >= 0 && total_rows >= 0, "fake_quant_weights_multi: negative size");
+    if (n_tensors == 0 || total_rows == 0) return OSQ_OK;
+    OSQ_REQUIRE(descs && row_end, "fake_quant_weights_multi: null table");
+    const int grid = static_cast<int>(std::min<int64_t>((total_rows + kThreads / OSQ_WAVE - 1) / (kThreads / OSQ_WAVE), kMaxBlocks * 4));
+    hipLaunchKernelGGL(fq_weights_multi_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), descs, row_end,
+                       n_tensors, total_rows);
+    return check_launch("fake_quant_weights_multi");
 }
 
 extern "C" int osq_set_tuning(const char* key, int value) {

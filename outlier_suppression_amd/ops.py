@@ -633,8 +633,15 @@ def mse_grid_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
 # gamma migration
 # ---------------------------------------------------------------------------------------
 
+# moved by every kernel of this package that writes a WEIGHT through its raw pointer (torch's ``_version`` does not see
+# those writes): cached fake-quantised weights (quantization/weight_cache.py) are keyed on it
+weight_epoch = 0
+
+
 def gamma_fold_(weight, gamma):
     """In place W[:, j] *= gamma[j] (gamma_migration.py:70-71)."""
+    global weight_epoch
+    weight_epoch += 1
     lib = _hip.load()
     _hip.require_device(weight, gamma)
     _check_f32(weight, gamma)

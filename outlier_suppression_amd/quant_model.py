@@ -29,4 +29,5 @@ def quantize_model(fp_model, w_qconfig, a_qconfig, backend="academic", is_remove
     fp_model.eval()
     model = _WRAPPERS[cls](copy.deepcopy(fp_model), w_qconfig, a_qconfig, qoutput=False, backend=backend,
                            is_remove_padding=is_remove_padding)
-    return model.eval()
+    from .quantization.weight_cache import adopt
+    return adopt(model.eval())

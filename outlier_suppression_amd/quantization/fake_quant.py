@@ -75,7 +75,13 @@ class QuantizeBase(nn.Module):
         s, z = self.scale, self.zero_point
         return (s.data if isinstance(s, nn.Parameter) else s), (z.data if isinstance(z, nn.Parameter) else z)
 
+    def _touch_qparams(self):
+        """A kernel is about to write scale / zero_point through raw pointers (torch's ``_version`` does not move):
+        anything derived from them -- the cached fake-quantised weight -- is stale."""
+        object.__setattr__(self, "_qparam_epoch", self.__dict__.get("_qparam_epoch", 0) + 1)
+
     def _observe(self, X, observation_mask, seq_pos):
+        self._touch_qparams()
         channels = 1 if self.ch_axis == -1 else X.shape[self.ch_axis]
         scale, zero_point = self._qparam_storage(X.device, channels)
         obs = self.observer
@@ -101,6 +107,7 @@ class QuantizeBase(nn.Module):
         prune = obs.token_path_prune()
         if prune is None:
             return None
+        self._touch_qparams()
         scale, zero_point = self._qparam_storage(X.device, 1)
         obs._home(X.device)
         gf = self._grad_factor(X) if self.param_mode != PARAM_FIXED else 1.0
@@ -186,6 +193,7 @@ class _LearnableFakeQuantize(QuantizeBase):
     def _sanitize(self):
         """fake_quant.py:152-153 / 188-191, one launch."""
         zp = self.zero_point.data if isinstance(self.zero_point, nn.Parameter) else None
+        self._touch_qparams()
         if self.scale.is_cuda:
             ops.lsq_sanitize_(self.scale.data, zp, self._eps_value, self.quant_min, self.quant_max)
         elif self.fake_quant_enabled == 1:

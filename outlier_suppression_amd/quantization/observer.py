@@ -28,6 +28,9 @@ class ObserverBase(nn.Module):
     """observer.py:24-119."""
 
     update_rule = UPDATE_RUNNING
+    # True for observers whose statistic is a per-batch (min, max) folded in by update_rule -- the ones sharded /
+    # cached calibration can record per batch (``_capture``) and replay later (calibration.py)
+    supports_capture = False
 
     def __init__(self, bit=8, symmetric=False, ch_axis=-1):
         super().__init__()
@@ -120,6 +123,8 @@ class ObserverBase(nn.Module):
 class MinMaxObserver(ObserverBase):
     """observer.py:122-145: running min / max over the calibration set; per-tensor or per-channel."""
 
+    supports_capture = True
+
     def token_path_prune(self):
         return False
 
@@ -135,6 +140,8 @@ class MinMaxObserver(ObserverBase):
 
 class AvgMinMaxObserver(ObserverBase):
     """observer.py:176-203: average of the per-batch min / max."""
+
+    supports_capture = True
 
     update_rule = UPDATE_AVERAGE
 
@@ -157,6 +164,8 @@ class AvgMinMaxObserver(ObserverBase):
 class AvgPruneMinMaxObserver(ObserverBase):
     """observer.py:206-237: token-wise clipping -- per-token extrema, percentile over tokens,
     clip range = extrema of the tokens inside the percentile; averaged over batches."""
+
+    supports_capture = True
 
     update_rule = UPDATE_AVERAGE
 

@@ -43,7 +43,12 @@ class QuantizedModule(nn.Module):
 
 
 class QuantizedOperator:
-    pass
+    """Marker base of the weight-quantized operators.  ``_quantized_weight`` is ``self.weight_fake_quant(self.weight)``
+    (quantized_module.py:72,98) served from quantization/weight_cache.py while weight and parameters are unchanged."""
+
+    def _quantized_weight(self):
+        from .weight_cache import quantized_weight
+        return quantized_weight(self)
 
 
 def _build_quantizer(cfg):
@@ -65,7 +70,7 @@ class QLinear(QuantizedOperator, nn.Linear):
         self.weight_fake_quant = WeightQuantizer(w_qconfig)
 
     def forward(self, input):
-        return F.linear(input, self.weight_fake_quant(self.weight), self.bias)
+        return F.linear(input, self._quantized_weight(), self.bias)
 
 
 class QConv2d(QuantizedOperator, nn.Conv2d):
@@ -77,7 +82,7 @@ class QConv2d(QuantizedOperator, nn.Conv2d):
         self.weight_fake_quant = WeightQuantizer(w_qconfig)
 
     def forward(self, input):
-        return self._conv_forward(input, self.weight_fake_quant(self.weight), self.bias)
+        return self._conv_forward(input, self._quantized_weight(), self.bias)
 
 
 class QEmbedding(QuantizedOperator, nn.Embedding):
@@ -89,7 +94,7 @@ class QEmbedding(QuantizedOperator, nn.Embedding):
         self.weight_fake_quant = WeightQuantizer(w_qconfig)
 
     def forward(self, input):
-        return F.embedding(input, self.weight_fake_quant(self.weight), self.padding_idx, self.max_norm,
+        return F.embedding(input, self._quantized_weight(), self.padding_idx, self.max_norm,
                            self.norm_type, self.scale_grad_by_freq, self.sparse)
 
 

@@ -275,14 +275,16 @@ int osq_set_wide_min_slots(int64_t slots);
  * extrema -- are identical for every candidate).  The caller keeps the per-token extrema of
  * every (quantizer, batch) pair: problem p = quantizer*n_batches + batch occupies
  * token_min/token_max[p*problem_stride ...], all with the same batch x tokens geometry;
- * lengths is [n_batches, batch]; prune_flags[quantizer] == 0 for 'attention_probs'
+ * lengths is [n_batches, batch] -- or, with lengths_per_quantizer, [n_quantizers, n_batches, batch]: sites of one model
+ * may be masked differently (BART's cross-attention keys see the DECODER lengths, quant_bart.py:167,172,472) --;
+ * prune_flags[quantizer] == 0 for 'attention_probs'
  * quantizers.  One launch re-thresholds all pairs for `percentile` and writes each pair's
  * (min, max) to cur_table[(batch_index*n_quantizers + quantizer)*2] -- per-batch statistics
  * that are then replayed in batch order with osq_observer_update.  `workspace` (nullable): with it,
  * and the layout rules of osq_token_range_finalize met, every pair gets two workgroups. */
 int osq_token_range_finalize_batched(const float* token_min, const float* token_max,
                                      int64_t problem_stride, int n_quantizers, int n_batches,
-                                     int64_t batch, int64_t tokens, const int64_t* lengths,
+                                     int64_t batch, int64_t tokens, const int64_t* lengths, int lengths_per_quantizer,
                                      const int32_t* prune_flags, double percentile,
                                      float* cur_table, void* workspace, osq_stream stream);
 

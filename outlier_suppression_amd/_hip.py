@@ -70,7 +70,7 @@ SIGNATURES = {
                                            _P, _L, _I, _F, _P, _P, _P]),
     "osq_fused_step_status": (_I, [_P, ctypes.POINTER(_I), _P]),
     "osq_set_wide_min_slots": (_I, [_L]),
-    "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _P, _D, _P, _P, _P]),
+    "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _I, _P, _D, _P, _P, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
     "osq_replay_statistics": (_I, [_P, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "osq_msefast_rows": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

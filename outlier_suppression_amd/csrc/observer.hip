@@ -459,6 +459,7 @@ struct FinalBatch {
     int64_t problem_stride;
     int n_batches, n_quantizers;
     const int* prune_flags;
+    int lengths_per_problem;      // lengths is [n_quantizers, n_batches, B] (every site its own mask) instead of [n_batches, B]
 };
 
 template <int SLOTS>
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         const int p = blockIdx.x, qi = p / fb.n_batches, bi = p - qi * fb.n_batches;
         tok_min += static_cast<int64_t>(p) * fb.problem_stride;
         tok_max += static_cast<int64_t>(p) * fb.problem_stride;
-        if (lengths) lengths += static_cast<int64_t>(bi) * B;
+        if (lengths) lengths += static_cast<int64_t>(fb.lengths_per_problem ? blockIdx.x : bi) * B;
         prune = fb.prune_flags ? fb.prune_flags[qi] : prune;
         fin.cur += 2 * (static_cast<int64_t>(bi) * fb.n_quantizers + qi);
     }
@@ -1389,7 +1390,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     const bool wide = batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune);
     if (!wide && workspace && select_fast_ok(token_min, token_max, batch, tokens, 0, 1)) {
         const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet(), g_select_shortcut};
-        launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr}, 1);
+        launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr, 0}, 1);
         return check_launch("token_range_finalize(select)");
     }
     if (wide) {
@@ -1404,7 +1405,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
         }
         return check_launch("token_range_finalize(wide)");
     }
-    const FinalBatch fb{0, 0, 0, nullptr};
+    const FinalBatch fb{0, 0, 0, nullptr, 0};
 #define OSQ_LAUNCH_FINAL(S)                                                                                        \
     hipLaunchKernelGGL(token_finalize_kernel<S>, dim3(1), dim3(kFinalThreads), 0, st, token_min, token_max, batch, \
                        tokens, lengths, prune, qf, fin, fb)
@@ -1564,14 +1565,15 @@ extern "C" int osq_fused_step_status(void* workspace, int* status_out, osq_strea
 
 extern "C" int osq_token_range_finalize_batched(const float* token_min, const float* token_max, int64_t problem_stride,
                                                 int n_quantizers, int n_batches, int64_t batch, int64_t tokens,
-                                                const int64_t* lengths, const int32_t* prune_flags, double percentile,
+                                                const int64_t* lengths, int lengths_per_quantizer,
+                                                const int32_t* prune_flags, double percentile,
                                                 float* cur_table, void* workspace, osq_stream stream) {
     OSQ_REQUIRE(token_min && token_max && cur_table && batch > 0 && tokens > 0, "token_range_finalize_batched: empty or null input");
     OSQ_REQUIRE(n_quantizers > 0 && n_batches > 0 && problem_stride >= batch * tokens, "token_range_finalize_batched: bad table shape");
     OSQ_REQUIRE(percentile >= 0.0 && percentile <= 1.0, "token_range_finalize_batched: percentile outside [0, 1]");
     OSQ_REQUIRE(batch * tokens < (1ll << 31), "token_range_finalize_batched: more than 2^31 token slots");
     const Finish fin{OSQ_UPDATE_NONE, 0, nullptr, nullptr, cur_table, 0, 1, 0, nullptr, nullptr, 0};
-    const FinalBatch fb{problem_stride, n_batches, n_quantizers, prune_flags};
+    const FinalBatch fb{problem_stride, n_batches, n_quantizers, prune_flags, lengths_per_quantizer ? 1 : 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qf = static_cast<float>(percentile);
     const int64_t problems = static_cast<int64_t>(n_quantizers) * n_batches;

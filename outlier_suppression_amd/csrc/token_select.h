@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
     if (fb.n_batches > 0) {
         const int64_t qi = p / fb.n_batches, bi = p - qi * fb.n_batches;
         src += p * fb.problem_stride;
-        if (lengths) lengths += bi * a.B;
+        if (lengths) lengths += (fb.lengths_per_problem ? p : bi) * a.B;
         prune = fb.prune_flags ? fb.prune_flags[qi] : prune;
         fin.cur += 2 * (bi * fb.n_quantizers + qi);
     }

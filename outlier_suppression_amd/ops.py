@@ -376,6 +376,8 @@ def token_minmax(x, seq_pos, lengths=None, out=None):
     view = token_view(x, seq_pos, None if lengths is None else lengths.numel())
     n = view.batch * view.tokens
     tmin, tmax = out if out is not None else _scratch(x.device, n)[:2]
+    if tmin.numel() < n or tmax.numel() < n:
+        raise ValueError(f"token_minmax: the output rows hold {tmin.numel()} slots, this tensor has {n} (batch x tokens)")
     _hip.check(lib.osq_token_minmax(_hip.ptr(x), ctypes.byref(view), _hip.ptr(lengths), _hip.ptr(tmin), _hip.ptr(tmax),
                                     _hip.stream_ptr(x.device)), "token_minmax")
     return tmin, tmax, view.batch, view.tokens, lengths
@@ -426,7 +428,11 @@ def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt,
     """A whole quantizer call (observe the masked activation, refresh scale / zero_point, fake-quantise) behind ONE
     call of the binding.  x: dense fp32 on the device.  Returns (y, batch, tokens, lengths_int64)."""
     lib = _hip._lib or _hip.load()
+    if not (lengths.is_cuda and scale.is_cuda and zero_point.is_cuda and min_val.is_cuda):
+        _hip.require_device(x, lengths, scale, zero_point, min_val, max_val)
     if lengths.dtype != torch.int64:
+        if lengths.is_floating_point():
+            raise TypeError("observation_mask must hold integer lengths")
         lengths = lengths.to(torch.int64)
     view = token_view(x, seq_pos, lengths.numel())
     dev = x.device
@@ -447,13 +453,25 @@ def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt,
 def token_range_finalize_batched(token_min, token_max, n_quantizers, n_batches, batch, tokens, lengths, prune_flags,
                                  percentile, cur_table):
     """Re-threshold the cached per-token extrema of every (quantizer, batch) pair in ONE launch.
-    token_min/token_max: [n_quantizers, n_batches, batch*tokens] fp32; lengths: [n_batches, batch] int64 or None;
-    prune_flags: [n_quantizers] int32; cur_table: [n_batches, n_quantizers, 2] fp32 (written)."""
+    token_min/token_max: [n_quantizers, n_batches, batch*tokens] fp32; lengths: [n_batches, batch] int64 (one mask for
+    every quantizer), [n_quantizers, n_batches, batch] (every quantizer its own) or None; prune_flags: [n_quantizers]
+    int32; cur_table: [n_batches, n_quantizers, 2] fp32 (written)."""
     lib = _hip.load()
     _hip.require_device(token_min, token_max, lengths, prune_flags, cur_table)
+    per_q = 0
+    if lengths is not None:
+        if lengths.dtype != torch.int64 or not lengths.is_contiguous():
+            raise ValueError("token_range_finalize_batched: lengths must be a contiguous int64 tensor")
+        if tuple(lengths.shape) == (n_quantizers, n_batches, batch):
+            per_q = 1
+        elif tuple(lengths.shape) != (n_batches, batch):
+            raise ValueError(f"token_range_finalize_batched: lengths has shape {tuple(lengths.shape)}, expected "
+                             f"({n_batches}, {batch}) or ({n_quantizers}, {n_batches}, {batch})")
+    if token_min.shape[-1] < batch * tokens or tuple(token_min.shape[:2]) != (n_quantizers, n_batches):
+        raise ValueError("token_range_finalize_batched: token arrays do not cover [n_quantizers, n_batches, batch*tokens]")
     _hip.check(lib.osq_token_range_finalize_batched(_hip.ptr(token_min), _hip.ptr(token_max), token_min.stride(1),
                                                     int(n_quantizers), int(n_batches), int(batch), int(tokens),
-                                                    _hip.ptr(lengths), _hip.ptr(prune_flags), float(percentile),
+                                                    _hip.ptr(lengths), per_q, _hip.ptr(prune_flags), float(percentile),
                                                     _hip.ptr(cur_table), _hip.ptr(_hip.workspace(token_min.device)),
                                                     _hip.stream_ptr(token_min.device)),
                "token_range_finalize_batched")

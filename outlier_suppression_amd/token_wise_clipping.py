@@ -267,38 +267,75 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
     for _, q in qs:
         q.observer._capture = None
     tok_cols = [i for i, s in enumerate(sites) if s is not None and s[0] == "tokens"]
-    geoms = {(sites[i][1], sites[i][2]) for i in tok_cols}
-    if len(geoms) > 1:
-        if world > 1:
-            raise NotImplementedError("find_ratio_cached: quantizers with different token geometries are not sharded yet")
-        return find_ratio(trainer, fp_input, fp_output, param)
-    n_tok = len(tok_cols)
-    masked = n_tok > 0 and sites[tok_cols[0]][3] is not None
-    if n_tok:
-        batch, tokens = next(iter(geoms))
-        slots = batch * tokens
-        tok_min = torch.empty(n_tok, rows, slots, dtype=torch.float32, device=dev)
-        tok_max = torch.empty(n_tok, rows, slots, dtype=torch.float32, device=dev)
-        lengths = torch.zeros(rows, batch, dtype=torch.int64, device=dev) if masked else None
-        prune_flags = torch.tensor([0 if "attention_probs" in qs[i][1].observer.name else 1 for i in tok_cols],
-                                   dtype=torch.int32, device=dev)
-        col_index = torch.tensor(tok_cols, device=dev)
-        cur_tok = torch.zeros(rows, n_tok, 2, dtype=torch.float32, device=dev)
+    # Token sites are grouped by what the re-threshold launch must share: (batch, tokens) and whether they are masked.
+    # Every site keeps its OWN lengths (BART's cross-attention keys are masked with the decoder's lengths although they
+    # have the encoder's geometry, quant_bart.py:167,172,472).
+    groups = {}
+    for i in tok_cols:
+        groups.setdefault((sites[i][1], sites[i][2], sites[i][3] is not None), []).append(i)
 
-    # ---- phase A: one FP pass, per-token extrema of every (quantizer, batch) kept on the device
+    class _Group:
+        pass
+    tok_groups = []
+    for (batch, tokens, masked), cols in groups.items():
+        gq = _Group()
+        gq.cols, gq.batch, gq.tokens, gq.masked, gq.n = cols, batch, tokens, masked, len(cols)
+        slots = batch * tokens
+        gq.tok_min = torch.empty(gq.n, rows, slots, dtype=torch.float32, device=dev)
+        gq.tok_max = torch.empty(gq.n, rows, slots, dtype=torch.float32, device=dev)
+        gq.lengths = torch.zeros(gq.n, rows, batch, dtype=torch.int64, device=dev) if masked else None
+        gq.prune_flags = torch.tensor([0 if "attention_probs" in qs[i][1].observer.name else 1 for i in cols],
+                                      dtype=torch.int32, device=dev)
+        gq.col_index = torch.tensor(cols, device=dev)
+        gq.cur = torch.zeros(rows, gq.n, 2, dtype=torch.float32, device=dev)
+        tok_groups.append(gq)
+    tok_set = set(tok_cols)
+
+    def _release():
+        for _, q in qs:
+            q.observer._token_cache = None
+            q.observer._capture = None
+
+    # ---- phase A: one FP pass, per-token extrema of every (quantizer, batch) kept on the device.  Every batch must
+    # show every site with the geometry of batch 0 (fixed-length padding); a batch that does not (dynamic padding, a
+    # short last batch) sends the search down the literal path instead of reading rows it did not fill.
+    same = True
     with torch.no_grad():
         for j, batch_in in enumerate(fp_input):
-            for k, i in enumerate(tok_cols):
-                qs[i][1].observer._token_cache = (tok_min[k, j], tok_max[k, j])
+            for gq in tok_groups:
+                for k, i in enumerate(gq.cols):
+                    qs[i][1].observer._token_cache = (gq.tok_min[k, j], gq.tok_max[k, j])
+                    object.__setattr__(qs[i][1].observer, "_last_site", None)
             for i, (_, q) in enumerate(qs):
-                if i not in tok_cols:
+                if i not in tok_set:
                     q.observer._capture = flat_table[j, i]
-            model(**batch_in)
-            if masked:
-                lengths[j].copy_(qs[tok_cols[0]][1].observer._last_site[3])
-    for _, q in qs:
-        q.observer._token_cache = None
-        q.observer._capture = None
+                    object.__setattr__(q.observer, "_last_site", None)
+            try:
+                model(**batch_in)
+            except ValueError:                      # a site outgrew its cache rows (ops.token_minmax checks the capacity)
+                same = False
+                break
+            for i, (_, q) in enumerate(qs):
+                site = q.observer._last_site
+                kind = None if site is None else site[0]
+                if (i in tok_set) != (kind == "tokens") or (sites[i] is None) != (site is None):
+                    same = False
+            for gq in tok_groups:
+                for k, i in enumerate(gq.cols):
+                    site = qs[i][1].observer._last_site
+                    if site is None or site[0] != "tokens" or (site[1], site[2], site[3] is not None) != (gq.batch, gq.tokens, gq.masked):
+                        same = False
+                    elif gq.masked:
+                        gq.lengths[k, j].copy_(site[3])
+            if not same:
+                break
+    _release()
+    if not same:
+        if world > 1:
+            raise NotImplementedError("find_ratio_cached: the calibration batches do not share one geometry per site "
+                                      "(dynamic padding?); pad to a fixed length or run find_ratio on one rank")
+        logger.info("find_ratio_cached: site geometry changes between batches, using the literal search")
+        return find_ratio(trainer, fp_input, fp_output, param)
 
     plan = calibration.ReplayPlan(qs, dev)
 
@@ -307,10 +344,10 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
         for _, q in qs:
             object.__setattr__(q.observer, "percentile", ratio)
         table = flat_table.clone()
-        if n_tok:
-            ops.token_range_finalize_batched(tok_min, tok_max, n_tok, rows, batch, tokens, lengths, prune_flags, ratio,
-                                             cur_tok)
-            table.index_copy_(1, col_index, cur_tok)
+        for gq in tok_groups:               # one launch per geometry group (one group for BERT / RoBERTa, three for BART)
+            ops.token_range_finalize_batched(gq.tok_min, gq.tok_max, gq.n, rows, gq.batch, gq.tokens, gq.lengths, gq.prune_flags,
+                                             ratio, gq.cur)
+            table.index_copy_(1, gq.col_index, gq.cur)
         ordered = calibration.gather_batch_table(table, n_batches, group)
         plan.run(ordered, fresh=True)       # one launch: running means from scratch + qparams of all quantizers
 

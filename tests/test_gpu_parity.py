@@ -986,3 +986,30 @@ def test_histogram_matches_torch_histc(dev):
         assert mxv.item() == min(np.float32(x.max().item()), clip), thr
         assert mn.item() == max(np.float32(x.min().item()), -clip), thr
         assert int(hist.sum().item()) == 0
+
+
+def test_batched_rethreshold_with_per_quantizer_lengths(dev):
+    """osq_token_range_finalize_batched: every (quantizer, batch) pair in one launch, each quantizer with its own mask
+    (BART: cross-attention keys are masked with the decoder's lengths, quant_bart.py:167,172,472) -- equal to the
+    single-problem finaliser called pair by pair; shape errors are refused, not read out of bounds."""
+    from outlier_suppression_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n_q, n_b, B, T = 3, 4, 8, 16
+    tmin = (-torch.rand(n_q, n_b, B * T, generator=gen) * 5).to(dev)
+    tmax = (torch.rand(n_q, n_b, B * T, generator=gen) * 5).to(dev)
+    lens_q = torch.randint(1, T + 1, (n_q, n_b, B), generator=gen).to(dev)
+    flags = torch.tensor([1, 0, 1], dtype=torch.int32, device=dev)
+    for lengths in (lens_q, lens_q[0].contiguous(), None):
+        cur = torch.zeros(n_b, n_q, 2, device=dev)
+        ops.token_range_finalize_batched(tmin, tmax, n_q, n_b, B, T, lengths, flags, 0.8, cur)
+        for qi in range(n_q):
+            for bi in range(n_b):
+                L = None if lengths is None else (lengths[qi, bi] if lengths.dim() == 3 else lengths[bi])
+                one = torch.zeros(2, device=dev)
+                ops.token_range_finalize(tmin[qi, bi], tmax[qi, bi], B, T, L, bool(flags[qi].item()), 0.8, ops.UPDATE_NONE, 0,
+                                         None, None, 0, 63, False, None, one)
+                assert torch.equal(cur[bi, qi], one), (qi, bi)
+    with pytest.raises(ValueError):
+        ops.token_range_finalize_batched(tmin, tmax, n_q, n_b, B, T, lens_q[:, :2].contiguous(), flags, 0.8, cur)
+    with pytest.raises(ValueError):
+        ops.token_minmax(torch.randn(B, T, 32, device=dev), 1, lens_q[0, 0], out=(tmin[0, 0, :16], tmax[0, 0, :16]))

@@ -15,15 +15,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, backend="gloo"):
     import logging
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    if world > 1:
+    tag = f"w{world}" if backend == "gloo" else f"{backend}{world}"
+    if world > 1 or backend != "gloo":
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":      # RCCL: device tensors go into the collectives as they are
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from transformers import BertConfig, BertForSequenceClassification
     from outlier_suppression_amd import calibration, token_wise_clipping as TWC
     from outlier_suppression_amd.gamma_migration import delay_ln
@@ -64,10 +69,29 @@ def _run(rank, world, port, out_dir):
     TWC.logger.addHandler(Grab())
     TWC.logger.setLevel(logging.INFO)
     mine = calibration.shard_batches(len(batches), rank, world)
+    if backend == "nccl":
+        # calibrate_sharded end to end on device tensors: capture -> all_gather_into_tensor (RCCL) -> ordered replay,
+        # against the plain sequential observer pass (token_wise_clipping.py:12-47) on a copy of the model
+        import copy
+        twin = copy.deepcopy(model)
+        TWC.set_ratio(model, 0.9)
+        TWC.set_ratio(twin, 0.9)
+        assert dist.get_backend() == "nccl"
+        ordered = calibration.calibrate_sharded(model, [batches[b] for b in mine], lambda m, b: m(**b), n_batches=len(batches))
+        assert ordered.is_cuda and ordered.shape[0] == len(batches)
+        with torch.no_grad():
+            for b in batches:
+                twin(**b)
+        qa = [m for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+        qb = [m for n, m in twin.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+        for x, y in zip(qa, qb):
+            assert torch.equal(x.observer.min_val, y.observer.min_val) and torch.equal(x.observer.max_val, y.observer.max_val)
+            assert torch.equal(x.scale, y.scale) and torch.equal(x.zero_point, y.zero_point) and x.observer.cnt == y.observer.cnt
+        disable_all(model)
     ratio = TWC.find_ratio_cached(NS(model=model), [batches[b] for b in mine], [fp_output[b] for b in mine],
                                   {"iters": 5, "step": 0.05}, n_batches=len(batches))
     qs = [m for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
-    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), ratio=ratio, losses=np.array(losses),
+    np.savez(os.path.join(out_dir, f"{tag}_r{rank}.npz"), ratio=ratio, losses=np.array(losses),
              scale=np.stack([q.scale.detach().cpu().numpy() for q in qs]),
              zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]),
              mn=np.stack([q.observer.min_val.cpu().numpy() for q in qs]),
@@ -75,11 +99,27 @@ def _run(rank, world, port, out_dir):
     # fine stage: sequential Adam on (scale, zero_point).  One process: the reference's loop; two ranks:
     # every step split inside the batch (half the samples each, averaged gradients)
     TWC.learn_scale_sharded(NS(model=model), batches, fp_output, {"lr": 1e-3, "epoch": 2})
-    np.savez(os.path.join(out_dir, f"learn_w{world}_r{rank}.npz"),
+    np.savez(os.path.join(out_dir, f"learn_{tag}_r{rank}.npz"),
              scale=np.stack([q.scale.detach().cpu().numpy() for q in qs]),
              zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]))
-    if world > 1:
+    if world > 1 or backend != "gloo":
         dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_equals_no_group(tmp_path):
+    """backend="nccl" IS RCCL on ROCm.  A one-rank group on the test GPU executes init_process_group(device_id=...),
+    the device-tensor all_gather_into_tensor of the statistics / loss tables and the all_reduce of the learn-scale
+    gradients -- the code path the 8-GPU node runs -- and must change nothing."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    mp.spawn(_run, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, 29741, str(tmp_path), "nccl"), nprocs=1, join=True)
+    one, rccl = np.load(tmp_path / "w1_r0.npz"), np.load(tmp_path / "nccl1_r0.npz")
+    for k in ("ratio", "losses", "scale", "zp", "mn", "cnt"):
+        assert np.array_equal(one[k], rccl[k]), k
+    l1, lr = np.load(tmp_path / "learn_w1_r0.npz"), np.load(tmp_path / "learn_nccl1_r0.npz")
+    assert np.array_equal(l1["scale"], lr["scale"]) and np.array_equal(l1["zp"], lr["zp"])
 
 
 def test_two_ranks_equal_one(tmp_path):

@@ -289,8 +289,163 @@ def main_bart():
           np.abs(out["logits_act_quant"] - out["logits_wrapped_fp"]).max())
 
 
+def _patch_stack(model, attr):
+    m = getattr(model, attr)
+    m.embeddings.position_embedding_type = "absolute"
+    m.encoder.gradient_checkpointing = False
+    for layer in m.encoder.layer:
+        layer.attention.pruned_heads = set()
+        layer.attention.self.position_embedding_type = "absolute"
+        if not hasattr(layer, "chunk_size_feed_forward"):
+            layer.chunk_size_feed_forward = 0
+    return model
+
+
+def main_variant(kind):
+    """The same pipeline for the two flows VERDICT r01 found unpinned:
+
+    bert-qa      BERT with the SQuAD head (model/quant_bert.py:690): start / end logits, the masked two-headed MSE of
+                 token_wise_clipping.py:38-41 / 95-99, FP targets already masked (ptq_qa_quant.py:126-131), and the
+                 batches RE-PREPARED at a smaller batch size before learn_scale (ptq_qa_quant.py:262-267);
+    roberta-cls  RoBERTa with its two-layer classification head (model/quant_roberta.py:621-643).
+    """
+    QB, GM, TWC, ST, QuantizeBase = import_reference()
+    gu = types.ModuleType("transformers.generation_utils")
+    sys.modules.setdefault("transformers.generation_utils", gu)
+    from quant_transformer.model import quant_roberta as RQ
+    import transformers as T
+    torch.set_num_threads(1)
+    torch.manual_seed({"bert-qa": 20241001, "roberta-cls": 20241002}[kind])
+    common = dict(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                  max_position_embeddings=40, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, type_vocab_size=2)
+    if kind == "bert-qa":
+        fp = _patch_stack(T.BertForQuestionAnswering(T.BertConfig(**common)).eval(), "bert")
+        ref_cls, attr, task = QB.QuantizedBertForQuestionAnswering, "bert", "squad"
+    else:
+        fp = _patch_stack(T.RobertaForSequenceClassification(T.RobertaConfig(num_labels=3, pad_token_id=1, **common)).eval(), "roberta")
+        ref_cls, attr, task = RQ.QuantizedRobertaForSequenceClassification, "roberta", "glue"
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.copy_(torch.rand(32, generator=g) * 1.2 + 0.4)
+                m.weight[5] = 4.0
+                m.bias.copy_(torch.randn(32, generator=g) * 0.2)
+        for m in fp.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0)
+    out = {f"sd::{k}": v.numpy() for k, v in fp.state_dict().items()}
+    out["kind"] = np.array(kind)
+
+    B, Tn, NB = 4, 16, 4
+    g = torch.Generator().manual_seed(99)
+    samples = []
+    for b in range(NB * B):
+        L = int(torch.randint(3, Tn + 1, (1,), generator=g))
+        if b % 5 == 0:
+            L = Tn
+        ids = torch.randint(3, 120, (Tn,), generator=g)
+        mask = (torch.arange(Tn) < L).long()
+        samples.append((ids * mask + (1 - mask), mask))        # pad id 1 (RoBERTa's padding_idx; harmless for BERT)
+
+    def batches_of(bs):
+        res = []
+        for i in range(0, len(samples), bs):
+            ids = torch.stack([s[0] for s in samples[i:i + bs]])
+            mask = torch.stack([s[1] for s in samples[i:i + bs]])
+            d = {"input_ids": ids, "attention_mask": mask}
+            if kind == "bert-qa":
+                d["token_type_ids"] = torch.zeros_like(ids)
+            res.append(d)
+        return res
+    batches = batches_of(B)
+    out["input_ids"] = np.stack([b["input_ids"].numpy() for b in batches])
+    out["attention_mask"] = np.stack([b["attention_mask"].numpy() for b in batches])
+
+    a_q = Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    model = ref_cls(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
+
+    def heads(outputs):
+        return [outputs[0], outputs[1]] if kind == "bert-qa" else [outputs[0]]
+
+    def prepare(bs_batches):
+        """prepare_input_output: ptq_qa_quant.py:114-134 (masked start / end logits) / ptq_glue_quant.py:94-107."""
+        res = []
+        with torch.no_grad():
+            for b in bs_batches:
+                o = model(**b)
+                if kind == "bert-qa":
+                    res.append([o[0][b["attention_mask"] == 1].detach(), o[1][b["attention_mask"] == 1].detach()])
+                else:
+                    res.append(o[0].detach())
+        return res
+
+    def logits(bs_batches):
+        with torch.no_grad():
+            return np.stack([np.stack([h.numpy() for h in heads(model(**b))]) for b in bs_batches])
+    ST.disable_all(model)
+    fp_output = prepare(batches)
+    out["logits_wrapped_fp"] = logits(batches)
+    model = GM.delay_ln(model, Cfg(a_qconfig=a_q, w_qconfig=w_q), Cfg(model_type=attr, task_type=task))
+    out["logits_after_gamma"] = logits(batches)
+    out["module_names"] = np.array([n for n, _ in model.named_modules()])
+    ST.enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+    with torch.no_grad():
+        model(**batches[0])
+    ST.disable_all(model)
+    ST.set_observer_name(model)
+    TWC.task_type, TWC.model_type = task, attr
+    losses = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            msg = record.getMessage()
+            if msg.startswith("the ratio is"):
+                losses.append(float(msg.split("the loss is")[1]))
+    h = Grab()
+    TWC.logger.addHandler(h)
+    TWC.logger.setLevel(logging.INFO)
+    trainer = types.SimpleNamespace(model=model)
+    iters, step = 6, 0.05
+    TWC.find_ratio(trainer, batches, fp_output, {"iters": iters, "step": step})
+    TWC.logger.removeHandler(h)
+    out["twc_losses"], out["twc_grid"] = np.array(losses, dtype=np.float64), np.array([iters, step])
+    names, scales, zps = quantizer_table(model, QuantizeBase)
+    out["q_names"] = np.array(names)
+    for i, (s_, z_) in enumerate(zip(scales, zps)):
+        out[f"q_after_twc_scale::{i}"], out[f"q_after_twc_zp::{i}"] = s_, z_
+    out["best_ratio"] = np.array([m.observer.percentile for n, m in model.named_modules()
+                                  if isinstance(m, QuantizeBase) and "act" in n][:1])
+    TWC.enable_quantization(model)
+    out["logits_act_quant"] = logits(batches)
+    if kind == "bert-qa":
+        # ptq_qa_quant.py:262-267: smaller batches for the fine stage, FP targets recomputed with every quantizer off
+        learn_bs = 2
+        ST.disable_all(model)
+        learn_batches = batches_of(learn_bs)
+        learn_output = prepare(learn_batches)
+        out["learn_batch_size"] = np.array(learn_bs)
+    else:
+        learn_batches, learn_output = batches, fp_output
+    TWC.learn_scale(trainer, learn_batches, learn_output, {"lr": 1e-3, "epoch": 2})
+    names, scales, zps = quantizer_table(model, QuantizeBase)
+    for i, (s_, z_) in enumerate(zip(scales, zps)):
+        out[f"q_after_learn_scale::{i}"], out[f"q_after_learn_zp::{i}"] = s_, z_
+    ST.enable_quantization(model)
+    out["logits_full_quant"] = logits(batches)
+    path = os.path.join(OUT, {"bert-qa": "bert_qa_tiny_pipeline.npz", "roberta-cls": "roberta_tiny_pipeline.npz"}[kind])
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(names), "quantizers; losses", losses)
+    print("logit drift gamma:", np.abs(out["logits_after_gamma"] - out["logits_wrapped_fp"]).max(),
+          "act-quant:", np.abs(out["logits_act_quant"] - out["logits_wrapped_fp"]).max(),
+          "full:", np.abs(out["logits_full_quant"] - out["logits_wrapped_fp"]).max())
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bart":
         main_bart()
+    elif len(sys.argv) > 1 and sys.argv[1] in ("bert-qa", "roberta-cls"):
+        main_variant(sys.argv[1])
     else:
         main()

@@ -369,6 +369,231 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
     return out
 
 
+def calibration_extra(dev, rank, world, which):
+    """Calibration wall-clock (SURVEY.md section 8d Metric 2) of BASELINE configs[2], [3], [4] at the reference's sizes,
+    random-init weights and synthetic ids; clock: batches resident on device -> every quantizer has its final
+    scale / zero_point.  One run each (the process is warm from configs[1]); phases as section 8d lists them.
+
+      2  BERT-base SQuAD-v1 twc_fine_gamma W6A6: T = 384, 256 features = 8 x [32, 384], 90 candidates (step 0.0033:
+         cac_step_iters(6 bit, bs 32, T 384), token_wise_clipping.py:118-129), masked two-headed loss, learn-scale at
+         batch 8 with re-prepared targets (ptq_qa_quant.py:235-277);
+      3  RoBERTa-base MNLI W4A6: weights 4-bit symmetric per output channel with MSEFastObserver (one bounded-Brent search
+         per row: 134 K rows, observer.py:496-517), activations 6-bit AvgMSEFastObserver, 8 x [32, 128];
+      4  BART XSum twc_fine_gamma W6A6, encoder + decoder: bart-base dimensions as the reference's shipped config uses
+         (exp/xsum/twc_fine_gamma/config.yaml:44; BASELINE names bart-large), 64 x ([4, 1024] source, [4, 62] target),
+         30 candidates, learn-scale 3 epochs (ptq_summ_quant.py:124-154).
+    N > 1: the grid search is sharded (batch b on rank b mod N); the statistics / loss tables are all-gathered per candidate
+    (calibration.gather_batch_table); learn-scale and the MSEFast searches run replicated (sequential Adam / float64
+    per-observer state), which the line says."""
+    import logging
+    from types import SimpleNamespace as NS
+    import torch.distributed as dist
+    import transformers as T
+    from outlier_suppression_amd import calibration, token_wise_clipping as TWC
+    from outlier_suppression_amd.gamma_migration import delay_ln
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
+    from outlier_suppression_amd.quantization.state import set_observer_name
+
+    logging.getLogger("transformer").setLevel(logging.WARNING)
+    torch.manual_seed(which)
+    g = torch.Generator().manual_seed(100 + which)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    gather_s = [0.0]
+    real_gather = calibration.gather_batch_table
+
+    def timed_gather(*a, **k):          # the collective's share of the wall-clock (host-side bracket, sync'ed)
+        if world == 1:
+            return real_gather(*a, **k)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = real_gather(*a, **k)
+        torch.cuda.synchronize()
+        gather_s[0] += time.perf_counter() - t
+        return r
+    twc_a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    twc_w = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    phases, out = {}, {}
+
+    def masked_batches(n_batches, B, Tn, vocab, lo):
+        res = []
+        for _ in range(n_batches):
+            L = torch.randint(lo, Tn + 1, (B,), generator=g)
+            mask = (torch.arange(Tn)[None, :] < L[:, None]).long()
+            ids = torch.randint(1000, vocab - 1000, (B, Tn), generator=g) * mask + (1 - mask)
+            res.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev)})
+        return res
+
+    if which == 2:
+        cfg = T.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        fp = T.BertForQuestionAnswering(cfg).eval().to(dev)
+        batches = masked_batches(8, 32, 384, 30522, 64)
+        for b in batches:
+            b["token_type_ids"] = torch.zeros_like(b["input_ids"])
+        task, mtype, grid = "squad", "bert", {"iters": 90, "step": 0.0033}
+        out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
+    elif which == 4:
+        cfg = T.BartConfig(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12, decoder_attention_heads=12,
+                           encoder_ffn_dim=3072, decoder_ffn_dim=3072, max_position_embeddings=1024, dropout=0.0,
+                           attention_dropout=0.0, activation_dropout=0.0)
+        fp = T.BartForConditionalGeneration(cfg).eval().to(dev)
+        batches = masked_batches(64, 4, 1024, 50265, 256)
+        for b in batches:
+            DL = torch.randint(16, 63, (4,), generator=g)
+            DL[0] = 62
+            dm = (torch.arange(62)[None, :] < DL[:, None]).long()
+            b["decoder_input_ids"] = (torch.randint(1000, 49000, (4, 62), generator=g) * dm + (1 - dm)).to(dev)
+            b["decoder_attention_mask"] = dm.to(dev)
+        task, mtype, grid = "summ", "bart", {"iters": 30, "step": 0.01}
+        out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, bart-base dimensions (the reference's shipped "
+                         "config), 256 samples (64 x ([4,1024] source, [4,62] target)), 30 candidates, learn-scale 3 epochs")
+    else:
+        cfg = T.RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, num_labels=3,
+                              hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        fp = T.RobertaForSequenceClassification(cfg).eval().to(dev)
+        batches = masked_batches(8, 32, 128, 50265, 8)
+        w_q = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
+        a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)
+        model = quantize_model(fp, w_q, a_q).to(dev)
+        sync()
+        t_start = t0 = time.perf_counter()
+        enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+        with torch.no_grad():
+            model(**batches[0])
+        sync(); phases["weight_calibration_msefast_per_channel"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        rows = sum(m.weight.shape[0] for m in model.modules() if hasattr(m, "weight_fake_quant"))
+        evals = sum(int(m.weight_fake_quant.observer.last_nfev.sum().item()) for m in model.modules() if hasattr(m, "weight_fake_quant"))
+        enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
+        with torch.no_grad():
+            for b in batches:
+                model(**b)
+        sync(); phases["activation_calibration_msefast_per_tensor"] = time.perf_counter() - t0
+        from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+        act_evals = sum(int(m.observer.last_nfev.sum().item()) for n, m in model.named_modules()
+                        if isinstance(m, QuantizeBase) and "act" in n and m.observer.last_nfev is not None)
+        return {"config": "configs[3]: RoBERTa-base MNLI W4A6, per-channel weights + MSEFast, 256 samples (8 x [32,128])",
+                "wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
+                "weight_rows_searched": rows, "weight_loss_evaluations": evals, "activation_loss_evaluations_last_batch": act_evals,
+                "n_gpus": world, "sharding": "replicas only (float64 per-observer search state)" if world > 1 else "one process"}
+
+    TWC.task_type, TWC.model_type = task, mtype
+    n_batches = len(batches)
+    mine = calibration.shard_batches(n_batches, rank, world)
+    model = quantize_model(fp, twc_w, twc_a).to(dev)
+    calibration.gather_batch_table = timed_gather
+    try:
+        def targets(bs):
+            res = []
+            with torch.no_grad():
+                for b in bs:
+                    o = model(**b)
+                    if task == "squad":
+                        keep = b["attention_mask"] == 1
+                        res.append([o[0][keep].detach(), o[1][keep].detach()])
+                    else:
+                        res.append(o[0][b["decoder_attention_mask"] == 1, :].detach())
+            return res
+        sync()
+        t_start = t0 = time.perf_counter()
+        fp_output = targets(batches)           # every rank: FP targets of all batches (cheap next to the search)
+        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        m = delay_ln(model, NS(a_qconfig=twc_a, w_qconfig=twc_w), NS(model_type=mtype, task_type=task))
+        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
+        with torch.no_grad():
+            m(**batches[0])
+        disable_all(m)
+        set_observer_name(m)
+        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid, n_batches=n_batches)
+        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        if which == 2:        # ptq_qa_quant.py:262-267: smaller batches for the fine stage, targets recomputed with everything off
+            disable_all(m)
+            model = m
+            small = []
+            for b in batches:
+                for i in range(0, 32, 8):
+                    small.append({k: v[i:i + 8] for k, v in b.items()})
+            learn_in, learn_out = small, targets(small)
+        else:
+            learn_in, learn_out = batches, fp_output
+        TWC.learn_scale_sharded(NS(model=m), learn_in, learn_out, {"lr": 1e-5, "epoch": 3})
+        sync(); phases["learn_scale"] = time.perf_counter() - t0
+        out.update({"wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
+                    "collective_s": round(gather_s[0], 4), "best_percentile": ratio, "twc_candidates": grid["iters"],
+                    "search": "cached per-token extrema, one re-threshold launch per candidate and geometry group, sharded over ranks",
+                    "learn_scale": "sequential Adam, replicated on every rank" if world > 1 else "sequential Adam, one process",
+                    "n_gpus": world})
+        return out
+    finally:
+        calibration.gather_batch_table = real_gather
+        TWC.task_type, TWC.model_type = "glue", "bert"
+
+
+def quantized_forward_times(dev):
+    """BERT-base, every weight and activation quantizer frozen and on (the PTQ evaluation state, ptq_glue_quant.py:251):
+    one [32,128] forward with the weights fake-quantised per operator on every forward, as the reference does (77 launches,
+    quantized_module.py:71-72,97-100), against the kept result (no launch) and the one-launch refresh."""
+    from types import SimpleNamespace as NS
+    from transformers import BertConfig, BertForSequenceClassification
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, enable_quantization, disable_all
+    from outlier_suppression_amd.quantization import weight_cache as WC
+    torch.manual_seed(0)
+    a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    fp = BertForSequenceClassification(BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).eval().to(dev)
+    model = quantize_model(fp, w_q, a_q).to(dev)
+    L = torch.randint(8, 129, (32,))
+    mask = (torch.arange(128)[None, :] < L[:, None]).long()
+    batch = {"input_ids": (torch.randint(1000, 30000, (32, 128)) * mask).to(dev), "attention_mask": mask.to(dev),
+             "token_type_ids": torch.zeros(32, 128, dtype=torch.long, device=dev)}
+    enable_calibration_woquantization(model)
+    with torch.no_grad():
+        model(**batch)
+    disable_all(model)
+    enable_quantization(model)
+
+    def timed(n=20):
+        with torch.no_grad():
+            for _ in range(3):
+                model(**batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                model(**batch)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    WC.enabled = False
+    per_op = timed()
+    WC.enabled = True
+    kept = timed()
+    for k in WC.stats:
+        WC.stats[k] = 0
+    WC.invalidate(model)
+    torch.cuda.synchronize()
+    with torch.no_grad():                  # the frozen-model state: nothing wants a gradient
+        WC.prepare_weights(model)          # builds the pointer table (once per model)
+        WC.invalidate(model)               # drops the results AND the table ...
+        WC.prepare_weights(model)
+        for m in model.modules():          # ... so stale results only: the table stays
+            WC._CACHE.pop(m, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = WC.prepare_weights(model)
+        torch.cuda.synchronize()
+    refresh = (time.perf_counter() - t0) * 1e3
+    return {"model": "BERT-base, W6A6, [32,128] batch, every quantizer frozen and on",
+            "weight_fake_quant_per_operator_every_forward_ms": round(per_op, 3), "weight_launches_per_forward_then": 77,
+            "weights_kept_ms": round(kept, 3), "weight_launches_per_forward_now": 0,
+            "one_launch_refresh_of_all_weights_ms": round(refresh, 3), "tensors_in_that_launch": n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +607,7 @@ def main():
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel timing table")
     ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
+    ap.add_argument("--calib-configs", default="1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -606,8 +832,22 @@ def main():
     if rank == 0 and not args.no_kernel_table:
         out["kernels"] = kernel_table(dev, xs, lengths)
     if not args.no_calib:
-        calib = calibration_wall_clock(dev, rank, world, args.calib_search)
-        out["calibration"] = calib
+        wanted = {int(c) for c in args.calib_configs.split(",") if c.strip()}
+        if 1 in wanted:
+            out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
+        for which in (2, 3, 4):
+            if which not in wanted:
+                continue
+            try:          # a failure here must not cost the headline line
+                out[f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
+            except Exception as e:
+                out[f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+        if rank == 0:
+            try:
+                out["quantized_forward"] = quantized_forward_times(dev)
+            except Exception as e:
+                out["quantized_forward"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
     elif rank == 0:

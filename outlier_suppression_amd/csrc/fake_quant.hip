@@ -597,7 +597,7 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
                        grad_out + n4 * 4, grad_x + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax,
-                       grad_scale, grad_zero_point, ws.doubles(), ws.counter(0));
+                       grad_scale, grad_zero_point, ws.doubles(kFamLsqBackward), ws.counter(kFamLsqBackward));
     return check_launch("lsq_backward_per_tensor");
 }
 

@@ -551,7 +551,7 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
-                           ws.doubles(), ws.counter(0));
+                           ws.doubles(kFamMseFlat), ws.counter(kFamMseFlat));
     return check_launch("msefast_tensor_evals_flat");
 }
 
@@ -563,7 +563,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_evals_tokens: empty view");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
-    double* count = ws.doubles() + kMaxBlocks;        // behind the partials
+    double* count = ws.doubles(kFamMseTokens) + kMaxBlocks;        // behind the partials
     hipLaunchKernelGGL(msefast_valid_count_kernel, dim3(1), dim3(64), 0, st, lengths, v.batch, v.tokens,
                        v.feat_outer * v.feat_inner, count);
     const int vec = v.stride_inner == 1 && v.feat_inner % 4 == 0 && aligned16(x) && v.stride_batch % 4 == 0 &&
@@ -571,7 +571,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     const int grid = grid_for(v.batch * v.tokens, kWavesPerBlock, kMaxBlocks);
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_token_loss_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, vec,
-                           static_cast<TensorSearch*>(state), ws.doubles(), ws.counter(0), count);
+                           static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count);
     return check_launch("msefast_tensor_evals_tokens");
 }
 

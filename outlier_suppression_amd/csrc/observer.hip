@@ -1303,7 +1303,7 @@ extern "C" int osq_observe_flat(const float* x, int64_t n,
         const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_FLAT);
         hipExtLaunchKernelGGL(observe_flat_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0,
                               reinterpret_cast<const float4*>(x), n4,
-                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(), ws.counter(1), fin);
+                           x + n4 * 4, static_cast<int>(n - n4 * 4), ws.floats(kFamObserveFlat), ws.counter(kFamObserveFlat), fin);
     } else {
         // misaligned base: peel to the next 16-byte boundary by treating the head as the "tail" is not
         // possible with one pointer, so fall back to the per-channel kernel with a single channel.
@@ -1396,7 +1396,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     if (wide) {
         Workspace wsp(workspace);
         WideArgs a{token_min, token_max, batch, tokens, lengths, reinterpret_cast<WideState*>(wsp.wide()),
-                   static_cast<unsigned int*>(list_scratch), wsp.counter(0), prune, qf};
+                   static_cast<unsigned int*>(list_scratch), wsp.counter(kFamWideFinal), prune, qf};
         const int grid = static_cast<int>((batch * tokens + kWideSlotsPerBlock - 1) / kWideSlotsPerBlock);
         hipLaunchKernelGGL(wide_hist_kernel, dim3(grid), dim3(kWideThreads), 0, st, a, fin);
         if (prune) {

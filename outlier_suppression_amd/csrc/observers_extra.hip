@@ -448,8 +448,8 @@ extern "C" int osq_observe_moments(const float* x, int64_t outer, int64_t channe
         int grid = 1;
         make_source(x, outer * inner, nullptr, nullptr, &src, &grid, 1024);
         Workspace ws(workspace);
-        hipLaunchKernelGGL(moments_flat_kernel, dim3(grid), dim3(kThreads), 0, st, src, min_val, max_val, q, ws.doubles(),
-                           ws.counter(0));
+        hipLaunchKernelGGL(moments_flat_kernel, dim3(grid), dim3(kThreads), 0, st, src, min_val, max_val, q, ws.doubles(kFamMoments),
+                           ws.counter(kFamMoments));
     } else {
         hipLaunchKernelGGL(moments_channels_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads), 0, st, x, outer,
                            channels, inner, min_val, max_val, q);
@@ -492,7 +492,7 @@ extern "C" int osq_mse_grid_tensor(const float* x, int64_t n, const osq_token_vi
     Workspace ws(workspace);
     for (int k0 = 0; k0 < g.n_cand; k0 += kCandBatch)
         hipLaunchKernelGGL(mse_grid_loss_kernel, dim3(grid), dim3(kThreads), 0, st, src, cur_minmax, g, k0, loss_scratch,
-                           ws.doubles(), ws.counter(0));
+                           ws.doubles(kFamHistogram), ws.counter(kFamHistogram));
     hipLaunchKernelGGL(mse_grid_commit_kernel, dim3(1), dim3(kThreads), 0, st, loss_scratch, cur_minmax, g, update_rule, cnt,
                        min_val, max_val, q);
     return check_launch("mse_grid_tensor");

@@ -9,8 +9,14 @@
 namespace osq {
 
 constexpr int kMaxBlocks = 2048;          // 256 CUs x 8 workgroups of 256 threads
-constexpr size_t kWsHeaderBytes = 4096;   // ticket counters, one 64-byte line each (33 used)
-constexpr size_t kWsScratchBytes = 64 * 1024;
+// Every kernel family that finishes in its last workgroup owns a block of ticket counters and a block of partials:
+// two such kernels of DIFFERENT families may overlap on one stream (graph branches) without sharing either.
+enum WsFamily { kFamLsqBackward = 0, kFamObserveFlat = 1, kFamWideFinal = 2, kFamMseFlat = 3, kFamMseTokens = 4,
+                kFamMoments = 5, kFamHistogram = 6, kWsFamilies = 8 };
+constexpr size_t kWsCounterBlock = 4096;                      // 33 counters used, one 64-byte line each
+constexpr size_t kWsHeaderBytes = kWsFamilies * kWsCounterBlock;
+constexpr size_t kWsScratchPerFamily = 64 * 1024;             // 2048 partials of 8 B + extras, or 256 x 32 partials (MSE grid)
+constexpr size_t kWsScratchBytes = kWsFamilies * kWsScratchPerFamily;
 constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
 constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of token_select_kernel (8 B per problem)
 constexpr size_t kWsFusedBytes = 1024;               // FusedState of the one-launch observe + fake-quant (fused_step.h)
@@ -44,15 +50,15 @@ static inline int check_launch(const char* what) {
     return OSQ_OK;
 }
 
-// Caller-owned scratch: [4 KiB of ticket counters][64 KiB scratch][16 KiB + 64 B wide-finaliser state][64 KiB rendezvous words]
-// [1 KiB state of the fused observe + fake-quant launch].  Counters are zero between
+// Caller-owned scratch: [8 x 4 KiB of ticket counters][8 x 64 KiB of partials][16 KiB + 64 B wide-finaliser state]
+// [64 KiB rendezvous words][1 KiB state of the fused observe + fake-quant launch].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
     explicit Workspace(void* p) : base(static_cast<char*>(p)) {}
-    unsigned int* counter(int) const { return reinterpret_cast<unsigned int*>(base); }
-    double* doubles() const { return reinterpret_cast<double*>(base + kWsHeaderBytes); }
-    float* floats() const { return reinterpret_cast<float*>(base + kWsHeaderBytes); }
+    unsigned int* counter(int family) const { return reinterpret_cast<unsigned int*>(base + family * kWsCounterBlock); }
+    double* doubles(int family) const { return reinterpret_cast<double*>(base + kWsHeaderBytes + family * kWsScratchPerFamily); }
+    float* floats(int family) const { return reinterpret_cast<float*>(base + kWsHeaderBytes + family * kWsScratchPerFamily); }
     void* wide() const { return base + kWsHeaderBytes + kWsScratchBytes; }
     unsigned long long* meet() const {
         return reinterpret_cast<unsigned long long*>(base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes);

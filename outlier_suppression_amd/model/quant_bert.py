@@ -18,6 +18,8 @@ import math
 import torch
 from torch import nn
 
+from ..quant_model_checks import _no_labels
+
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import GammaResidual, QuantizedLayerNorm, activation_fake_quant, residual_layernorm
 
@@ -236,6 +238,7 @@ class QuantizedBertForSequenceClassification(QuantizedModule):
             self.classifier_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
+        _no_labels(unused)
         obs = _observation_mask(attention_mask, self.is_remove_padding)
         _, pooled = self.bert(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.classifier(self.dropout_post_act_fake_quantize(self.dropout(pooled)))
@@ -257,6 +260,7 @@ class QuantizedBertForQuestionAnswering(QuantizedModule):
             self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
+        _no_labels(unused)
         obs = _observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.bert(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.qa_outputs(seq)

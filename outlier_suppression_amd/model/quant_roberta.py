@@ -10,6 +10,7 @@ Sub-module names follow the reference (``roberta.*``, ``classifier.dense`` ...),
 """
 import torch
 
+from ..quant_model_checks import _no_labels
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import QuantizedLayerNorm
 from . import quant_bert as B
@@ -163,6 +164,7 @@ class QuantizedRobertaForSequenceClassification(QuantizedModule):
                                                              backend=backend)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
+        _no_labels(unused)
         obs = B._observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.roberta(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         return (self.classifier(seq),)
@@ -181,6 +183,7 @@ class QuantizedRobertaForQuestionAnswering(QuantizedModule):
             self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
+        _no_labels(unused)
         obs = B._observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.roberta(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.qa_outputs(seq)

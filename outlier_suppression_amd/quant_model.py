@@ -23,6 +23,8 @@ def model_type_of(model_name):
 
 def quantize_model(fp_model, w_qconfig, a_qconfig, backend="academic", is_remove_padding=True):
     """deepcopy the FP model and wrap it with qoutput=False (quant_model.py:43-49)."""
+    from .quant_model_checks import require_academic
+    require_academic(backend)
     cls = type(fp_model).__name__
     if cls not in _WRAPPERS:
         raise NotImplementedError(f"no quantized counterpart for {cls} yet")

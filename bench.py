@@ -588,7 +588,41 @@ def quantized_forward_times(dev):
         n = WC.prepare_weights(model)
         torch.cuda.synchronize()
     refresh = (time.perf_counter() - t0) * 1e3
+    # observer pass (token_wise_clipping.py:12-19, 29-47: observers on, fake-quant off) of one [32,128] batch: every
+    # masked site its own two launches, against the sites of the forward recorded and reduced together
+    from outlier_suppression_amd import token_wise_clipping as TWC
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    from outlier_suppression_amd.quantization.state import set_observer_name
+    tw_a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    obs_model = quantize_model(fp, w_q, tw_a).to(dev)
+    set_observer_name(obs_model)
+    TWC.set_ratio(obs_model, 0.95)
+
+    def observer_pass(defer, n=20):
+        info = {}
+        with torch.no_grad():
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if defer:
+                    with deferred_observation() as sites:
+                        for _ in range(n):
+                            obs_model(**batch)
+                            sites.flush()
+                    info = {"launches_per_forward": sites.launches / n, "sites_per_forward": sites.flushed_sites / n}
+                else:
+                    for _ in range(n):
+                        obs_model(**batch)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n * 1e3
+        return dt, info
+    each_ms, _ = observer_pass(False)
+    defer_ms, info = observer_pass(True)
+    n_sites = info.get("sites_per_forward", 0) or 1
     return {"model": "BERT-base, W6A6, [32,128] batch, every quantizer frozen and on",
+            "observer_pass_site_by_site_ms": round(each_ms, 3), "observer_launches_per_masked_site_then": 2,
+            "observer_pass_deferred_ms": round(defer_ms, 3), "masked_sites_per_forward": n_sites,
+            "observer_launches_per_masked_site_now": round(info.get("launches_per_forward", 0) / n_sites, 4),
             "weight_fake_quant_per_operator_every_forward_ms": round(per_op, 3), "weight_launches_per_forward_then": 77,
             "weights_kept_ms": round(kept, 3), "weight_launches_per_forward_now": 0,
             "one_launch_refresh_of_all_weights_ms": round(refresh, 3), "tensors_in_that_launch": n}

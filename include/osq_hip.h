@@ -214,6 +214,23 @@ int osq_observe_channels(const float* x, int64_t outer, int64_t channels, int64_
 int osq_token_minmax(const float* x, const osq_token_view* view, const int64_t* lengths,
                      float* token_min, float* token_max, osq_stream stream);
 
+/* osq_token_minmax for MANY tensors in ONE launch (the observer passes of a calibration forward call ~100 sites of 6-50 MB
+ * each, token_wise_clipping.py:29-47: launch-bound one by one).  descs / tok_end: DEVICE arrays of n_sites entries; site i
+ * is `x` seen through `view`, valid tokens t < lengths[b] (NULL: all), extrema written to token_min / token_max[batch*tokens]
+ * (padded slots untouched); vec != 0 promises what osq_token_minmax checks for its 16-byte path (stride_inner == 1,
+ * feat_inner % 4 == 0, every other stride % 4 == 0, x 16-byte aligned); tok_end[i] = token slots of sites 0..i. */
+typedef struct osq_site_desc {
+    const float* x;
+    const int64_t* lengths;
+    float* token_min;
+    float* token_max;
+    osq_token_view view;
+    int32_t vec;
+    int32_t pad;
+} osq_site_desc;
+int osq_token_minmax_multi(const osq_site_desc* descs, const int64_t* tok_end, int n_sites, int64_t total_tokens,
+                           osq_stream stream);
+
 /* Everything after the per-token extrema in AvgPruneMinMaxObserver.forward /
  * AvgMinMaxObserver.forward / MinMaxObserver.forward with a mask:
  *   prune != 0: cac_thres + prune_token (observer.py:50-70) with `percentile`;

@@ -41,6 +41,12 @@ class WeightDesc(ctypes.Structure):
                 ("quant_max", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class SiteDesc(ctypes.Structure):
+    """``osq_site_desc``: one entry of the table of osq_token_minmax_multi."""
+    _fields_ = [("x", _P), ("lengths", _P), ("token_min", _P), ("token_max", _P), ("view", TokenView),
+                ("vec", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); one entry per symbol declared in include/osq_hip.h
 SIGNATURES = {
     "osq_last_error": (ctypes.c_char_p, []),
@@ -64,6 +70,7 @@ SIGNATURES = {
     "osq_observe_flat": (_I, [_P, _L, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_observe_channels": (_I, [_P, _L, _L, _L, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "osq_token_minmax": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
+    "osq_token_minmax_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I,

@@ -388,6 +388,63 @@ __global__ __launch_bounds__(kThreads) void token_minmax_generic_kernel(const fl
     }
 }
 
+// Many sites, one launch (observer passes of a calibration forward: 98 masked sites for BERT-base, each 4-9 us of
+// kernel for 6-50 MB -- launch-bound).  The sites of a forward are recorded while the model runs
+// (quantization/deferred.py) and reduced together: wave = one token of one site, found by bisection over the
+// table's running token counts; padded tokens are skipped without a read; any layout (16-byte loads when the
+// innermost feature axis is contiguous and aligned).
+__global__ __launch_bounds__(kThreads) void token_minmax_multi_kernel(const osq_site_desc* __restrict__ descs,
+                                                                      const int64_t* __restrict__ tok_end, int n_sites,
+                                                                      int64_t total_tokens) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+    for (int64_t g = wave0; g < total_tokens; g += nwaves) {
+        int lo = 0, hi = n_sites - 1;                 // first site whose tok_end exceeds g
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tok_end[mid] > g) hi = mid; else lo = mid + 1;
+        }
+        const osq_site_desc d = descs[lo];
+        const int64_t tok = g - (lo ? tok_end[lo - 1] : 0);
+        const int64_t b = tok / d.view.tokens, t = tok - b * d.view.tokens;
+        if (d.lengths && t >= d.lengths[b]) continue;
+        const float* base = d.x + b * d.view.stride_batch + t * d.view.stride_token;
+        MinMax acc;
+        acc.init();
+        if (d.vec) {
+            const int inner4 = static_cast<int>(d.view.feat_inner / 4);
+            const int64_t F4 = d.view.feat_outer * inner4;
+            if (d.view.feat_outer == 1) {
+                const float4* row = reinterpret_cast<const float4*>(base);
+                int64_t j = lane;
+                for (; j + 2 * OSQ_WAVE < F4; j += 3 * OSQ_WAVE) {        // 768 features = exactly one trip
+                    const float4 a = load_stream(row + j), c = load_stream(row + j + OSQ_WAVE), e = load_stream(row + j + 2 * OSQ_WAVE);
+                    acc.add4(a); acc.add4(c); acc.add4(e);
+                }
+                for (; j < F4; j += OSQ_WAVE) acc.add4(load_stream(row + j));
+            } else {
+                for (int64_t j = lane; j < F4; j += OSQ_WAVE) {
+                    const int64_t o = j / inner4, i = j - o * inner4;
+                    acc.add4(load_stream(reinterpret_cast<const float4*>(base + o * d.view.stride_outer) + i));
+                }
+            }
+        } else {
+            const int64_t F = d.view.feat_outer * d.view.feat_inner;
+            for (int64_t j = lane; j < F; j += OSQ_WAVE) {
+                const int64_t o = j / d.view.feat_inner, i = j - o * d.view.feat_inner;
+                acc.add(base[o * d.view.stride_outer + i * d.view.stride_inner]);
+            }
+        }
+        acc.wave_reduce();
+        if (lane == 0) {
+            acc.poison();
+            d.token_min[tok] = acc.mn;
+            d.token_max[tok] = acc.mx;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- token range finaliser (K7b + K8 + K9)
 
 // Single workgroup of 1024 threads.  Valid slots: b*T + t with t < lengths[b] (all if
@@ -1367,6 +1424,17 @@ extern "C" int osq_token_minmax(const float* x, const osq_token_view* view, cons
                            token_max);
     }
     return check_launch("token_minmax");
+}
+
+extern "C" int osq_token_minmax_multi(const osq_site_desc* descs, const int64_t* tok_end, int n_sites,
+                                      int64_t total_tokens, osq_stream stream) {
+    OSQ_REQUIRE(n_sites >= 0 && total_tokens >= 0, "token_minmax_multi: negative size");
+    if (n_sites == 0 || total_tokens == 0) return OSQ_OK;
+    OSQ_REQUIRE(descs && tok_end, "token_minmax_multi: null table");
+    const int grid = grid_for(total_tokens, kWavesPerBlock, kMaxBlocks * 8);
+    hipLaunchKernelGGL(token_minmax_multi_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), descs, tok_end,
+                       n_sites, total_tokens);
+    return check_launch("token_minmax_multi");
 }
 
 extern "C" int osq_token_range_finalize(const float* token_min, const float* token_max,

@@ -87,6 +87,9 @@ class QuantizeBase(nn.Module):
         obs = self.observer
         if hasattr(obs, "observe_into"):
             if X.numel():
+                # nothing reads scale / zero_point before the next launch on this stream unless this very call quantises:
+                # only then may the observation be recorded and reduced later (quantization/deferred.py)
+                object.__setattr__(obs, "_defer_ok", self.fake_quant_enabled != 1)
                 obs.observe_into(X.detach(), observation_mask, seq_pos, QParamSink(scale, zero_point))
         else:   # foreign observer object: the reference's three steps, still on the device
             obs(X.detach(), observation_mask=observation_mask, seq_pos=seq_pos)

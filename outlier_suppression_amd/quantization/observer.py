@@ -24,6 +24,11 @@ def _quant_range(bit, symmetric):
     return 0, (1 << bit) - 1
 
 
+# quantization/deferred.py: while a DeferredSites object is installed here, masked activation observers record their
+# site and return; the statistics of the whole forward are then computed in a handful of launches
+DEFERRED = None
+
+
 class ObserverBase(nn.Module):
     """observer.py:24-119."""
 
@@ -80,6 +85,9 @@ class ObserverBase(nn.Module):
         if self._token_cache is not None:     # keep the per-token extrema; thresholds are applied later, per candidate
             _, _, batch, tokens, lengths = ops.token_minmax(x, seq_pos, lengths, out=self._token_cache)
             object.__setattr__(self, "_last_site", ("tokens", batch, tokens, lengths))   # nn.Module.__setattr__ costs microseconds
+            return
+        if (DEFERRED is not None and self._capture is None and self.__dict__.get("_defer_ok", False)
+                and DEFERRED.add(self, x, lengths, seq_pos, prune, sink)):
             return
         self._home(x.device)
         rule, cur = self.update_rule, None

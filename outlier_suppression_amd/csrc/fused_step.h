@@ -43,7 +43,7 @@ constexpr unsigned int kFusedSpinLimit = 1u << 21;
 struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch
     unsigned int arrive[kFusedShards][16];    // one 64-byte line per counter; zero between launches
     unsigned int epoch, pad0[15];             // launches completed on this workspace
-    unsigned long long side[2][8];            // one granule per selector: tag30 << 34 | empty << 33 | bad << 32 | value bits
+    unsigned long long side[16];              // side[0], side[1]: one granule per selector (tag30 << 34 | empty << 33 | bad << 32 | value bits), adjacent: one 16-byte poll reads both
     unsigned int status, pad3[15];            // sticky: 1 = a selector timed out, 2 = a streaming workgroup timed out
     unsigned int go[2][16];                   // = tag once selector `side` has pulled the per-token extrema into its registers
 };
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         }
         OSQ_FSTAMP(2);
         if (tid == 0)
-            __hip_atomic_store(&st->side[side][0], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->side[side], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         OSQ_FSTAMP(3);
         return;
     }
@@ -336,30 +336,49 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     // ---- phase A2: this wave's padded tokens -> registers / LDS, while the selectors work.  Not before every workgroup
     // has arrived and the selectors hold the extrema (they raise `go`): padded loads issued earlier take bandwidth from the workgroups still in
     // A1 and from the selectors' own loads, and both are what the scale waits for.
+    // a.gate: 0 = nothing waits, 1 = every padded load waits, 2 = the register slots' padded tokens are loaded at once
+    // (they fill the memory system while the last workgroups finish A1), the LDS slots' after `go`
+    if (a.gate != 1) {
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            if (j >= V && j < total) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u)
+                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
     if (a.gate) {
         if (tid == 0) {
             for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
                 if (peek32(&st->go[0][0]) == tag && peek32(&st->go[1][0]) == tag) break;
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
         }
         __syncthreads();
     }
+    if (a.gate == 1) {
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-        const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
-        if (j >= V && j < total) {
-            if (k < SR) {
+        for (int k = 0; k < SR; ++k) {
+            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            if (j >= V && j < total) {
 #pragma unroll
                 for (int u = 0; u < NV; ++u)
-                    hold[k < SR ? k : 0][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
-            } else {
-                v4u32 w[NV];
-#pragma unroll
-                for (int u = 0; u < NV; ++u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
-#pragma unroll
-                for (int u = 0; u < NV; ++u) keep_w[((k - SR) * NV + u) * OSQ_WAVE] = w[u];
+                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
             }
+        }
+    }
+#pragma unroll
+    for (int k = SR; k < S; ++k) {
+        const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+        if (j >= V && j < total) {
+            v4u32 w[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+#pragma unroll
+            for (int u = 0; u < NV; ++u) keep_w[((k - SR) * NV + u) * OSQ_WAVE] = w[u];
         }
     }
     asm volatile("" ::: "memory");
@@ -370,12 +389,14 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         unsigned long long g0 = 0ull, g1 = 0ull;
         bool ok = false;
         const unsigned long long want = static_cast<unsigned long long>(tag & 0x3fffffffu);
+        const auto srs = __builtin_amdgcn_make_buffer_rsrc(st->side, 0, 16, 0x00020000);
         for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
-            g0 = peek64(&st->side[0][0]);
-            g1 = peek64(&st->side[1][0]);
+            const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(srs, 0, 0, 16);      // sc1: both granules, one request
+            g0 = (static_cast<unsigned long long>(w.y) << 32) | w.x;
+            g1 = (static_cast<unsigned long long>(w.w) << 32) | w.z;
             ok = (g0 >> 34) == want && (g1 >> 34) == want;
             if (ok) break;
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(1);
         }
         float s = __builtin_nanf(""), z = s;
         if (!ok) {

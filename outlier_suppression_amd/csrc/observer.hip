@@ -864,7 +864,7 @@ static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): a
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
 static int g_fused_step = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_fused_gate = 1;          // osq_set_tuning("fused_gate", 0): padded tokens are loaded without waiting for the last arrival
+static int g_fused_gate = 2;          // osq_set_tuning("fused_gate", 0|1|2): which padded loads wait for the selectors (fused_step.h, phase A2)
 static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
@@ -1272,7 +1272,7 @@ bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
     if (k == "fused_step") { g_fused_step = value != 0; return true; }
-    if (k == "fused_gate") { g_fused_gate = value != 0; return true; }
+    if (k == "fused_gate") { if (value < 0 || value > 2) return false; g_fused_gate = value; return true; }
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }

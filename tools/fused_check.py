@@ -65,8 +65,9 @@ def timing(shape=(256, 128, 768), steps=400):
         x[..., 7] *= 20
     valid = int(lengths.sum().item()) * shape[2]
     nbytes = 4 * valid + 8 * xs[0].numel()
-    for fused in (0, 1):
+    for fused, gate in ((0, 1), (1, 1), (1, 2), (1, 0), (1, 1), (1, 2), (1, 0)):
         ops.set_tuning("fused_step", fused)
+        ops.set_tuning("fused_gate", gate)
         q = mk()
         with torch.no_grad():
             for i in range(50):
@@ -78,9 +79,10 @@ def timing(shape=(256, 128, 768), steps=400):
             th = time.perf_counter() - t0
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print(f"fused={fused}: {dt / steps * 1e6:.2f} us/step (host enqueue {th / steps * 1e6:.2f}) -> {nbytes / (dt / steps) / 1e9:.1f} GB/s algorithmic "
+        print(f"fused={fused} gate={gate}: {dt / steps * 1e6:.2f} us/step (host enqueue {th / steps * 1e6:.2f}) -> {nbytes / (dt / steps) / 1e9:.1f} GB/s algorithmic "
               f"= {nbytes / (dt / steps) / 8e12 * 100:.1f} % of 8 TB/s; status={status()}", flush=True)
     ops.set_tuning("fused_step", 1)
+    ops.set_tuning("fused_gate", 1)
 
 
 if __name__ == "__main__":

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         const bool arrived = s_word[1] != 0u;
         SideResult r{__builtin_nanf(""), true, false};     // timed out: poison the call instead of hanging
 #ifdef OSQ_FINAL_TIMING
-        long long* sstamps = g_osq_dbg ? g_osq_dbg + 8 * 256 + 8 * side : nullptr;
+        long long* sstamps = g_osq_dbg ? g_osq_dbg + 8 * 256 + 16 * side : nullptr;
 #else
         long long* sstamps = nullptr;
 #endif

@@ -58,11 +58,13 @@ struct SelectArgs {
 // stores on the producer side, sc1 loads on the consumer side).
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
-struct SelShared {            // LDS of one selecting workgroup
+struct alignas(16) SelShared {            // LDS of one selecting workgroup (the list and the partials are read 16 bytes at a time)
     unsigned int hist[kSelBins];
     unsigned int list[kListCap];
+    // per-wave partials of pass 0: plain stores, nothing to initialise, no atomics; every thread folds the sixteen entries
+    unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves];
     SelState sel;
-    unsigned int s_n, s_bad, s_kmin, s_kmax, s_plain, s_fill, s_next, s_found[2], s_sel, s_pos;
+    unsigned int s_fill, s_next, s_found[2], s_sel, s_pos;
     unsigned int s_wtot[kSelWaves];
 };
 
@@ -142,8 +144,7 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
     // LDS set-up overlaps the loads
     for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
     if (tid == 0) {
-        S.s_n = 0u; S.s_bad = 0u; S.s_kmin = 0xffffffffu; S.s_kmax = 0u; S.s_plain = 0u; S.s_fill = 0u;
-        S.s_next = 0xffffffffu; S.s_found[0] = S.s_found[1] = 0xffffffffu; S.s_sel = 0u; S.s_pos = 0u;
+        S.s_fill = 0u; S.s_next = 0xffffffffu; S.s_found[0] = S.s_found[1] = 0xffffffffu; S.s_sel = 0u; S.s_pos = 0u;
     }
     OSQ_SSTAMP(1);
 
@@ -155,6 +156,20 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
 #pragma unroll
     for (int j = 0; j < R4; ++j) {
         const float e[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+        if (!straddle && __all(rem_a[j] >= 4)) {
+            // the whole wave's groups are valid (all but one or two waves of a problem): no validity selects
+            n += 4u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = __uint_as_float(__float_as_uint(e[k]) ^ flip);
+                bad |= x != x;
+                amin = fminf(amin, __builtin_fabsf(x));
+                amax = fmaxf(amax, __builtin_fabsf(x));
+                plain = fmaxf(plain, x);
+                v[4 * j + k] = x;
+            }
+            continue;
+        }
         bool ok[4];
         if (!straddle) {
             const int r = rem_a[j];
@@ -180,28 +195,42 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
         }
     }
     {
+        // every wave leaves its partials in its own LDS words; after ONE barrier every thread folds the sixteen entries
         amin = wave_min(amin);
         amax = wave_max(amax);
         plain = wave_max(plain);
         const bool wbad = wave_any(bad);
         n = wave_inclusive_scan_u32(n);
-        __syncthreads();                       // LDS initialisation above is complete
-        if (lane == OSQ_WAVE - 1) atomicAdd(&S.s_n, n);
+        if (lane == OSQ_WAVE - 1) S.w_n[wv] = n;
         if (lane == 0) {
-            if (wbad) atomicOr(&S.s_bad, 1u);
-            atomicMin(&S.s_kmin, __float_as_uint(amin));       // non-negative floats order like their bit patterns
-            atomicMax(&S.s_kmax, __float_as_uint(amax));
-            atomicMax(&S.s_plain, ordered_bits(plain));
+            S.w_bad[wv] = wbad ? 1u : 0u;
+            S.w_kmin[wv] = __float_as_uint(amin);          // non-negative floats order like their bit patterns
+            S.w_kmax[wv] = __float_as_uint(amax);
+            S.w_plain[wv] = ordered_bits(plain);
         }
     }
-    __syncthreads();
+    __syncthreads();                           // also: the LDS set-up above is complete
+    unsigned int N = 0u, any_bad_u = 0u, kmin = 0xffffffffu, kmax = 0u, plain_o = 0u;
+#pragma unroll
+    for (int k = 0; k < kSelWaves; k += 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(&S.w_n[k]), b = *reinterpret_cast<const uint4*>(&S.w_bad[k]);
+        const uint4 c = *reinterpret_cast<const uint4*>(&S.w_kmin[k]), d = *reinterpret_cast<const uint4*>(&S.w_kmax[k]);
+        const uint4 e = *reinterpret_cast<const uint4*>(&S.w_plain[k]);
+        N += a.x + a.y + a.z + a.w;
+        any_bad_u |= b.x | b.y | b.z | b.w;
+        kmin = min(min(kmin, min(c.x, c.y)), min(c.z, c.w));
+        kmax = max(max(kmax, max(d.x, d.y)), max(d.z, d.w));
+        plain_o = max(max(plain_o, max(e.x, e.y)), max(e.z, e.w));
+    }
+    N = uniform(N);
+    kmin = uniform(kmin);
+    kmax = uniform(kmax);
     OSQ_SSTAMP(2);
     // every thread's loads have returned: the fused launch lets its streaming workgroups use the memory system again
     if (loaded_flag && tid == 0) __hip_atomic_store(loaded_flag, loaded_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int N = S.s_n;
     if (N == 0u) return SideResult{0.0f, false, true};     // both sides agree: nothing observed
-    const bool any_bad = S.s_bad != 0u;
-    float result = from_ordered_bits(S.s_plain);
+    const bool any_bad = uniform(any_bad_u) != 0u;
+    float result = from_ordered_bits(uniform(plain_o));
 
     if (prune && !any_bad) {
         const float rank = aq * static_cast<float>(N - 1u);
@@ -210,8 +239,8 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
         const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
         const float w = rank - rlo;
         if (tid == 0) {
-            S.sel.lo = S.s_kmin;
-            S.sel.width = S.s_kmax - S.s_kmin + 1u;
+            S.sel.lo = kmin;
+            S.sel.width = kmax - kmin + 1u;
             S.sel.rank = k_lo;
             S.sel.shift = level_shift(S.sel.width);
             S.sel.le = 0u;
@@ -294,16 +323,31 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
                 if (lane == 0 && nx < 0x80000000u) atomicMin(&S.s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
             }
             __syncthreads();
+            // ---- rank by counting.  Entry `mine` is the key at rank r iff (#keys < mine) <= r < (#keys <= mine): every
+            // holder of the keys at ranks want / want + 1 reports itself and whether it is non-negative -- one barrier
+            // for the two order statistics AND the sign facts of the shortcut below
             const unsigned int cnt = S.s_fill, want = S.sel.rank;
-            if (static_cast<unsigned int>(tid) < cnt) {     // rank by counting, ties broken by position
-                const unsigned int mine = S.list[tid] & 0x7fffffffu;
-                unsigned int r = 0u;
-                for (unsigned int j = 0; j < cnt; ++j) {
-                    const unsigned int o = S.list[j] & 0x7fffffffu;
-                    r += (o < mine || (o == mine && j < static_cast<unsigned int>(tid))) ? 1u : 0u;
+            if (static_cast<unsigned int>(tid) < cnt) {
+                const unsigned int ent = S.list[tid], mine = ent & 0x7fffffffu;
+                unsigned int lt = 0u, le = 0u;
+                for (unsigned int j = 0; j < cnt; j += 4u) {        // 16-byte LDS reads; entries at or beyond cnt are stale, never counted
+                    const uint4 o4 = *reinterpret_cast<const uint4*>(&S.list[j]);
+                    const unsigned int o[4] = {o4.x & 0x7fffffffu, o4.y & 0x7fffffffu, o4.z & 0x7fffffffu, o4.w & 0x7fffffffu};
+#pragma unroll
+                    for (unsigned int e = 0; e < 4u; ++e) {
+                        const bool in = j + e < cnt;
+                        lt += (in && o[e] < mine) ? 1u : 0u;
+                        le += (in && o[e] <= mine) ? 1u : 0u;
+                    }
                 }
-                if (r == want) S.s_found[0] = mine;
-                if (r == want + 1u) S.s_found[1] = mine;
+                if (lt <= want && want < le) {
+                    S.s_found[0] = mine;
+                    if (!(ent >> 31)) atomicOr(&S.s_pos, 1u);
+                }
+                if (lt <= want + 1u && want + 1u < le) {
+                    S.s_found[1] = mine;
+                    if (!(ent >> 31)) atomicOr(&S.s_pos, 2u);
+                }
             }
             __syncthreads();
             v_lo = S.s_found[0];
@@ -316,14 +360,6 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
             // key.  Both facts are in the S.list (it holds every element of the bin, with sign) as long as the
             // upper key is listed or not reached; otherwise the register pass below decides.
             if (use_shortcut) {
-                if (static_cast<unsigned int>(tid) < cnt) {
-                    const unsigned int e = S.list[tid];
-                    if (!(e >> 31)) {
-                        if (e == v_lo) atomicOr(&S.s_pos, 1u);
-                        if (e == v_hi) atomicOr(&S.s_pos, 2u);
-                    }
-                }
-                __syncthreads();
                 const unsigned int pos = S.s_pos;
                 const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
                 const float d = hi_f - lo_f;

@@ -926,6 +926,57 @@ def test_select_shortcut_equals_full_pass(dev):
     assert n_cases == 960
 
 
+def test_select_large_problems_match_oracle(dev):
+    """token_select_kernel at 4096 .. 32768 token slots (2 .. 8 sixteen-byte groups per thread) against the oracle,
+    bit for bit: i.i.d. values, outlier tokens, heavy duplicates, one constant, values sorted along the slots, all
+    negative, with and without masks, T % 4 != 0, percentiles from 0 to 1; the shortcut and the register pass agree."""
+    from outlier_suppression_amd import ops
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(77)
+    cur = [torch.empty(2, device=dev), torch.empty(2, device=dev)]
+    n_cases = 0
+    for (B, T_) in ((256, 128), (64, 101), (36, 130), (128, 64), (16, 384), (32, 128)):
+        n = B * T_
+        for kind in ("iid", "outliers", "dups", "const", "sorted", "negative"):
+            if kind == "iid":
+                tmax = torch.randn(n, generator=gen).abs() + 2.0
+            elif kind == "outliers":
+                tmax = torch.randn(n, generator=gen).abs() + 2.0
+                tmax[torch.rand(n, generator=gen) < 0.03] *= 25.0
+            elif kind == "dups":
+                tmax = torch.randint(0, 7, (n,), generator=gen).float()
+            elif kind == "const":
+                tmax = torch.full((n,), 3.5)
+            elif kind == "sorted":
+                tmax = torch.sort(torch.randn(n, generator=gen).abs() + 1.0).values
+            else:
+                tmax = -torch.rand(n, generator=gen) * 4.0 - 0.25
+            tmin = tmax - torch.rand(n, generator=gen) * 3.0 - (torch.randint(0, 5, (n,), generator=gen).float() if kind == "dups" else 0.0)
+            for masked in (False, True):
+                if masked:
+                    L = torch.randint(T_ // 2, T_ + 1, (B,), generator=gen)
+                    L[0] = T_
+                else:
+                    L = torch.full((B,), T_)
+                valid = (torch.arange(T_)[None, :] < L[:, None]).reshape(-1)
+                tmin_d, tmax_d, L_d = tmin.to(dev), tmax.to(dev), L.to(dev)
+                for p in (0.0, 0.3, 0.5, 0.77, 0.9, 0.95, 0.99, 0.999, 1.0):
+                    for k, flag in enumerate((1, 0)):
+                        ops.set_tuning("select_shortcut", flag)
+                        try:
+                            ops.token_range_finalize(tmin_d, tmax_d, B, T_, L_d if masked else None, True, p, ops.UPDATE_NONE, 0,
+                                                     None, None, 0, 63, False, None, cur[k])
+                        finally:
+                            ops.set_tuning("select_shortcut", 1)
+                    a, b = cur[0].cpu(), cur[1].cpu()
+                    assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (B, T_, kind, masked, p, a, b)
+                    lo, up = OB.prune_thresholds(tmin[valid].numpy(), tmax[valid].numpy(), p)
+                    want = np.array([up if lo > up else lo, up], dtype=np.float32)
+                    assert np.array_equal(a.numpy().view(np.int32), want.view(np.int32)), (B, T_, kind, masked, p, a, want)
+                    n_cases += 1
+    assert n_cases == 6 * 6 * 2 * 9
+
+
 # ----------------------------------------------------------------------------------- remaining observers (N3)
 
 def test_other_observers_golden(golden, eq32, dev):

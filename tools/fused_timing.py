@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(1234)
 full = len(sys.argv) > 1 and sys.argv[1] == "full"
 lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, 129, (shape[0],), generator=g)).to(dev)
 xs = [torch.randn(*shape, device=dev) for _ in range(4)]
-dbg = torch.zeros(258 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(260 * 8, dtype=torch.int64, device=dev)
 assert lib.osq_debug_buffer(dbg.data_ptr()) == 0
 q = mk()
 with torch.no_grad():
@@ -24,14 +24,14 @@ with torch.no_grad():
     dbg.zero_()
     q(xs[2], lengths, 1)
     torch.cuda.synchronize()
-d = dbg.view(258, 8).cpu()
-sel = d[256:]
+d = dbg.view(260, 8).cpu()
+sel = d[256:].reshape(2, 16)
 d = d[:256]
 t0 = int(d[:, 0][d[:, 0] > 0].min())
 us = lambda v: (v.double() - t0) / 100.0
 print("selectors (us since first start): ", [[round(float(x), 2) for x in us(d[b, :4])] for b in range(2)])
 for side in range(2):
-    print(f"select side {side} (issue, loads+pass0, hist+scan, list+rank, threshold) us:", [round(float(x), 2) for x in us(sel[side, :6])])
+    print(f"select side {side} (issue, loads+pass0, hist+scan, list+rank, threshold) us:", [round(float(x), 2) for x in us(sel[side, :11])], "cnt/total/M/sh/before", sel[side, 11:16].tolist())
 s = d[2:]
 for k, name in [(0, "start"), (7, "prefix sums"), (1, "mapped"), (2, "A1 done (wave 0)"), (3, "arrived"), (4, "scale seen"), (5, "after barrier"), (6, "end")]:
     v = us(s[:, k])

@@ -252,6 +252,43 @@ def test_token_observer_vs_oracle(shape, seq_pos, eq32, dev):
             assert ob.cnt == st.cnt
 
 
+@pytest.mark.parametrize("shape,seq_pos,n_mask,name", [
+    ((8, 12, 384, 384), 2, 8, "attention_probs"),          # configs[2]: SQuAD, T = 384 (tokens-first rows of 12 x 384 = 4608 features)
+    ((8, 12, 384, 64), 2, 8, "query"),
+    ((8, 384, 3072), 1, 8, "intermediate"),
+    ((4, 1024, 1024), 1, 4, "final_layer_norm"),            # configs[4]: BART-large encoder, d = 1024, T = 1024
+    ((4, 1024, 4096), 1, 4, "fc1"),
+    ((16, 1024, 1024), 1, 4, "attention_probs"),            # 3-D probabilities [B*h, T, S] with a length-B mask: zip truncation
+    ((64, 62, 1024), 1, 4, "attention_probs"),              # decoder cross-attention
+    ((4, 62, 1024), 1, 4, "decoder_ln"),
+])
+def test_config_site_shapes_vs_oracle(shape, seq_pos, n_mask, name, eq32, dev):
+    """The site shapes of BASELINE configs 2 (SQuAD, T = 384) and 4 (BART-large, d = 1024, T = 1024) at their real
+    sizes against the oracle (SURVEY 8a size table; quirk 9: a 3-D probability tensor with a length-B mask is cut to
+    its first B rows by remove_padding's zip)."""
+    from outlier_suppression_amd.quantization.observer import AvgPruneMinMaxObserver
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(hash(shape) % 1000)
+    Tn = shape[seq_pos]
+    ob = AvgPruneMinMaxObserver(bit=6, symmetric=False).to(dev)
+    ob.set_name(f"layer.{name}_post_act_fake_quantize.observer")
+    st = OB.ObserverState(bit=6, symmetric=False, name=ob.name)
+    ob.set_percentile(0.93)
+    st.percentile = 0.93
+    for it in range(2):
+        x = torch.rand(*shape, generator=gen) if name == "attention_probs" else torch.randn(*shape, generator=gen)
+        if name != "attention_probs":
+            x.select(-1, 1).mul_(15.0)
+        L = torch.randint(1, Tn + 1, (n_mask,), generator=gen)
+        L[0] = Tn
+        ob(x.to(dev), L.to(dev), seq_pos)
+        OB.observe_avg_prune_minmax(st, x.numpy(), L.numpy(), seq_pos)
+        assert eq32(N(ob.min_val), st.min_val) and eq32(N(ob.max_val), st.max_val), (shape, it, N(ob.min_val), st.min_val, N(ob.max_val), st.max_val)
+    scale, zp = ob.calculate_qparams(ob.min_val, ob.max_val)
+    s_o, z_o = st.qparams()
+    assert eq32(N(scale), s_o) and np.array_equal(N(zp), z_o)
+
+
 def test_flat_and_channel_observers_vs_oracle(eq32, dev):
     from outlier_suppression_amd.quantization.observer import MinMaxObserver, AvgMinMaxObserver
     from oracle import observer_oracle as OB

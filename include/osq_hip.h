@@ -89,7 +89,8 @@ size_t      osq_workspace_bytes(void);
  *   "obs_blocks" grid cap of osq_observe_flat (768: power-of-two grids put a thread's strided loads on the
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
- *   threshold pass (the last two exist so that tests can drive every implementation). */
+ *   threshold pass; "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
+ *   of the one-launch resident form (the last three exist so that tests can drive every implementation). */
 int osq_set_tuning(const char* key, int value);
 
 /* Measurement aid (bench.py).  The events given to osq_time_next_launch ride on the dispatch packet of the
@@ -379,6 +380,14 @@ int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_t n, int n_
 int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token_view* view,
                                     const int64_t* lengths, int n_evals,
                                     void* workspace, osq_stream stream);
+/* The whole per-tensor search in ONE persistent launch (between _begin and _commit; replaces the _evals_* / _done loop):
+ * the valid part of the tensor is loaded once into the registers of a one-workgroup-per-CU grid, every loss
+ * evaluation is one exchange of per-workgroup partial sums through the workspace.  view == NULL: x is flat, n
+ * elements; otherwise a token view with valid lengths (n ignored).  OSQ_ERR_UNSUPPORTED (nothing launched): more
+ * than 16 float4 per lane of the grid (67 MB on 256 CUs), batch > 1024, a misaligned flat tensor, or
+ * osq_set_tuning("mse_resident", 0) -- the caller then runs the _evals_* loop. */
+int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
+                              const int64_t* lengths, void* workspace, osq_stream stream);
 int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
 int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt,
                               double* min_val, double* max_val,

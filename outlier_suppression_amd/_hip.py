@@ -20,6 +20,7 @@ PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
 TIME_LAYERNORM, TIME_FUSED_STEP = 6, 7
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
+ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -85,6 +86,7 @@ SIGNATURES = {
     "osq_msefast_tensor_begin": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "osq_msefast_tensor_evals_flat": (_I, [_P, _P, _L, _I, _P, _P]),
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
+    "osq_msefast_tensor_search": (_I, [_P, _P, _L, ctypes.POINTER(TokenView), _P, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
     "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -647,6 +647,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }
     else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 3, "fq_nt must be 0..3"); osq::g_fq_nt = value; }
     else if (osq::set_observer_tuning(key, value)) { }
+    else if (osq::set_msefast_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
     return OSQ_OK;
 }

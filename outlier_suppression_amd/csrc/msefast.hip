@@ -16,6 +16,7 @@
 // observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error in
 // fp32, summed in float64 from the first addition on, the mean rounded to fp32 once (the
 // reference's torch mean is an fp32 sum whose order depends on the machine's vector width).
+#include <string>
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -499,6 +500,217 @@ __global__ void msefast_done_kernel(const TensorSearch* __restrict__ ts, int* __
     if (threadIdx.x == 0 && blockIdx.x == 0) done_out[0] = ts->S.done;
 }
 
+// ---------------------------------------------------------------- per-tensor, resident: the whole search in ONE launch
+//
+// The launch-per-evaluation form above costs ~12 us per evaluation on a BERT-base site whatever the tensor's size (a
+// kernel boundary, the parameters' round trip through memory, the ticket of the last workgroup, and a 6-27 MB tensor
+// streamed again from L2 / HBM), and an asymmetric per-tensor search is 300-600 evaluations.  Here the VALID part of
+// the tensor is loaded ONCE into the registers of a persistent grid (one 1024-thread workgroup per CU; 16 float4 per
+// lane = 67 MB on 256 CUs), and one evaluation is: every thread's squared errors -> one double per workgroup,
+// published as two tagged 8-byte granules -> EVERY workgroup collects all partials, adds them in the same order and
+// advances its own copy of the state machine (identical arithmetic on identical numbers: no master, no second
+// exchange).  One hop through memory per evaluation instead of a kernel boundary.  Padded slots hold 0.0f, whose
+// fake-quant is 0 for every candidate (the zero-point is clamped into the quantised range), so the loop carries no mask.
+// Tags: epoch + 1 + evaluation; the epoch word lives in the workspace (read by every workgroup at its start, advanced by
+// workgroup 0 at its end -- every workgroup has taken part in the last evaluation by then).  Two buffers of granules:
+// a workgroup can be at most one evaluation ahead of the slowest reader of its previous partial.
+constexpr int kResThreads = 1024;
+constexpr int kResWaves = kResThreads / OSQ_WAVE;
+constexpr unsigned int kResSpinLimit = 1u << 22;
+
+struct ResidentState {                                   // workspace slice, all-zero before the first launch
+    unsigned int epoch, pad0[15];                        // tags handed out so far
+    unsigned int status, pad1[15];                       // sticky: 1 = a workgroup timed out waiting for a partial
+    unsigned long long part[2][kResidentMaxBlocks][2];   // [evaluation parity][workgroup]{tag << 32 | low word, tag << 32 | high word}
+};
+static_assert(sizeof(ResidentState) == kWsResidentBytes, "ResidentState must fill its slice of the workspace");
+
+struct ResidentArgs {
+    const float* x;
+    int64_t n;                    // flat tensor: n elements (v.batch == 0)
+    osq_token_view v;             // masked / strided activation: valid tokens only
+    const int64_t* lengths;
+    int vec;
+    TensorSearch* ts;
+    ResidentState* rs;
+};
+
+template <int K>
+__global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentArgs a) {
+    __shared__ unsigned int pre[1025];
+    __shared__ unsigned int s_wtot[kResWaves];
+    __shared__ double s_part[kResWaves], s_tot[kResWaves];
+    __shared__ Search S;
+    __shared__ float s_scale, s_zp;
+    __shared__ double s_scale_d, s_count;
+    __shared__ unsigned int s_epoch, s_fail;
+
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    const unsigned int NT = gridDim.x * kResThreads, gt = blockIdx.x * kResThreads + tid;
+    ResidentState* rs = a.rs;
+    if (tid == 0) {
+        S = a.ts->S;
+        s_scale = a.ts->scale;
+        s_zp = a.ts->zp;
+        s_scale_d = a.ts->scale_d;
+        s_epoch = __hip_atomic_load(&rs->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fail = 0u;
+    }
+    // ---- load this thread's share of the valid elements: float4 group g = gt + k * NT of the valid-element stream
+    float4 hold[K];
+    if (a.v.batch == 0) {
+        const int64_t n4 = a.n / 4;
+        const int tail = static_cast<int>(a.n - n4 * 4);
+        const float4* x4 = reinterpret_cast<const float4*>(a.x);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t g = static_cast<int64_t>(gt) + static_cast<int64_t>(k) * NT;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < n4) {
+                h = x4[g];
+            } else if (g == n4 && tail) {
+                const float* t = a.x + n4 * 4;
+                h.x = t[0];
+                if (tail > 1) h.y = t[1];
+                if (tail > 2) h.z = t[2];
+            }
+            hold[k] = h;
+        }
+        if (tid == 0) s_count = static_cast<double>(a.n);
+    } else {
+        const osq_token_view v = a.v;
+        const unsigned int Bu = static_cast<unsigned int>(v.batch);
+        {
+            unsigned int len = 0u;
+            if (static_cast<unsigned int>(tid) < Bu) {
+                int64_t l = a.lengths ? a.lengths[tid] : v.tokens;
+                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
+                len = static_cast<unsigned int>(l);
+            }
+            const unsigned int incl = wave_inclusive_scan_u32(len);
+            if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl;
+            __syncthreads();
+            unsigned int base = 0u;
+#pragma unroll
+            for (int k = 0; k < kResWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
+            if (tid == 0) pre[0] = 0u;
+            if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
+            __syncthreads();
+        }
+        const unsigned int V = pre[Bu];                                // valid tokens
+        const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
+        const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
+        if (tid == 0) s_count = static_cast<double>(V) * static_cast<double>(F);   // observer.py:72-84: what remove_padding keeps
+        auto token_base = [&](unsigned int j) -> const float* {       // valid token j -> its first element
+            unsigned int lo = 0u, hi = Bu;                             // invariant pre[lo] <= j < pre[hi]
+            while (lo + 1u < hi) {
+                const unsigned int mid = (lo + hi) >> 1;
+                if (pre[mid] <= j) lo = mid; else hi = mid;
+            }
+            return a.x + static_cast<int64_t>(lo) * v.stride_batch + static_cast<int64_t>(j - pre[lo]) * v.stride_token;
+        };
+        if (a.vec) {                                                   // feat_inner contiguous, 16-byte aligned segments
+            const unsigned int inner4 = fi / 4u, F4 = F / 4u;
+            const uint64_t G = static_cast<uint64_t>(V) * F4;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint64_t g = static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT;
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < G) {
+                    const unsigned int j = static_cast<unsigned int>(g / F4), i = static_cast<unsigned int>(g - static_cast<uint64_t>(j) * F4);
+                    const unsigned int o = i / inner4, ii = i - o * inner4;
+                    h = reinterpret_cast<const float4*>(token_base(j) + static_cast<int64_t>(o) * v.stride_outer)[ii];
+                }
+                hold[k] = h;
+            }
+        } else {
+            const uint64_t E = static_cast<uint64_t>(V) * F;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float e4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint64_t q = (static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT) * 4u + c;
+                    if (q < E) {
+                        const unsigned int j = static_cast<unsigned int>(q / F), f = static_cast<unsigned int>(q - static_cast<uint64_t>(j) * F);
+                        const unsigned int o = f / fi, i = f - o * fi;
+                        e4[c] = token_base(j)[static_cast<int64_t>(o) * v.stride_outer + static_cast<int64_t>(i) * v.stride_inner];
+                    }
+                }
+                hold[k] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int base_tag = s_epoch + 1u;
+    const double count = s_count;
+    const float qmin = static_cast<float>(S.quant_min), qmax = static_cast<float>(S.quant_max);
+    const bool f64 = S.f64 != 0;
+    unsigned int e = 0u;
+    // ---- one trip per loss evaluation
+    while (!S.done) {                                                  // LDS, uniform: written by thread 0 before the closing barrier
+        const float s = s_scale, z = s_zp;
+        const double sd = s_scale_d;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += f64 ? sq_err4_f64(hold[k], sd, z, qmin, qmax) : sq_err4(hold[k], s, z, qmin, qmax);
+        acc = wave_sum(acc);
+        if (lane == 0) s_part[wv] = acc;
+        __syncthreads();
+        const unsigned int tag = base_tag + e;
+        if (tid == 0) {
+            double p = 0.0;
+            for (int k = 0; k < kResWaves; ++k) p += s_part[k];
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
+            unsigned long long* slot = rs->part[e & 1u][blockIdx.x];
+            __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // every workgroup collects every partial: thread t polls workgroup t's granules
+        double mine = 0.0;
+        if (static_cast<unsigned int>(tid) < gridDim.x) {
+            const unsigned long long* slot = rs->part[e & 1u][tid];
+            unsigned long long g0 = 0ull, g1 = 0ull;
+            unsigned int spins = 0u;
+            for (; spins < kResSpinLimit; ++spins) {
+                g0 = __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (static_cast<unsigned int>(g0 >> 32) == tag && static_cast<unsigned int>(g1 >> 32) == tag) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (spins == kResSpinLimit) s_fail = 1u;
+            mine = __longlong_as_double(static_cast<long long>(((g1 & 0xffffffffull) << 32) | (g0 & 0xffffffffull)));
+        }
+        mine = wave_sum(mine);                                         // workgroups in order of their number: the same in every workgroup
+        if (lane == 0) s_tot[wv] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            if (s_fail) {                                              // poison the search instead of hanging
+                S.best_min = S.best_max = __builtin_nan("");
+                S.done = 1;
+                __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                double tot = 0.0;
+                for (int k = 0; k < kResWaves; ++k) tot += s_tot[k];
+                const double mean = tot / count;
+                S.tell(f64 ? mean : static_cast<double>(static_cast<float>(mean)));
+                if (!S.done) {
+                    float sc, zp;
+                    double scd;
+                    loss_qparams(S.cand_min, S.cand_max, S.quant_min, S.quant_max, S.symmetric, &sc, &zp, &scd);
+                    s_scale = sc; s_zp = zp; s_scale_d = scd;
+                }
+            }
+        }
+        __syncthreads();
+        ++e;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        a.ts->S = S;
+        __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 static inline int grid_for(int64_t items, int per_block, int max_blocks) {
     int64_t b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -573,6 +785,58 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
         hipLaunchKernelGGL(msefast_token_loss_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, vec,
                            static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count);
     return check_launch("msefast_tensor_evals_tokens");
+}
+
+static int g_mse_resident = 1;     // osq_set_tuning("mse_resident", 0): per-tensor searches always run one launch per evaluation (tests)
+namespace osq { bool set_msefast_tuning(const char* key, int value) {
+    if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
+    return false;
+} }
+
+/* The whole per-tensor search in one persistent launch (between osq_msefast_tensor_begin and _commit).
+ * OSQ_ERR_UNSUPPORTED: the tensor does not fit the grid's registers (or the layout / device does not qualify) and
+ * nothing was launched -- the caller runs osq_msefast_tensor_evals_* instead. */
+extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
+                                         const int64_t* lengths, void* workspace, osq_stream stream) {
+    OSQ_REQUIRE(state && x && workspace, "msefast_tensor_search: null pointer");
+    if (!g_mse_resident) return OSQ_ERR_UNSUPPORTED;
+    ResidentArgs a{};
+    a.x = x;
+    a.ts = static_cast<TensorSearch*>(state);
+    a.rs = static_cast<ResidentState*>(Workspace(workspace).resident());
+    int64_t elems;
+    if (view) {
+        const osq_token_view v = *view;
+        OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_search: empty view");
+        if (v.batch > 1024) return OSQ_ERR_UNSUPPORTED;
+        elems = v.batch * v.tokens * v.feat_outer * v.feat_inner;
+        a.v = v;
+        a.lengths = lengths;
+        a.vec = v.stride_inner == 1 && v.feat_inner % 4 == 0 && aligned16(x) && v.stride_batch % 4 == 0 &&
+                v.stride_token % 4 == 0 && (v.feat_outer == 1 || v.stride_outer % 4 == 0);
+    } else {
+        OSQ_REQUIRE(n > 0, "msefast_tensor_search: empty tensor");
+        if (!aligned16(x)) return OSQ_ERR_UNSUPPORTED;
+        elems = n;
+        a.n = n;
+    }
+    static int grid = -1;       // per process; devices of one node are identical
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_kernel<16>), kResThreads);
+    if (grid < 1 || grid > kResidentMaxBlocks || grid > kResThreads) return OSQ_ERR_UNSUPPORTED;
+    const int64_t per_k = static_cast<int64_t>(grid) * kResThreads * 4;      // elements one float4 per lane holds
+    const int64_t need = (elems + per_k - 1) / per_k;
+    if (need > 16) return OSQ_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!persistent_serialize(st)) return OSQ_ERR_UNSUPPORTED;
+#define OSQ_RESIDENT(KK) hipLaunchKernelGGL(msefast_resident_kernel<KK>, dim3(grid), dim3(kResThreads), 0, st, a)
+    if (need <= 1) OSQ_RESIDENT(1);
+    else if (need <= 2) OSQ_RESIDENT(2);
+    else if (need <= 4) OSQ_RESIDENT(4);
+    else if (need <= 8) OSQ_RESIDENT(8);
+    else if (need <= 12) OSQ_RESIDENT(12);
+    else OSQ_RESIDENT(16);
+#undef OSQ_RESIDENT
+    return check_launch("msefast_tensor_search");
 }
 
 extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream) {

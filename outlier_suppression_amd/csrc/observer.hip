@@ -1511,7 +1511,7 @@ namespace osq {
 
 // Workgroups that can be resident together: the fused kernel spins across workgroups, so the grid must not
 // exceed what the device holds at once.  One 1024-thread workgroup per CU (its 16 waves own the CU's register file).
-static int fused_grid_for(const void* kernel) {
+int persistent_grid_for(const void* kernel, int threads) {
     static int cus[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
@@ -1522,11 +1522,14 @@ static int fused_grid_for(const void* kernel) {
     }
     if (cus[dev] < 3) return 0;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFusedThreads, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         return 0;
     }
-    int grid = cus[dev];
+    return cus[dev];
+}
+static int fused_grid_for(const void* kernel) {
+    int grid = persistent_grid_for(kernel, kFusedThreads);
     if (g_fused_grid >= 3 && g_fused_grid < grid) grid = g_fused_grid;
     return grid;
 }
@@ -1535,7 +1538,7 @@ static int fused_grid_for(const void* kernel) {
 // grids would spin on each other until their time-outs.  Launches of one stream are ordered anyway; when the stream
 // changes, the new stream first waits for everything the previous one has been given (one event, only at the switch).
 // Other PROCESSES sharing the GPU cannot be ordered from here: set OSQ_FUSED_STEP=0 there.
-static bool fused_serialize(hipStream_t st) {
+bool persistent_serialize(hipStream_t st) {
     static std::mutex mu;
     static hipStream_t last[64];
     static hipEvent_t ev[64];
@@ -1566,7 +1569,7 @@ static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) 
     static int grid = -1;       // per process; devices of one node are identical
     if (grid < 0 || g_fused_grid) grid = fused_grid_for(reinterpret_cast<const void*>(&observe_fq_fused_kernel<NV>));
     if (grid < 3) return false;
-    if (!fused_serialize(st)) return false;
+    if (!persistent_serialize(st)) return false;
     const TimingHook th = take_timing_hook(OSQ_TIME_FUSED_STEP);
     hipExtLaunchKernelGGL(observe_fq_fused_kernel<NV>, dim3(grid), dim3(kFusedThreads), 0, st, th.start, th.stop, 0, a, fin);
     return true;

@@ -20,9 +20,12 @@ constexpr size_t kWsScratchBytes = kWsFamilies * kWsScratchPerFamily;
 constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
 constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of token_select_kernel (8 B per problem)
 constexpr size_t kWsFusedBytes = 1024;               // FusedState of the one-launch observe + fake-quant (fused_step.h)
+constexpr int kResidentMaxBlocks = 512;              // workgroups of the resident MSEFast search (msefast.hip)
+constexpr size_t kWsResidentBytes = 128 + 2 * kResidentMaxBlocks * 2 * 8;   // its epoch / status words + two buffers of partial-sum granules
 
 void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
+bool set_msefast_tuning(const char* key, int value);    // msefast.hip
 
 // Measurement aid (osq_time_next_launch): events that the next launch of kernel family `which` on this thread
 // carries on its dispatch packet (hipExtLaunchKernelGGL); {nullptr, nullptr} = plain launch.
@@ -30,6 +33,13 @@ struct TimingHook {
     hipEvent_t start, stop;
 };
 TimingHook take_timing_hook(int which);
+
+// Persistent launches (workgroups that spin on each other: the fused observe + fake-quant step, the resident MSEFast
+// search).  persistent_grid_for: workgroups of `threads` threads that are resident together (one per CU), 0 = do not
+// launch.  persistent_serialize: two such grids must never be in flight together on one device -- when the stream
+// changes, the new stream first waits for what the previous one was given (observer.hip).
+int persistent_grid_for(const void* kernel, int threads);
+bool persistent_serialize(hipStream_t st);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -51,7 +61,7 @@ static inline int check_launch(const char* what) {
 }
 
 // Caller-owned scratch: [8 x 4 KiB of ticket counters][8 x 64 KiB of partials][16 KiB + 64 B wide-finaliser state]
-// [64 KiB rendezvous words][1 KiB state of the fused observe + fake-quant launch].  Counters are zero between
+// [64 KiB rendezvous words][1 KiB state of the fused observe + fake-quant launch][16.1 KiB state of the resident MSEFast search].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
@@ -64,6 +74,7 @@ struct Workspace {
         return reinterpret_cast<unsigned long long*>(base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes);
     }
     void* fused() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes; }
+    void* resident() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes + kWsFusedBytes; }
 };
 
 }  // namespace osq

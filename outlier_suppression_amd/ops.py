@@ -549,10 +549,16 @@ def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symm
             view = token_view(x, seq_pos, lengths.numel())
     else:
         view, lengths = None, None
+    # the whole search in one persistent launch when the tensor fits the grid's registers ...
+    rc = lib.osq_msefast_tensor_search(_hip.ptr(state), _hip.ptr(x), x.numel(), None if view is None else ctypes.byref(view),
+                                       _hip.ptr(lengths), _hip.ptr(ws), st)
+    if rc not in (0, _hip.ERR_UNSUPPORTED):
+        _hip.check(rc, "msefast_tensor_search")
+    # ... otherwise one launch per loss evaluation, enqueued in chunks
     done = torch.zeros(1, dtype=torch.int32, device=dev)
     chunk = chunk or (64 if two_d else 32)
     launched = 0
-    while True:
+    while rc != 0:
         if view is None:
             _hip.check(lib.osq_msefast_tensor_evals_flat(_hip.ptr(state), _hip.ptr(x), x.numel(), chunk, _hip.ptr(ws), st),
                        "msefast_evals_flat")

@@ -24,6 +24,7 @@ namespace osq {
 
 constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / OSQ_WAVE;
+typedef unsigned int v4u32_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- bounded Brent, ask/tell
 
@@ -238,6 +239,35 @@ __device__ __forceinline__ double sq_err_f64(float xf, double s, double z, doubl
     const double y = (q - z) * s;
     const double d = fabs(y - x);
     return d * d;
+}
+// The same with x / s computed as Markstein's sequence for a divisor shared by all elements: y = RN(1 / s) once, then
+// q0 = x*y, two rounds of (r = x - q*s exactly, by fma; q += r*y).  The second round's result is the correctly rounded
+// quotient -- the same bits as the division -- whenever no intermediate over/underflows and the significand of s is
+// not all ones (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, 2nd ed., Theorem 4.9 / section
+// 4.7.2).  x holds finite fp32 values (|x| in [1.4e-45, 3.4e38] or 0) and s lies in [1e-8, 1.1e37], so quotients stay
+// within [1e-82, 3.4e46]: nothing leaves the normal range.  5 full-rate fma-class instructions instead of
+// v_rcp_f64 (quarter rate) + its Newton steps + div_scale / div_fmas / div_fixup.  The caller checks the two conditions.
+__device__ __forceinline__ double sq_err_f64_rcp(float xf, double s, double y, double z, double qmin, double qmax) {
+    const double x = xf;
+    const double q0 = x * y;
+    const double q1 = __builtin_fma(__builtin_fma(-q0, s, x), y, q0);
+    const double u = __builtin_fma(__builtin_fma(-q1, s, x), y, q1);
+    // u is finite here, so (rint(u) - u) + u == rint(u) exactly (the difference is exact by Sterbenz's lemma, or 0), and
+    // the clamp never meets a NaN: fmax / fmin give what the two compare-and-selects give
+    const double x_int = rint(u) + z;
+    const double q = __builtin_fmin(__builtin_fmax(x_int, qmin), qmax);
+    const double yv = (q - z) * s;
+    const double d = fabs(yv - x);
+    return d * d;
+}
+__device__ __forceinline__ double sq_err4_f64_rcp(const float4& a, double s, double y, double z, double qmin, double qmax) {
+    return (sq_err_f64_rcp(a.x, s, y, z, qmin, qmax) + sq_err_f64_rcp(a.y, s, y, z, qmin, qmax)) +
+           (sq_err_f64_rcp(a.z, s, y, z, qmin, qmax) + sq_err_f64_rcp(a.w, s, y, z, qmin, qmax));
+}
+__device__ __forceinline__ bool rcp_division_exact(double s, double x_min, double x_max) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(s));
+    const bool finite = fabs(x_min) <= 3.5e38 && fabs(x_max) <= 3.5e38;        // false for NaN / inf extrema
+    return finite && (b & 0xfffffffffffffull) != 0xfffffffffffffull && s >= 1e-9 && s <= 1e38;
 }
 __device__ __forceinline__ double sq_err4_f64(const float4& a, double s, double z, double qmin, double qmax) {
     return (sq_err_f64(a.x, s, z, qmin, qmax) + sq_err_f64(a.y, s, z, qmin, qmax)) +
@@ -539,11 +569,12 @@ template <int K>
 __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentArgs a) {
     __shared__ unsigned int pre[1025];
     __shared__ unsigned int s_wtot[kResWaves];
-    __shared__ double s_part[kResWaves], s_tot[kResWaves];
+    __shared__ double s_part[kResWaves];
     __shared__ Search S;
     __shared__ float s_scale, s_zp;
     __shared__ double s_scale_d, s_count;
-    __shared__ unsigned int s_epoch, s_fail;
+    __shared__ double s_rcp;
+    __shared__ unsigned int s_epoch, s_done, s_fast, s_kv;
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
     const unsigned int NT = gridDim.x * kResThreads, gt = blockIdx.x * kResThreads + tid;
@@ -554,7 +585,9 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
         s_zp = a.ts->zp;
         s_scale_d = a.ts->scale_d;
         s_epoch = __hip_atomic_load(&rs->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_fail = 0u;
+        s_done = a.ts->S.done ? 1u : 0u;
+        s_rcp = 1.0 / a.ts->scale_d;
+        s_fast = rcp_division_exact(a.ts->scale_d, a.ts->S.x_min, a.ts->S.x_max) ? 1u : 0u;
     }
     // ---- load this thread's share of the valid elements: float4 group g = gt + k * NT of the valid-element stream
     float4 hold[K];
@@ -576,7 +609,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
             }
             hold[k] = h;
         }
-        if (tid == 0) s_count = static_cast<double>(a.n);
+        if (tid == 0) { s_count = static_cast<double>(a.n); s_kv = static_cast<unsigned int>(((a.n + 3) / 4 + NT - 1) / NT); }
     } else {
         const osq_token_view v = a.v;
         const unsigned int Bu = static_cast<unsigned int>(v.batch);
@@ -600,7 +633,11 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
         const unsigned int V = pre[Bu];                                // valid tokens
         const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
         const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
-        if (tid == 0) s_count = static_cast<double>(V) * static_cast<double>(F);   // observer.py:72-84: what remove_padding keeps
+        if (tid == 0) {
+            s_count = static_cast<double>(V) * static_cast<double>(F);   // observer.py:72-84: what remove_padding keeps
+            const uint64_t groups = (static_cast<uint64_t>(V) * F + 3u) / 4u;
+            s_kv = static_cast<unsigned int>((groups + NT - 1) / NT);
+        }
         auto token_base = [&](unsigned int j) -> const float* {       // valid token j -> its first element
             unsigned int lo = 0u, hi = Bu;                             // invariant pre[lo] <= j < pre[hi]
             while (lo + 1u < hi) {
@@ -646,65 +683,111 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
     const double count = s_count;
     const float qmin = static_cast<float>(S.quant_min), qmax = static_cast<float>(S.quant_max);
     const bool f64 = S.f64 != 0;
+    const int kv = static_cast<int>(s_kv);                 // float4 slots of every lane that can hold valid data (the rest is padding)
     unsigned int e = 0u;
+#ifdef OSQ_FINAL_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define OSQ_RSTAMP(i) do { if (blockIdx.x == 0 && tid == 0) { const long long now = wall_clock64(); tacc[i] += now - tprev; tprev = now; } } while (0)
+    if (blockIdx.x == 0 && tid == 0) tprev = wall_clock64();
+#else
+#define OSQ_RSTAMP(i) do { } while (0)
+#endif
     // ---- one trip per loss evaluation
-    while (!S.done) {                                                  // LDS, uniform: written by thread 0 before the closing barrier
+    while (!s_done) {                                                  // LDS, uniform: written by thread 0 before the closing barrier
         const float s = s_scale, z = s_zp;
-        const double sd = s_scale_d;
+        const double sd = s_scale_d, rcp = s_rcp;
+        const bool fast = s_fast != 0u;
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc += f64 ? sq_err4_f64(hold[k], sd, z, qmin, qmax) : sq_err4(hold[k], s, z, qmin, qmax);
+        for (int k = 0; k < K; ++k) {
+            if (k < kv) {
+                if (!f64) acc += sq_err4(hold[k], s, z, qmin, qmax);
+                else if (fast) acc += sq_err4_f64_rcp(hold[k], sd, rcp, z, qmin, qmax);
+                else acc += sq_err4_f64(hold[k], sd, z, qmin, qmax);
+            }
+        }
         acc = wave_sum(acc);
         if (lane == 0) s_part[wv] = acc;
         __syncthreads();
-        const unsigned int tag = base_tag + e;
-        if (tid == 0) {
+        OSQ_RSTAMP(0);
+        if (wv == 0) {
+            // ---- wave 0: publish this workgroup's partial, collect everybody's, advance the state machine
+            const unsigned int tag = base_tag + e;
             double p = 0.0;
+#pragma unroll
             for (int k = 0; k < kResWaves; ++k) p += s_part[k];
-            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
-            unsigned long long* slot = rs->part[e & 1u][blockIdx.x];
-            __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // every workgroup collects every partial: thread t polls workgroup t's granules
-        double mine = 0.0;
-        if (static_cast<unsigned int>(tid) < gridDim.x) {
-            const unsigned long long* slot = rs->part[e & 1u][tid];
-            unsigned long long g0 = 0ull, g1 = 0ull;
-            unsigned int spins = 0u;
-            for (; spins < kResSpinLimit; ++spins) {
-                g0 = __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g1 = __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (static_cast<unsigned int>(g0 >> 32) == tag && static_cast<unsigned int>(g1 >> 32) == tag) break;
-                __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) {
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
+                unsigned long long* slot = rs->part[e & 1u][blockIdx.x];
+                __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (spins == kResSpinLimit) s_fail = 1u;
-            mine = __longlong_as_double(static_cast<long long>(((g1 & 0xffffffffull) << 32) | (g0 & 0xffffffffull)));
-        }
-        mine = wave_sum(mine);                                         // workgroups in order of their number: the same in every workgroup
-        if (lane == 0) s_tot[wv] = mine;
-        __syncthreads();
-        if (tid == 0) {
-            if (s_fail) {                                              // poison the search instead of hanging
-                S.best_min = S.best_max = __builtin_nan("");
-                S.done = 1;
-                __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                double tot = 0.0;
-                for (int k = 0; k < kResWaves; ++k) tot += s_tot[k];
-                const double mean = tot / count;
-                S.tell(f64 ? mean : static_cast<double>(static_cast<float>(mean)));
-                if (!S.done) {
-                    float sc, zp;
-                    double scd;
-                    loss_qparams(S.cand_min, S.cand_max, S.quant_min, S.quant_max, S.symmetric, &sc, &zp, &scd);
-                    s_scale = sc; s_zp = zp; s_scale_d = scd;
+            OSQ_RSTAMP(1);
+            // lane l takes workgroups l, l + 64, ...: one 16-byte sc1 load per partial (each half carries its own tag), all
+            // of a lane's loads in flight together; halves still stale are read again
+            constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
+            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
+            double got[kSlots];
+            unsigned int pending = 0u;
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) {
+                got[i] = 0.0;
+                if (static_cast<unsigned int>(lane + i * OSQ_WAVE) < gridDim.x) pending |= 1u << i;
+            }
+            unsigned int spins = 0u;
+            while (__any(pending != 0u)) {
+                if (++spins > kResSpinLimit) break;
+                v4u32_t w[kSlots];
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i)
+                    if (pending & (1u << i)) w[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, static_cast<unsigned int>(lane + i * OSQ_WAVE) * 16u, 0, 16);
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i) {
+                    if ((pending & (1u << i)) && w[i].y == tag && w[i].w == tag) {
+                        got[i] = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(w[i].z) << 32) | w[i].x));
+                        pending &= ~(1u << i);
+                    }
+                }
+                if (pending) __builtin_amdgcn_s_sleep(1);
+            }
+            const bool failed = __any(pending != 0u);
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) mine += got[i];           // the same order in every workgroup
+            const double tot = wave_sum(mine);
+            OSQ_RSTAMP(2);
+            if (lane == 0) {
+                if (failed) {                                          // poison the search instead of hanging
+                    S.best_min = S.best_max = __builtin_nan("");
+                    S.done = 1;
+                    s_done = 1u;
+                    __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const double mean = tot / count;
+                    S.tell(f64 ? mean : static_cast<double>(static_cast<float>(mean)));
+                    if (!S.done) {
+                        float sc, zp;
+                        double scd;
+                        loss_qparams(S.cand_min, S.cand_max, S.quant_min, S.quant_max, S.symmetric, &sc, &zp, &scd);
+                        s_scale = sc; s_zp = zp; s_scale_d = scd;
+                        s_rcp = 1.0 / scd;
+                        s_fast = rcp_division_exact(scd, S.x_min, S.x_max) ? 1u : 0u;
+                    }
+                    s_done = S.done ? 1u : 0u;
                 }
             }
+            OSQ_RSTAMP(4);
         }
         __syncthreads();
+        OSQ_RSTAMP(5);
         ++e;
     }
+#ifdef OSQ_FINAL_TIMING
+    if (blockIdx.x == 0 && tid == 0 && e > 0)
+        printf("resident K=%d kv=%d evals=%u: compute+reduce %.2f publish %.2f poll+sum %.2f (unused %.2f) tell %.2f barrier %.2f us per evaluation\n",
+               K, kv, e, tacc[0] / 100.0 / e, tacc[1] / 100.0 / e, tacc[2] / 100.0 / e, tacc[3] / 100.0 / e, tacc[4] / 100.0 / e, tacc[5] / 100.0 / e);
+#endif
+#undef OSQ_RSTAMP
     if (blockIdx.x == 0 && tid == 0) {
         a.ts->S = S;
         __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

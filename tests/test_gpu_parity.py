@@ -728,6 +728,58 @@ def test_msefast_equals_oracle(dev):
             np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=2e-3 if sym else 3e-2)
 
 
+def test_msefast_resident_search_equals_launch_per_evaluation(dev):
+    """The per-tensor search has two forms: one persistent launch with the valid part of the tensor in the grid's
+    registers (default when it fits), and one launch per loss evaluation.  Both run the same state machine on the same
+    squared errors, summed in a different order: in float32 arithmetic (first call of an observer) the mean is rounded
+    to fp32 once and the searches must agree exactly -- range and evaluation count; in float64 arithmetic (later calls)
+    the sum's order is in its last bits (see test_msefast_equals_oracle): same evaluation count or a range within the
+    oracle's own order-sensitivity.  Layouts: flat with a tail, dense masked, head-split view, strided key view (scalar
+    gathers), 3-D probabilities with the zip truncation, a tensor that does NOT fit (falls back by itself)."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+    gen = torch.Generator().manual_seed(31)
+    B, Tn = 8, 48
+    L = torch.randint(1, Tn + 1, (B,), generator=gen)
+    L[0] = Tn
+    L[3] = 0
+    base = torch.randn(B, Tn, 96, generator=gen)
+    base[..., 3] *= 9
+    cases = [
+        ("flat+tail", torch.randn(4099, generator=gen) * 2, None, -1),
+        ("dense masked", base, L, 1),
+        ("head split", base.view(B, Tn, 4, 24).permute(0, 2, 1, 3), L, 2),
+        ("key view", base.view(B, Tn, 4, 24).permute(0, 2, 3, 1), L, 3),
+        ("probs 3-D", torch.rand(4 * B, Tn, Tn, generator=gen), L, 1),
+        ("one-sided", base.abs(), L, 1),
+        ("too large for the registers", torch.randn(40, 512, 1024, generator=gen), torch.randint(1, 513, (40,), generator=gen), 1),
+    ]
+    for name, x, mask, seq_pos in cases:
+        for cls in (AvgMSEFastObserver, MSEFastObserver):
+            for sym in (False, True):
+                got = {}
+                for resident in (1, 0):
+                    ops.set_tuning("mse_resident", resident)
+                    try:
+                        ob = cls(bit=6, symmetric=sym).to(dev)
+                        rec = []
+                        for it in range(2 if x.numel() < (1 << 22) else 1):
+                            xi = (x * (1.0 + 0.5 * it)).to(dev)
+                            if mask is None:
+                                ob(xi)
+                            else:
+                                ob(xi, mask.to(dev), seq_pos)
+                            rec.append((float(N(ob.min_val)), float(N(ob.max_val)), int(ob.last_nfev.sum().item())))
+                        got[resident] = rec
+                    finally:
+                        ops.set_tuning("mse_resident", 1)
+                (a0, b0) = got[1][0], got[0][0]
+                assert a0 == b0, (name, cls.__name__, sym, a0, b0)                    # float32 arithmetic: exact
+                for a, b in zip(got[1][1:], got[0][1:]):                             # float64 arithmetic
+                    assert a[2] == b[2] or abs(a[2] - b[2]) <= 0.35 * b[2], (name, cls.__name__, sym, a, b)
+                    np.testing.assert_allclose(a[:2], b[:2], rtol=2e-3 if sym else 3e-2, atol=1e-9, err_msg=f"{name} {cls.__name__} {sym}")
+
+
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_against_reference(golden, name, dev):
     """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;

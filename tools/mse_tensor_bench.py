@@ -3,6 +3,8 @@ wall time per call and per loss evaluation, first call (float32 arithmetic) and 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from outlier_suppression_amd import _hip
+if os.environ.get("OSQ_DBG_LIB"): _hip.LIB_PATH = _hip.LIB_PATH.replace("libosq_hip.so", "libosq_hip_dbg.so")
 from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)

@@ -260,6 +260,29 @@ def kernel_table(dev, xs, lengths, reps=20):
                 rows[f"weight {tag}: MSEFast 4-bit symmetric per-channel (one bounded-Brent search per row)"] = {
                     "avg_us": round(us, 2), "bound": "compute (row in registers, ~15 loss evaluations per row)",
                     "algorithmic_MB": round(4 * w.numel() / 1e6, 1), "rows": shp[0]}
+        # per-tensor MSEFast (configs[3] activations): one asymmetric search = 300-600 loss evaluations; resident form (one
+        # persistent launch, tensor in registers) against one launch per evaluation, second call (float64 arithmetic)
+        from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
+        for tag, shp in (("32x128x768", (32, 128, 768)), ("32x128x3072", (32, 128, 3072))):
+            xm = torch.randn(*shp, device=dev)
+            xm[..., 5] *= 20
+            res = {}
+            for resident in (1, 0):
+                ops.set_tuning("mse_resident", resident)
+                try:
+                    ob = AvgMSEFastObserver(bit=6, symmetric=False).to(dev)
+                    ob(xm, l32, 1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ob(xm, l32, 1)
+                    torch.cuda.synchronize()
+                    res[resident] = ((time.perf_counter() - t0) * 1e6, int(ob.last_nfev.sum().item()))
+                finally:
+                    ops.set_tuning("mse_resident", 1)
+            rows[f"site {tag}: AvgMSEFast per-tensor 6-bit asymmetric search (masked)"] = {
+                "wall_us": round(res[1][0], 1), "loss_evaluations": res[1][1], "us_per_evaluation": round(res[1][0] / max(res[1][1], 1), 2),
+                "one_launch_per_evaluation_us_per_evaluation": round(res[0][0] / max(res[0][1], 1), 2),
+                "bound": "per evaluation: fp64 VALU work on the resident tensor + one exchange through memory (~2 us) + the serial Brent step (~1.5 us)"}
         # Infinity Cache: the same 96 MiB tensor over and over (x + y = 192 MiB < 256 MiB) against the buffer cycle above
         warm_y = ev_timed(lambda i: ops.fake_quant_per_tensor(xs[0], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
         add_ev("fake_quant_forward, warm (same input every launch; Infinity Cache)", warm_y, 8 * n)

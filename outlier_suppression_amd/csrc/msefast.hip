@@ -8,10 +8,11 @@
 // scipy in oracle/brent.py + tests/test_oracle_pinning.py) is a device-side state machine:
 //   * per-channel weights: ONE launch; one wave per row, the row lives in registers, the whole
 //     search (1-D, or nested 2-D for asymmetric two-sided rows) runs inside the wave;
-//   * per-tensor activations: the search state sits in device memory; each loss evaluation is
-//     one streaming launch (4 B/elem, padded tokens skipped) whose last workgroup feeds the
-//     loss to the state machine and publishes the next candidate.  Launches are enqueued in
-//     chunks; a finished search turns the remaining launches of a chunk into no-ops.
+//   * per-tensor activations: ONE persistent launch per search when the tensor fits the grid's
+//     registers (msefast_resident_kernel below); otherwise the search state sits in device
+//     memory and each loss evaluation is one streaming launch (4 B/elem, padded tokens skipped)
+//     whose last workgroup feeds the loss to the state machine and publishes the next candidate
+//     -- launches are enqueued in chunks, a finished search turns the rest of a chunk into no-ops.
 // Numerics follow the reference: candidates and qparams in float64 (scipy hands float64,
 // observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error in
 // fp32, summed in float64 from the first addition on, the mean rounded to fp32 once (the

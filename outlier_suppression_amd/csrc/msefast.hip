@@ -17,6 +17,7 @@
 // observer.py:423-428), scale applied as fp32, zero-point truncated to int, squared error in
 // fp32, summed in float64 from the first addition on, the mean rounded to fp32 once (the
 // reference's torch mean is an fp32 sum whose order depends on the machine's vector width).
+#include <stdlib.h>
 #include <string>
 #include "osq_device.h"
 #include "osq_host.h"
@@ -871,7 +872,9 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     return check_launch("msefast_tensor_evals_tokens");
 }
 
-static int g_mse_resident = 1;     // osq_set_tuning("mse_resident", 0): per-tensor searches always run one launch per evaluation (tests)
+// osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 in the environment (the switch for processes that SHARE a GPU:
+// persistent grids of two processes cannot be ordered against each other): per-tensor searches run one launch per evaluation
+static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
     return false;

@@ -269,8 +269,7 @@ def test_other_observers(golden, eq32):
         x = g[f"mse{k}_x"]
         for r_ in range(int(reps)):
             OB.observe_mse(st, x[r_] if int(reps) > 1 else x, average=cls.startswith("Avg"))
-            # grid points are compared by fp32 losses whose summation order differs: near-ties may pick the
-            # neighbouring grid point (1 % of the range)
-            np.testing.assert_allclose(st.min_val, g[f"mse{k}_min"][r_], rtol=0.03, atol=1e-6)
-            np.testing.assert_allclose(st.max_val, g[f"mse{k}_max"][r_], rtol=0.03, atol=1e-6)
+            # grid points are compared by fp32 losses whose summation order differs from torch's: a near-tie could pick the
+            # neighbouring grid point (1 % of the range) -- on every fixture the oracle lands on the reference's point
+            assert eq32(st.min_val, g[f"mse{k}_min"][r_]) and eq32(st.max_val, g[f"mse{k}_max"][r_]), (k, r_)
         assert st.one_side_dist == osd

@@ -169,3 +169,42 @@ def test_fused_step_many_launches_two_streams(dev):
     for k, s in enumerate(streams):
         with torch.cuda.stream(s):
             assert fused_status(dev) == 0
+
+
+def test_two_persistent_kernel_families_share_the_device(dev):
+    """The fused observe + fake-quant step and the resident MSEFast search are both persistent grids that want every CU:
+    launches of the two families alternate between two streams (the library orders them at every stream switch); every
+    search must return what it returns alone, every fused step what the three launches return, no time-out."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    B, T, H = 32, 128, 768
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, T, H, device=dev)
+    x[..., 11] *= 9
+    L = torch.randint(1, T + 1, (B,), generator=gen).to(dev)
+    alone = MSEFastObserver(bit=6, symmetric=False).to(dev)
+    alone(x, L, 1)
+    want = (alone.min_val.clone(), alone.max_val.clone(), int(alone.last_nfev.sum().item()))
+    q = make(dev, "LSQPlusFakeQuantize", "MinMaxObserver", False)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs, searches = [], []
+    for it in range(40):
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[0]), torch.no_grad():
+            y = q(x, L, 1)
+            if it % 10 == 0:
+                outs.append((y, q.scale.detach().clone(), q.zero_point.detach().clone()))
+        with torch.cuda.stream(streams[1]), torch.no_grad():
+            ob = MSEFastObserver(bit=6, symmetric=False).to(dev)
+            ob(x, L, 1)
+            searches.append(ob)
+    torch.cuda.synchronize()
+    for ob in searches:
+        assert torch.equal(ob.min_val, want[0]) and torch.equal(ob.max_val, want[1]) and int(ob.last_nfev.sum().item()) == want[2]
+    for y, s, z in outs:
+        assert torch.equal(y, ops.fake_quant_per_tensor(x, s, z, 0, 63, ops.PARAM_LSQPLUS, 1.0 / (x.numel() * 63) ** 0.5))
+    for s in streams:
+        with torch.cuda.stream(s):
+            assert fused_status(dev) == 0

@@ -388,6 +388,17 @@ int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token
  * osq_set_tuning("mse_resident", 0) -- the caller then runs the _evals_* loop. */
 int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
                               const int64_t* lengths, void* workspace, osq_stream stream);
+/* Several searches in ONE persistent launch (the observers of a forward are independent while fake-quant is off):
+ * osq_msefast_resident_slots(elems) = float4 slots per lane of the resident grid a search over `elems` elements takes
+ * (1..16; 0 = cannot be resident); a group fits when it has at most 16 searches whose slots add up to at most 16.
+ * Every round of the launch evaluates the pending candidate of every unfinished search; the exchange of the partial
+ * sums and the serial Brent steps of the searches overlap.  Arrays are HOST arrays of n_sites entries; views[i].batch
+ * == 0 marks a flat tensor of ns[i] elements.  Each search sits between its own _begin and _commit.
+ * OSQ_ERR_UNSUPPORTED: the group does not fit, nothing was launched. */
+int osq_msefast_resident_slots(int64_t elems);
+int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs, const int64_t* ns,
+                                    const osq_token_view* views, const int64_t* const* lengths, int n_sites,
+                                    void* workspace, osq_stream stream);
 int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
 int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt,
                               double* min_val, double* max_val,

@@ -87,6 +87,9 @@ SIGNATURES = {
     "osq_msefast_tensor_evals_flat": (_I, [_P, _P, _L, _I, _P, _P]),
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
     "osq_msefast_tensor_search": (_I, [_P, _P, _L, ctypes.POINTER(TokenView), _P, _P, _P]),
+    "osq_msefast_resident_slots": (_I, [_L]),
+    "osq_msefast_tensor_search_multi": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L), ctypes.POINTER(TokenView),
+                                             ctypes.POINTER(_P), _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
     "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -553,7 +553,7 @@ constexpr unsigned int kResSpinLimit = 1u << 22;
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
     unsigned int epoch, pad0[15];                        // tags handed out so far
     unsigned int status, pad1[15];                       // sticky: 1 = a workgroup timed out waiting for a partial
-    unsigned long long part[2][kResidentMaxBlocks][2];   // [evaluation parity][workgroup]{tag << 32 | low word, tag << 32 | high word}
+    unsigned long long part[2][kResidentMaxSites][kResidentMaxBlocks][2];   // [evaluation parity][site][workgroup]{tag << 32 | low word, tag << 32 | high word}
 };
 static_assert(sizeof(ResidentState) == kWsResidentBytes, "ResidentState must fill its slice of the workspace");
 
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
             for (int k = 0; k < kResWaves; ++k) p += s_part[k];
             if (lane == 0) {
                 const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
-                unsigned long long* slot = rs->part[e & 1u][blockIdx.x];
+                unsigned long long* slot = rs->part[e & 1u][0][blockIdx.x];
                 __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
             // lane l takes workgroups l, l + 64, ...: one 16-byte sc1 load per partial (each half carries its own tag), all
             // of a lane's loads in flight together; halves still stale are read again
             constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
-            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
+            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][0][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
             double got[kSlots];
             unsigned int pending = 0u;
 #pragma unroll
@@ -793,6 +793,291 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
     if (blockIdx.x == 0 && tid == 0) {
         a.ts->S = S;
         __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------- several resident searches in ONE launch
+//
+// One evaluation of a resident search is ~1.6 us of arithmetic inside ~5.9 us: the exchange of the partial sums and the
+// serial Brent step leave the VALUs idle.  The observers of one forward are independent (observer passes run with
+// fake-quant off), so up to 16 of them share a launch: a lane's float4 slots are dealt out to the sites (slot_site),
+// every round evaluates every unfinished site's loss, wave w of every workgroup publishes / collects the partials of
+// site w and advances site w's state machine -- the exchange and the Brent steps of all sites overlap.
+struct ResidentSite {
+    const float* x;
+    int64_t n;                    // flat tensor (v.batch == 0)
+    osq_token_view v;
+    const int64_t* lengths;
+    TensorSearch* ts;
+    int vec, slot0, slots, pad;   // this site's float4 slots per lane: slot0 .. slot0 + slots - 1
+};
+struct ResidentMultiArgs {
+    ResidentSite site[kResidentMaxSites];
+    int n_sites;
+    ResidentState* rs;
+};
+
+__device__ __forceinline__ unsigned int uniform(unsigned int v) {
+    return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    const unsigned long long u = (static_cast<unsigned long long>(uniform(static_cast<unsigned int>(b >> 32))) << 32) | uniform(static_cast<unsigned int>(b));
+    return __longlong_as_double(static_cast<long long>(u));
+}
+
+template <int KT>
+__global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(ResidentMultiArgs a) {
+    __shared__ unsigned int pre[1025];
+    __shared__ unsigned int s_wtot[kResWaves];
+    __shared__ double s_part[kResidentMaxSites][kResWaves];
+    __shared__ Search S[kResidentMaxSites];
+    __shared__ float s_scale[kResidentMaxSites], s_zp[kResidentMaxSites];
+    __shared__ double s_scale_d[kResidentMaxSites], s_rcp[kResidentMaxSites], s_count[kResidentMaxSites];
+    __shared__ unsigned int s_done[kResidentMaxSites], s_fast[kResidentMaxSites], s_kv[kResidentMaxSites], s_epoch, s_active;
+    __shared__ ResidentSite s_site[kResidentMaxSites];     // a by-value kernel argument indexed dynamically would be copied to scratch
+    __shared__ int s_slot_site[KT];                        // slot -> site (or -1)
+
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    const unsigned int NT = gridDim.x * kResThreads, gt = blockIdx.x * kResThreads + tid;
+    ResidentState* rs = a.rs;
+    const int ns = a.n_sites;
+    {
+        // the site table, word by word (static indices into the argument), and the slot map
+        constexpr int kWords = static_cast<int>(sizeof(ResidentSite) / 4);
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(&a.site[0]);
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&s_site[0]);
+        for (int i = tid; i < kResidentMaxSites * kWords; i += kResThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < KT) {
+        int site = -1;
+        for (int q = 0; q < ns; ++q) site = (tid >= s_site[q].slot0 && tid < s_site[q].slot0 + s_site[q].slots) ? q : site;
+        s_slot_site[tid] = site;
+    }
+    if (tid < ns) {
+        const TensorSearch* ts = s_site[tid].ts;
+        S[tid] = ts->S;
+        s_scale[tid] = ts->scale;
+        s_zp[tid] = ts->zp;
+        s_scale_d[tid] = ts->scale_d;
+        s_rcp[tid] = 1.0 / ts->scale_d;
+        s_fast[tid] = rcp_division_exact(ts->scale_d, ts->S.x_min, ts->S.x_max) ? 1u : 0u;
+        s_done[tid] = ts->S.done ? 1u : 0u;
+    }
+    if (tid == 0) s_epoch = __hip_atomic_load(&rs->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- load: site after site (the prefix sums of a masked site's lengths take their turn in `pre`)
+    float4 hold[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) hold[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int si = 0; si < ns; ++si) {
+        const ResidentSite st = s_site[si];
+        __syncthreads();                                               // `pre` of the previous site is no longer read
+        if (st.v.batch == 0) {
+            const int64_t n4 = st.n / 4;
+            const int tail = static_cast<int>(st.n - n4 * 4);
+            const float4* x4 = reinterpret_cast<const float4*>(st.x);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int kk = k - st.slot0;
+                if (kk < 0 || kk >= st.slots) continue;                // uniform
+                const int64_t g = static_cast<int64_t>(gt) + static_cast<int64_t>(kk) * NT;
+                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < n4) {
+                    h = x4[g];
+                } else if (g == n4 && tail) {
+                    const float* t = st.x + n4 * 4;
+                    h.x = t[0];
+                    if (tail > 1) h.y = t[1];
+                    if (tail > 2) h.z = t[2];
+                }
+                hold[k] = h;
+            }
+            if (tid == 0) { s_count[si] = static_cast<double>(st.n); s_kv[si] = static_cast<unsigned int>(((st.n + 3) / 4 + NT - 1) / NT); }
+            continue;
+        }
+        const osq_token_view v = st.v;
+        const unsigned int Bu = static_cast<unsigned int>(v.batch);
+        {
+            unsigned int len = 0u;
+            if (static_cast<unsigned int>(tid) < Bu) {
+                int64_t l = st.lengths ? st.lengths[tid] : v.tokens;
+                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
+                len = static_cast<unsigned int>(l);
+            }
+            const unsigned int incl = wave_inclusive_scan_u32(len);
+            if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl;
+            __syncthreads();
+            unsigned int base = 0u;
+#pragma unroll
+            for (int k = 0; k < kResWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
+            if (tid == 0) pre[0] = 0u;
+            if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
+            __syncthreads();
+        }
+        const unsigned int V = pre[Bu];
+        const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
+        const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
+        if (tid == 0) {
+            s_count[si] = static_cast<double>(V) * static_cast<double>(F);
+            const uint64_t groups = (static_cast<uint64_t>(V) * F + 3u) / 4u;
+            s_kv[si] = static_cast<unsigned int>((groups + NT - 1) / NT);
+        }
+        auto token_base = [&](unsigned int j) -> const float* {
+            unsigned int lo = 0u, hi = Bu;
+            while (lo + 1u < hi) {
+                const unsigned int mid = (lo + hi) >> 1;
+                if (pre[mid] <= j) lo = mid; else hi = mid;
+            }
+            return st.x + static_cast<int64_t>(lo) * v.stride_batch + static_cast<int64_t>(j - pre[lo]) * v.stride_token;
+        };
+        const unsigned int inner4 = fi / 4u, F4 = F / 4u;
+        const uint64_t G = static_cast<uint64_t>(V) * F4, E = static_cast<uint64_t>(V) * F;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int kk = k - st.slot0;
+            if (kk < 0 || kk >= st.slots) continue;                    // uniform
+            const uint64_t g = static_cast<uint64_t>(gt) + static_cast<uint64_t>(kk) * NT;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st.vec) {
+                if (g < G) {
+                    const unsigned int j = static_cast<unsigned int>(g / F4), i = static_cast<unsigned int>(g - static_cast<uint64_t>(j) * F4);
+                    const unsigned int o = i / inner4, ii = i - o * inner4;
+                    h = reinterpret_cast<const float4*>(token_base(j) + static_cast<int64_t>(o) * v.stride_outer)[ii];
+                }
+            } else {
+                float e4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint64_t q = g * 4u + c;
+                    if (q < E) {
+                        const unsigned int j = static_cast<unsigned int>(q / F), f = static_cast<unsigned int>(q - static_cast<uint64_t>(j) * F);
+                        const unsigned int o = f / fi, i = f - o * fi;
+                        e4[c] = token_base(j)[static_cast<int64_t>(o) * v.stride_outer + static_cast<int64_t>(i) * v.stride_inner];
+                    }
+                }
+                h = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            }
+            hold[k] = h;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int act = 0u;
+        for (int si = 0; si < ns; ++si) act += s_done[si] ? 0u : 1u;
+        s_active = act;
+    }
+    __syncthreads();
+    const unsigned int base_tag = s_epoch + 1u;
+    unsigned int e = 0u;
+    // ---- one trip per round: one loss evaluation of every unfinished site
+    while (s_active != 0u) {
+        int si = -1;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            // slots of a site are contiguous: a change of site closes the previous site's sum (uniform control flow)
+            const int site_k = s_slot_site[k];
+            if (site_k != si) {
+                if (si >= 0 && !s_done[si]) {
+                    acc = wave_sum(acc);
+                    if (lane == 0) s_part[si][wv] = acc;
+                }
+                si = site_k;
+                acc = 0.0;
+            }
+            if (si < 0 || s_done[si] || static_cast<unsigned int>(k - s_site[si].slot0) >= s_kv[si]) continue;
+            // the site's parameters go to SGPRs: as vector registers, hoisted above the arithmetic, the parameters of all
+            // slots would be alive together (11 VGPRs per slot, spilled)
+            const float qmin = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S[si].quant_min))));
+            const float qmax = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S[si].quant_max))));
+            const float zp = __uint_as_float(uniform(__float_as_uint(s_zp[si])));
+            if (!uniform(static_cast<unsigned int>(S[si].f64))) {
+                acc += sq_err4(hold[k], __uint_as_float(uniform(__float_as_uint(s_scale[si]))), zp, qmin, qmax);
+            } else {
+                const double sd = uniform_f64(s_scale_d[si]);
+                if (uniform(s_fast[si])) acc += sq_err4_f64_rcp(hold[k], sd, uniform_f64(s_rcp[si]), zp, qmin, qmax);
+                else acc += sq_err4_f64(hold[k], sd, zp, qmin, qmax);
+            }
+            __builtin_amdgcn_sched_barrier(0);                         // one slot's temporaries at a time
+        }
+        if (si >= 0 && !s_done[si]) {
+            acc = wave_sum(acc);
+            if (lane == 0) s_part[si][wv] = acc;
+        }
+        __syncthreads();
+        if (wv < ns && !s_done[wv]) {
+            // ---- wave w: site w's partial out, everybody's in, site w's state machine one step on
+            const int w = wv;
+            const unsigned int tag = base_tag + e;
+            double p = 0.0;
+#pragma unroll
+            for (int k = 0; k < kResWaves; ++k) p += s_part[w][k];
+            if (lane == 0) {
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
+                unsigned long long* slot = rs->part[e & 1u][w][blockIdx.x];
+                __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
+            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][w][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
+            double got[kSlots];
+            unsigned int pending = 0u;
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) {
+                got[i] = 0.0;
+                if (static_cast<unsigned int>(lane + i * OSQ_WAVE) < gridDim.x) pending |= 1u << i;
+            }
+            unsigned int spins = 0u;
+            while (__any(pending != 0u)) {
+                if (++spins > kResSpinLimit) break;
+                v4u32_t wd[kSlots];
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i)
+                    if (pending & (1u << i)) wd[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, static_cast<unsigned int>(lane + i * OSQ_WAVE) * 16u, 0, 16);
+#pragma unroll
+                for (int i = 0; i < kSlots; ++i) {
+                    if ((pending & (1u << i)) && wd[i].y == tag && wd[i].w == tag) {
+                        got[i] = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(wd[i].z) << 32) | wd[i].x));
+                        pending &= ~(1u << i);
+                    }
+                }
+                if (pending) __builtin_amdgcn_s_sleep(1);
+            }
+            const bool failed = __any(pending != 0u);
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) mine += got[i];
+            const double tot = wave_sum(mine);
+            if (lane == 0) {
+                if (failed) {
+                    S[w].best_min = S[w].best_max = __builtin_nan("");
+                    S[w].done = 1;
+                    __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const double mean = tot / s_count[w];
+                    S[w].tell(S[w].f64 ? mean : static_cast<double>(static_cast<float>(mean)));
+                    if (!S[w].done) {
+                        float sc, zp;
+                        double scd;
+                        loss_qparams(S[w].cand_min, S[w].cand_max, S[w].quant_min, S[w].quant_max, S[w].symmetric, &sc, &zp, &scd);
+                        s_scale[w] = sc; s_zp[w] = zp; s_scale_d[w] = scd;
+                        s_rcp[w] = 1.0 / scd;
+                        s_fast[w] = rcp_division_exact(scd, S[w].x_min, S[w].x_max) ? 1u : 0u;
+                    }
+                }
+                if (S[w].done) {
+                    s_done[w] = 1u;
+                    atomicSub(&s_active, 1u);
+                }
+            }
+        }
+        __syncthreads();
+        ++e;
+    }
+    if (blockIdx.x == 0) {
+        if (tid < ns) s_site[tid].ts->S = S[tid];
+        if (tid == 0) __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -924,6 +1209,75 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
     else OSQ_RESIDENT(16);
 #undef OSQ_RESIDENT
     return check_launch("msefast_tensor_search");
+}
+
+/* Float4 slots per lane of the resident grid that a per-tensor search over `elems` elements occupies (1..16), or 0 when
+ * it cannot be resident (too large, no persistent grid on this device, osq_set_tuning("mse_resident", 0)).  A group of
+ * searches fits one osq_msefast_tensor_search_multi launch when there are at most 16 of them and their slots add up to
+ * at most 16. */
+extern "C" int osq_msefast_resident_slots(int64_t elems) {
+    if (!g_mse_resident || elems <= 0) return 0;
+    static int grid = -1;
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<16>), kResThreads);
+    if (grid < 1 || grid > kResidentMaxBlocks || grid > kResThreads) return 0;
+    const int64_t per_k = static_cast<int64_t>(grid) * kResThreads * 4;
+    const int64_t need = (elems + per_k - 1) / per_k;
+    return need > 16 ? 0 : static_cast<int>(need);
+}
+
+/* Up to 16 per-tensor searches (each between its own osq_msefast_tensor_begin and _commit) in ONE persistent launch:
+ * every round evaluates the pending candidate of every unfinished search.  states[i] / xs[i] / ns[i] / views[i] /
+ * lengths[i] as in osq_msefast_tensor_search (views[i].batch == 0: flat, ns[i] elements).  The caller groups with
+ * osq_msefast_resident_slots; a group that does not fit returns OSQ_ERR_UNSUPPORTED and launches nothing. */
+extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs, const int64_t* ns,
+                                               const osq_token_view* views, const int64_t* const* lengths, int n_sites,
+                                               void* workspace, osq_stream stream) {
+    OSQ_REQUIRE(states && xs && ns && views && lengths && workspace && n_sites > 0, "msefast_tensor_search_multi: bad argument");
+    if (!g_mse_resident || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
+    ResidentMultiArgs a{};
+    a.n_sites = n_sites;
+    a.rs = static_cast<ResidentState*>(Workspace(workspace).resident());
+    int slot = 0;
+    for (int i = 0; i < n_sites; ++i) {
+        ResidentSite& s = a.site[i];
+        OSQ_REQUIRE(states[i] && xs[i], "msefast_tensor_search_multi: null site");
+        s.x = xs[i];
+        s.ts = static_cast<TensorSearch*>(states[i]);
+        int64_t elems;
+        if (views[i].batch > 0) {
+            const osq_token_view v = views[i];
+            OSQ_REQUIRE(v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_search_multi: empty view");
+            if (v.batch > 1024) return OSQ_ERR_UNSUPPORTED;
+            elems = v.batch * v.tokens * v.feat_outer * v.feat_inner;
+            s.v = v;
+            s.lengths = lengths[i];
+            s.vec = v.stride_inner == 1 && v.feat_inner % 4 == 0 && aligned16(s.x) && v.stride_batch % 4 == 0 &&
+                    v.stride_token % 4 == 0 && (v.feat_outer == 1 || v.stride_outer % 4 == 0);
+        } else {
+            OSQ_REQUIRE(ns[i] > 0, "msefast_tensor_search_multi: empty tensor");
+            if (!aligned16(s.x)) return OSQ_ERR_UNSUPPORTED;
+            elems = ns[i];
+            s.n = ns[i];
+        }
+        const int k = osq_msefast_resident_slots(elems);
+        if (k == 0) return OSQ_ERR_UNSUPPORTED;
+        s.slot0 = slot;
+        s.slots = k;
+        slot += k;
+    }
+    if (slot > 16) return OSQ_ERR_UNSUPPORTED;
+    static int grid = -1;
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<16>), kResThreads);
+    if (grid < 1) return OSQ_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!persistent_serialize(st)) return OSQ_ERR_UNSUPPORTED;
+#define OSQ_RESIDENT_MULTI(KK) hipLaunchKernelGGL(msefast_resident_multi_kernel<KK>, dim3(grid), dim3(kResThreads), 0, st, a)
+    if (slot <= 4) OSQ_RESIDENT_MULTI(4);
+    else if (slot <= 8) OSQ_RESIDENT_MULTI(8);
+    else if (slot <= 12) OSQ_RESIDENT_MULTI(12);
+    else OSQ_RESIDENT_MULTI(16);
+#undef OSQ_RESIDENT_MULTI
+    return check_launch("msefast_tensor_search_multi");
 }
 
 extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream) {

@@ -526,18 +526,20 @@ def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
     return bmin, bmax, nfev
 
 
-def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
-                   rule, cnt, min_val, max_val, sink=None, chunk=None, float64_input=False):
-    """Per-tensor search (observer.py:497-499): loss launches are enqueued in chunks and the converged
-    flag is read back once per chunk (the reference syncs on every evaluation).  min_val/max_val: float64."""
+class MseSearch:
+    """One per-tensor MSEFast search between its begin and its commit (state on the device, what the launches need)."""
+    __slots__ = ("state", "x", "view", "lengths", "args", "elems")
+
+
+def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
+                         float64_input=False):
     lib = _hip.load()
     dev = x.device
-    st = _hip.stream_ptr(dev)
-    state = torch.zeros(int(lib.osq_msefast_state_bytes()), dtype=torch.uint8, device=dev)
-    ws = _hip.workspace(dev)
-    _hip.check(lib.osq_msefast_tensor_begin(_hip.ptr(state), _hip.ptr(cur), int(quant_min), int(quant_max),
-                                            int(bool(symmetric)), SIDE[one_side], int(bool(two_d)), int(bool(float64_input)), st),
-               "msefast_begin")
+    r = MseSearch()
+    r.state = torch.zeros(int(lib.osq_msefast_state_bytes()), dtype=torch.uint8, device=dev)
+    _hip.check(lib.osq_msefast_tensor_begin(_hip.ptr(r.state), _hip.ptr(cur), int(quant_min), int(quant_max),
+                                            int(bool(symmetric)), SIDE[one_side], int(bool(two_d)), int(bool(float64_input)),
+                                            _hip.stream_ptr(dev)), "msefast_begin")
     if observation_mask is not None or not is_dense(x):
         lengths = observation_mask
         if lengths is not None and lengths.dtype != torch.int64:
@@ -549,32 +551,82 @@ def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symm
             view = token_view(x, seq_pos, lengths.numel())
     else:
         view, lengths = None, None
-    # the whole search in one persistent launch when the tensor fits the grid's registers ...
-    rc = lib.osq_msefast_tensor_search(_hip.ptr(state), _hip.ptr(x), x.numel(), None if view is None else ctypes.byref(view),
-                                       _hip.ptr(lengths), _hip.ptr(ws), st)
+    r.x, r.view, r.lengths, r.elems = x, view, lengths, x.numel()
+    r.args = (int(quant_min), int(quant_max), int(bool(symmetric)))
+    return r
+
+
+def msefast_tensor_run(r, chunk=None, two_d=True):
+    """The loss evaluations of one search: one persistent launch when the tensor fits the grid's registers, otherwise one
+    launch per evaluation, enqueued in chunks (the converged flag is read back once per chunk; the reference syncs on
+    every evaluation)."""
+    lib = _hip.load()
+    dev = r.x.device
+    st = _hip.stream_ptr(dev)
+    ws = _hip.workspace(dev)
+    rc = lib.osq_msefast_tensor_search(_hip.ptr(r.state), _hip.ptr(r.x), r.x.numel(), None if r.view is None else ctypes.byref(r.view),
+                                       _hip.ptr(r.lengths), _hip.ptr(ws), st)
     if rc not in (0, _hip.ERR_UNSUPPORTED):
         _hip.check(rc, "msefast_tensor_search")
-    # ... otherwise one launch per loss evaluation, enqueued in chunks
     done = torch.zeros(1, dtype=torch.int32, device=dev)
     chunk = chunk or (64 if two_d else 32)
     launched = 0
     while rc != 0:
-        if view is None:
-            _hip.check(lib.osq_msefast_tensor_evals_flat(_hip.ptr(state), _hip.ptr(x), x.numel(), chunk, _hip.ptr(ws), st),
+        if r.view is None:
+            _hip.check(lib.osq_msefast_tensor_evals_flat(_hip.ptr(r.state), _hip.ptr(r.x), r.x.numel(), chunk, _hip.ptr(ws), st),
                        "msefast_evals_flat")
         else:
-            _hip.check(lib.osq_msefast_tensor_evals_tokens(_hip.ptr(state), _hip.ptr(x), ctypes.byref(view),
-                                                           _hip.ptr(lengths), chunk, _hip.ptr(ws), st), "msefast_evals_tokens")
+            _hip.check(lib.osq_msefast_tensor_evals_tokens(_hip.ptr(r.state), _hip.ptr(r.x), ctypes.byref(r.view),
+                                                           _hip.ptr(r.lengths), chunk, _hip.ptr(ws), st), "msefast_evals_tokens")
         launched += chunk
-        _hip.check(lib.osq_msefast_tensor_done(_hip.ptr(state), _hip.ptr(done), st), "msefast_done")
+        _hip.check(lib.osq_msefast_tensor_done(_hip.ptr(r.state), _hip.ptr(done), st), "msefast_done")
         if int(done.item()) or launched > 500 * 500:
             break
+
+
+def msefast_tensor_run_group(group):
+    """Several searches (MseSearch records of one device) in ONE persistent launch; False = the group does not fit (nothing
+    launched).  The caller sizes groups with msefast_resident_slots."""
+    lib = _hip.load()
+    n = len(group)
+    dev = group[0].x.device
+    states = (ctypes.c_void_p * n)(*[_hip.ptr(r.state) for r in group])
+    xs = (ctypes.c_void_p * n)(*[_hip.ptr(r.x) for r in group])
+    ns = (ctypes.c_int64 * n)(*[r.x.numel() for r in group])
+    views = (_hip.TokenView * n)()
+    for i, r in enumerate(group):
+        if r.view is not None:
+            views[i] = r.view
+    lens = (ctypes.c_void_p * n)(*[_hip.ptr(r.lengths) for r in group])
+    rc = lib.osq_msefast_tensor_search_multi(states, xs, ns, views, lens, n, _hip.ptr(_hip.workspace(dev)), _hip.stream_ptr(dev))
+    if rc == _hip.ERR_UNSUPPORTED:
+        return False
+    _hip.check(rc, "msefast_tensor_search_multi")
+    return True
+
+
+def msefast_resident_slots(elems):
+    return int(_hip.load().osq_msefast_resident_slots(int(elems)))
+
+
+def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None):
+    lib = _hip.load()
+    dev = r.x.device
+    quant_min, quant_max, symmetric = r.args
     s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
     nfev = torch.empty(1, dtype=torch.int32, device=dev)
-    _hip.check(lib.osq_msefast_tensor_commit(_hip.ptr(state), rule, int(cnt), _hip.ptr(min_val), _hip.ptr(max_val),
-                                             int(quant_min), int(quant_max), int(bool(symmetric)), s_ptr, z_ptr, z_type,
-                                             _hip.ptr(nfev), st), "msefast_commit")
+    _hip.check(lib.osq_msefast_tensor_commit(_hip.ptr(r.state), rule, int(cnt), _hip.ptr(min_val), _hip.ptr(max_val),
+                                             quant_min, quant_max, symmetric, s_ptr, z_ptr, z_type,
+                                             _hip.ptr(nfev), _hip.stream_ptr(dev)), "msefast_commit")
     return nfev
+
+
+def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
+                   rule, cnt, min_val, max_val, sink=None, chunk=None, float64_input=False):
+    """Per-tensor search (observer.py:497-499), begin -> loss evaluations -> commit.  min_val/max_val: float64."""
+    r = msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d, float64_input)
+    msefast_tensor_run(r, chunk, two_d)
+    return msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink)
 
 
 # ---------------------------------------------------------------------------------------

@@ -29,8 +29,43 @@ from . import observer as _observer
 class DeferredSites:
     def __init__(self):
         self.sites = []
+        self.mse = []
         self.launches = 0
         self.flushed_sites = 0
+
+    def add_mse(self, obs, search, two_d, sink):
+        """A per-tensor MSEFast search that has begun (ops.msefast_tensor_begin): its loss evaluations run at the flush,
+        together with the other searches of the forward (up to 16 per persistent launch); its batch counter is the one
+        of the call."""
+        self.mse.append((obs, search, two_d, sink, obs._counter(), obs.update_rule))
+
+    def _flush_mse(self):
+        pending, self.mse = self.mse, []
+        if not pending:
+            return 0
+        # greedy groups: at most 16 searches and 16 float4 slots per lane in a launch; what cannot be resident runs alone
+        groups, cur, used = [], [], 0
+        for item in pending:
+            k = ops.msefast_resident_slots(item[1].elems)
+            if k == 0:
+                groups.append([item])
+                continue
+            if cur and (used + k > 16 or len(cur) == 16):
+                groups.append(cur)
+                cur, used = [], 0
+            cur.append(item)
+            used += k
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            if len(g) == 1 or not ops.msefast_tensor_run_group([it[1] for it in g]):
+                for it in g:
+                    ops.msefast_tensor_run(it[1], None, it[2])
+            self.launches += 1
+        for obs, search, two_d, sink, cnt, rule in pending:
+            obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink)
+        self.flushed_sites += len(pending)
+        return len(pending)
 
     def add(self, obs, x, lengths, seq_pos, prune, sink):
         if sink is None or sink.scale is None or not x.is_cuda or x.dtype != torch.float32 or x.dim() not in (3, 4):
@@ -48,9 +83,10 @@ class DeferredSites:
         return True
 
     def flush(self):
+        n_mse = self._flush_mse()
         sites, self.sites = self.sites, []
         if not sites:
-            return 0
+            return n_mse
         lib = _hip.load()
         dev = sites[0][1].device
         st = _hip.raw_stream(dev)
@@ -142,3 +178,4 @@ def deferred_observation():
     finally:
         _observer.DEFERRED = previous
         sites.sites = []
+        sites.mse = []

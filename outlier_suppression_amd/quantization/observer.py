@@ -241,10 +241,17 @@ class MSEFastObserver(ObserverBase):
             if self.min_val.dtype != torch.float64 or self.min_val.device != x.device:
                 self.min_val = self.min_val.to(device=x.device, dtype=torch.float64)
                 self.max_val = self.max_val.to(device=x.device, dtype=torch.float64)
-            self.last_nfev = ops.msefast_tensor(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
-                                                self.symmetric, self.one_side_dist, two_d, self.update_rule,
-                                                self._counter(), self.min_val, self.max_val, sink,
-                                                float64_input=float64_input)
+            if DEFERRED is not None and self.__dict__.get("_defer_ok", False) and x.is_cuda:
+                # an observer pass (fake-quant off): the search joins the other searches of this forward in one launch
+                # (quantization/deferred.py); min_val / max_val / scale move at the flush
+                DEFERRED.add_mse(self, ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
+                                                                self.symmetric, self.one_side_dist, two_d, float64_input),
+                                 two_d, sink)
+            else:
+                self.last_nfev = ops.msefast_tensor(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
+                                                    self.symmetric, self.one_side_dist, two_d, self.update_rule,
+                                                    self._counter(), self.min_val, self.max_val, sink,
+                                                    float64_input=float64_input)
         else:
             bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
                                                           self.symmetric, self.one_side_dist, two_d)

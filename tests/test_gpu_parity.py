@@ -816,6 +816,59 @@ def test_msefast_resident_search_equals_launch_per_evaluation(dev):
                     np.testing.assert_allclose(a[:2], b[:2], rtol=2e-3 if sym else 3e-2, atol=1e-9, err_msg=f"{name} {cls.__name__} {sym}")
 
 
+def test_msefast_searches_of_a_forward_share_a_launch(dev):
+    """Inside deferred_observation() the per-tensor MSEFast searches of a forward are recorded and run together, up to 16
+    per persistent launch (every round evaluates every unfinished search).  Each search does the arithmetic it does
+    alone -- same threads, same elements, same order of every sum: ranges, running statistics, scales and evaluation
+    counts are bit-equal to the immediate path, in float32 arithmetic (first batch) and in float64 (later batches).
+    23 sites of mixed layouts and sizes (several launches; one site too large to be resident), 3 batches."""
+    from outlier_suppression_amd.quantization import Quantizer
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    gen = torch.Generator().manual_seed(77)
+    B, Tn = 8, 40
+    L = torch.randint(1, Tn + 1, (B,), generator=gen)
+    L[0] = Tn
+    base = torch.randn(B, Tn, 96, generator=gen)
+    base[..., 3] *= 9
+    def site_inputs(scale):
+        x = base * scale
+        return [(x, L, 1), (x.view(B, Tn, 4, 24).permute(0, 2, 1, 3), L, 2), (x.view(B, Tn, 4, 24).permute(0, 2, 3, 1), L, 3),
+                (torch.rand(2 * B, Tn, Tn, generator=gen) * scale, L, 1), (x.abs(), L, 1), (torch.randn(4099, generator=gen) * scale, None, -1)]
+    cfgs = [NS(quantizer="FixedFakeQuantize", observer=o, bit=6, symmetric=s, ch_axis=-1)
+            for o in ("AvgMSEFastObserver", "MSEFastObserver") for s in (False, True)]
+    results = {}
+    for deferred in (False, True):
+        gen.manual_seed(123)           # both passes draw the same tensors
+        qs = []
+        big = torch.randn(40, 512, 1024, generator=torch.Generator().manual_seed(5))       # 84 MB: not resident
+        big_L = torch.randint(1, 513, (40,), generator=torch.Generator().manual_seed(6))
+        for it in range(3):
+            inputs = site_inputs(1.0 + 0.4 * it)
+            calls = [(inputs[k % len(inputs)], cfgs[k % len(cfgs)]) for k in range(22)]
+            if it == 0:
+                qs = [Quantizer(None, c).to(dev) for _, c in calls] + [Quantizer(None, cfgs[0]).to(dev)]
+                for q in qs:
+                    q.enable_observer()
+                    q.disable_fake_quant()
+            def forward():
+                for q, ((x, mask, sp), _) in zip(qs, calls):
+                    q(x.to(dev), None if mask is None else mask.to(dev), sp)
+                if it == 0:
+                    qs[-1](big.to(dev), big_L.to(dev), 1)
+            if deferred:
+                with deferred_observation() as sites:
+                    forward()
+                    sites.flush()
+                assert sites.flushed_sites == (23 if it == 0 else 22) and sites.launches < 10
+            else:
+                forward()
+        torch.cuda.synchronize()
+        results[deferred] = [(q.observer.min_val.clone(), q.observer.max_val.clone(), q.scale.detach().clone(), q.zero_point.detach().clone(),
+                              int(q.observer.last_nfev.sum().item())) for q in qs]
+    for k, (a, b) in enumerate(zip(results[False], results[True])):
+        assert all(torch.equal(u, v) for u, v in zip(a[:4], b[:4])) and a[4] == b[4], (k, a, b)
+
+
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_against_reference(golden, name, dev):
     """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;

@@ -492,17 +492,20 @@ def calibration_extra(dev, rank, world, which):
         rows = sum(m.weight.shape[0] for m in model.modules() if hasattr(m, "weight_fake_quant"))
         evals = sum(int(m.weight_fake_quant.observer.last_nfev.sum().item()) for m in model.modules() if hasattr(m, "weight_fake_quant"))
         enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
-        with torch.no_grad():
+        from outlier_suppression_amd.quantization.deferred import deferred_observation
+        with torch.no_grad(), deferred_observation() as sites:      # the searches of a forward share persistent launches
             for b in batches:
                 model(**b)
+                sites.flush()
         sync(); phases["activation_calibration_msefast_per_tensor"] = time.perf_counter() - t0
+        search_launches = sites.launches
         from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
         act_evals = sum(int(m.observer.last_nfev.sum().item()) for n, m in model.named_modules()
                         if isinstance(m, QuantizeBase) and "act" in n and m.observer.last_nfev is not None)
         return {"config": "configs[3]: RoBERTa-base MNLI W4A6, per-channel weights + MSEFast, 256 samples (8 x [32,128])",
                 "wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
                 "weight_rows_searched": rows, "weight_loss_evaluations": evals, "activation_loss_evaluations_last_batch": act_evals,
-                "n_gpus": world, "sharding": "replicas only (float64 per-observer search state)" if world > 1 else "one process"}
+                "activation_search_launches": search_launches, "n_gpus": world, "sharding": "replicas only (float64 per-observer search state)" if world > 1 else "one process"}
 
     TWC.task_type, TWC.model_type = task, mtype
     n_batches = len(batches)

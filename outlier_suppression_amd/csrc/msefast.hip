@@ -820,6 +820,11 @@ struct ResidentMultiArgs {
 __device__ __forceinline__ unsigned int uniform(unsigned int v) {
     return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
 }
+// the true-division form of the float64 chain, out of line: it runs only for a scale whose significand is all ones (or
+// non-finite extrema), and inlined sixteen times it costs the multi-site loop its registers
+__device__ __attribute__((noinline)) double sq_err4_f64_outofline(float4 a, double s, double z, double qmin, double qmax) {
+    return sq_err4_f64(a, s, z, qmin, qmax);
+}
 __device__ __forceinline__ double uniform_f64(double v) {
     const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
     const unsigned long long u = (static_cast<unsigned long long>(uniform(static_cast<unsigned int>(b >> 32))) << 32) | uniform(static_cast<unsigned int>(b));
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
             } else {
                 const double sd = uniform_f64(s_scale_d[si]);
                 if (uniform(s_fast[si])) acc += sq_err4_f64_rcp(hold[k], sd, uniform_f64(s_rcp[si]), zp, qmin, qmax);
-                else acc += sq_err4_f64(hold[k], sd, zp, qmin, qmax);
+                else acc += sq_err4_f64_outofline(hold[k], sd, zp, qmin, qmax);
             }
             __builtin_amdgcn_sched_barrier(0);                         // one slot's temporaries at a time
         }

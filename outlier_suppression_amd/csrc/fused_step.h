@@ -64,6 +64,8 @@ struct FusedArgs {
     int zp_type, mode;
     float g, qmin, qmax;
     int gate;                     // 1: padded tokens are loaded only after every workgroup has arrived
+    int deal;                     // how a slot's tokens are dealt to the waves (see the kernel): 0 = 16 consecutive tokens per workgroup,
+                                  // 2 = round the workgroups token by token, 1 = only the slot with the last valid tokens
 };
 
 __device__ __forceinline__ unsigned long long peek64(const unsigned long long* p) {
@@ -224,7 +226,29 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         old_s = a.scale_p[0];
         old_z = load_zp(a.zp_p, a.zp_type);
     }
-    const unsigned int gw = (blockIdx.x - 2u) * kFusedWaves + static_cast<unsigned int>(wv);
+    const unsigned int bp = blockIdx.x - 2u;                                         // this workgroup's number among the streaming ones
+    const unsigned int gw = bp * kFusedWaves + static_cast<unsigned int>(wv);
+    // How the W tokens of a slot are dealt to the waves (a.deal, osq_set_tuning("fused_deal")).
+    //   0: workgroup bp takes 16 consecutive tokens.  The same wave of neighbouring workgroups -- they issue their loads and
+    //      stores at about the same time -- is then 16 rows apart, a multiple of 16 KiB at every feature count the kernel
+    //      takes: simultaneous requests crowd a few memory channels.  And V is rarely a multiple of W: the slot that holds
+    //      the last valid tokens gives the first (V % W) / 16 workgroups one valid token per wave more than the others
+    //      (5 against 4 at the bench lengths), and the selection waits for those.
+    //   2 (default): wave w of workgroup bp takes token w * G + bp (G streaming workgroups): simultaneous requests are one
+    //      row apart, every workgroup has the same share of a slot's valid tokens.  Measured on one box, graph replay of
+    //      the bench step: 44.3 -> 41.5 us ([256,128,768], bench lengths), 55.0 -> 52.8 (all valid), 35.4 -> 33.0
+    //      ([32,128,3072]), 21.7 -> 20.0 ([64,128,1024]), 43.6 -> 41.1 ([32,128,4096]).  Two, four tokens per workgroup or
+    //      the workgroups of one XCD on consecutive tokens measure the same as one; numbering the workgroups in the order
+    //      they start (a ticket: XCDs receive a launch up to 2 us apart) costs the ticket's round trip: +1.5 us.
+    //   1: only the slot that holds the last valid tokens is dealt like 2 (the balance without the channel spreading: -0.3 us).
+    const unsigned int nwg = gridDim.x - 2u;
+    const unsigned int gwi = static_cast<unsigned int>(wv) * nwg + bp;
+    const unsigned int kdeal = a.deal >= 2 ? 0xffffffffu : (a.deal == 1 ? V / nwv : 0xfffffffeu);   // slot(s) dealt token by token
+    // 16 KiB rows (4096 features): workgroup bp starts a token at piece bp % 16, otherwise the workgroups' simultaneous
+    // requests are again whole multiples of 16 KiB apart (-1 us of 41 on [32,128,4096]; no effect at 768 / 1024 / 3072)
+    const unsigned int prot = NV == 16 ? bp % 16u : 0u;
+#define OSQ_FUSED_PIECE(u) ((((static_cast<unsigned int>(u) + prot) >= static_cast<unsigned int>(NV)) ? static_cast<unsigned int>(u) + prot - NV : static_cast<unsigned int>(u) + prot) * 1024u)
+#define OSQ_FUSED_TOKEN(k) (static_cast<unsigned int>(k) * nwv + ((kdeal == 0xffffffffu || kdeal == static_cast<unsigned int>(k)) ? gwi : gw))
     // Rows are addressed as buffer base (SGPR descriptor) + wave-uniform row offset (SGPR) + lane * 16 (one VGPR for
     // every access): no 64-bit address pair per token in flight -- the lanes' registers are for data.
     const unsigned int tensor_bytes = total * static_cast<unsigned int>(H4 * 16);      // < 4 GiB, checked by the launcher
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     // (All sixteen waves counting with ballots, 64 entries at a time, took 3 us: the CU's issue slots, not latency.)
     if (tid < kFusedWaves * S) {
         const unsigned int k = static_cast<unsigned int>(tid) / kFusedWaves, w = static_cast<unsigned int>(tid) % kFusedWaves;
-        const unsigned int j = (blockIdx.x - 2u) * kFusedWaves + w + k * nwv;
+        const unsigned int j = k * nwv + ((kdeal == 0xffffffffu || kdeal == k) ? w * nwg + bp : bp * kFusedWaves + w);
         unsigned int r = 0u;
         if (j < total) {
             const bool valid = j < V;
@@ -270,18 +294,18 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         v4u32 tmp[SL > 0 ? SL : 1][NV];
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            const unsigned int j = OSQ_FUSED_TOKEN(k);
             if (j < V) {
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
-                    const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+                    const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + OSQ_FUSED_PIECE(u), kNt);
                     if (k < SR) hold[k][u] = w; else tmp[k - SR][u] = w;
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            const unsigned int j = OSQ_FUSED_TOKEN(k);
             if (j < V) {
                 MinMax acc;
                 acc.init();
@@ -341,11 +365,11 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     if (a.gate != 1) {
 #pragma unroll
         for (int k = 0; k < SR; ++k) {
-            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            const unsigned int j = OSQ_FUSED_TOKEN(k);
             if (j >= V && j < total) {
 #pragma unroll
                 for (int u = 0; u < NV; ++u)
-                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + OSQ_FUSED_PIECE(u), kNt);
             }
         }
         asm volatile("" ::: "memory");
@@ -362,21 +386,21 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     if (a.gate == 1) {
 #pragma unroll
         for (int k = 0; k < SR; ++k) {
-            const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+            const unsigned int j = OSQ_FUSED_TOKEN(k);
             if (j >= V && j < total) {
 #pragma unroll
                 for (int u = 0; u < NV; ++u)
-                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+                    hold[k][u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + OSQ_FUSED_PIECE(u), kNt);
             }
         }
     }
 #pragma unroll
     for (int k = SR; k < S; ++k) {
-        const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+        const unsigned int j = OSQ_FUSED_TOKEN(k);
         if (j >= V && j < total) {
             v4u32 w[NV];
 #pragma unroll
-            for (int u = 0; u < NV; ++u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + u * 1024u, kNt);
+            for (int u = 0; u < NV; ++u) w[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, lane_off, row[k] * kRowBytes + OSQ_FUSED_PIECE(u), kNt);
 #pragma unroll
             for (int u = 0; u < NV; ++u) keep_w[((k - SR) * NV + u) * OSQ_WAVE] = w[u];
         }
@@ -440,14 +464,14 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     // ---- phase C: quantise from the registers / LDS
 #pragma unroll
     for (int k = 0; k < S; ++k) {
-        const unsigned int j = gw + static_cast<unsigned int>(k) * nwv;
+        const unsigned int j = OSQ_FUSED_TOKEN(k);
         if (j < total) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const v4u32 w = k < SR ? hold[k < SR ? k : 0][u] : keep_w[((k - SR) * NV + u) * OSQ_WAVE];
                 float4 o, q;
                 fq4_plain(as_float4(w), o, q, qs, qz, a.qmin, a.qmax);
-                store_row16(as_v4u32(o), yrs, lane_off, row[k] * kRowBytes + u * 1024u);
+                store_row16(as_v4u32(o), yrs, lane_off, row[k] * kRowBytes + OSQ_FUSED_PIECE(u));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -483,6 +507,8 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         }
     }
     OSQ_FSTAMP(6);
+#undef OSQ_FUSED_TOKEN
+#undef OSQ_FUSED_PIECE
 }
 
 }  // namespace osq

@@ -865,6 +865,10 @@ static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces 
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
 static int g_fused_step = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_fused_gate = 2;          // osq_set_tuning("fused_gate", 0|1|2): which padded loads wait for the selectors (fused_step.h, phase A2)
+#ifndef OSQ_FUSED_DEAL_DEFAULT
+#define OSQ_FUSED_DEAL_DEFAULT 2
+#endif
+static int g_fused_deal = OSQ_FUSED_DEAL_DEFAULT;   // osq_set_tuning("fused_deal", 0|1|2): how a slot's tokens are dealt to the waves (fused_step.h)
 static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
@@ -1273,6 +1277,7 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
     if (k == "fused_step") { g_fused_step = value != 0; return true; }
     if (k == "fused_gate") { if (value < 0 || value > 2) return false; g_fused_gate = value; return true; }
+    if (k == "fused_deal") { if (value < 0 || value > 2) return false; g_fused_deal = value; return true; }
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
@@ -1601,7 +1606,7 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
         const Finish fin{update_rule, cnt, min_val, max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
         const FusedArgs a{x, y, v.batch, v.tokens, lengths, token_min, token_max, prune, static_cast<float>(percentile),
                           g_select_shortcut, static_cast<FusedState*>(Workspace(workspace).fused()), scale, zero_point,
-                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate};
+                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_fused_deal};
         hipStream_t st = static_cast<hipStream_t>(stream);
         bool launched = false;
         switch (nv) {

@@ -135,6 +135,33 @@ def test_fused_step_equals_three_launches(shape, lengths, dev):
     assert fused_status(dev) == 0
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 768), (32, 128, 4096), (96, 64, 1024)])
+def test_fused_step_token_dealings_agree(shape, dev):
+    """osq_set_tuning("fused_deal", 0 | 1 | 2) changes which wave streams which token (fused_step.h), never a result:
+    statistics, parameters and every output element are bit-equal across the three dealings, with and without padding."""
+    from outlier_suppression_amd import ops
+    B, T, H = shape
+    gen = torch.Generator().manual_seed(B * T + H)
+    gd = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(*shape, device=dev, generator=gd)
+    x[..., 9] *= 15
+    try:
+        for L in (torch.randint(0, T + 1, (B,), generator=gen).to(dev), torch.full((B,), T, device=dev)):
+            out = []
+            for deal in (2, 1, 0):
+                ops.set_tuning("fused_deal", deal)
+                q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False, percentile=0.93)
+                with torch.no_grad():
+                    y = q(x, L, 1)
+                out.append((y, q.observer.min_val.clone(), q.observer.max_val.clone(), q.scale.detach().clone(), q.zero_point.detach().clone()))
+            for other in out[1:]:
+                for a, b in zip(out[0], other):
+                    assert torch.equal(a, b)
+    finally:
+        ops.set_tuning("fused_deal", 2)
+    assert fused_status(dev) == 0
+
+
 def test_fused_step_many_launches_two_streams(dev):
     """Launch-to-launch state: 300 launches with changing masks alternate between two streams (each has its own
     workspace; the host orders launches of different streams, two persistent grids must never share the device);

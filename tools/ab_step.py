@@ -15,12 +15,17 @@ def child(lib_name, full):
     import time
     import torch
     from outlier_suppression_amd import _hip
+    label = lib_name
+    lib_name, _, knobs = lib_name.partition(":")          # libosq_hip.so:fused_deal=2,fused_gate=1
     _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), lib_name)
     from tools.fused_check import mk, dev, status
     lib = _hip.load()
-    shape = (256, 128, 768)
+    for kv in filter(None, knobs.split(",")):
+        key, _, val = kv.partition("=")
+        assert lib.osq_set_tuning(key.encode(), int(val)) == 0, kv
+    shape = tuple(int(v) for v in os.environ.get("AB_SHAPE", "256x128x768").split("x"))
     g = torch.Generator().manual_seed(1234)
-    lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, 129, (shape[0],), generator=g)).to(dev)
+    lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, shape[1] + 1, (shape[0],), generator=g)).to(dev)
     xs = [torch.randn(*shape, device=dev) for _ in range(4)]
     for x in xs:
         x[..., 7] *= 20
@@ -65,7 +70,7 @@ def child(lib_name, full):
             ks.append(us.value)
     ks.sort()
     reps.sort()
-    print(f"{lib_name:28s} graph us/step min {reps[0]:6.2f} med {reps[len(reps) // 2]:6.2f} | kernel us med {ks[len(ks) // 2]:6.2f} min {ks[0]:6.2f} | status {status()}", flush=True)
+    print(f"{label:28s} graph us/step min {reps[0]:6.2f} med {reps[len(reps) // 2]:6.2f} | kernel us med {ks[len(ks) // 2]:6.2f} min {ks[0]:6.2f} | status {status()}", flush=True)
 
 
 if __name__ == "__main__":

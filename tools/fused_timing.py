@@ -11,7 +11,10 @@ lib = _hip.load()
 lib.osq_debug_buffer.argtypes = [ctypes.c_void_p]
 shape = (256, 128, 768)
 g = torch.Generator().manual_seed(1234)
-full = len(sys.argv) > 1 and sys.argv[1] == "full"
+full = "full" in sys.argv[1:]
+for a in sys.argv[1:]:
+    if a.startswith("deal="):
+        ops.set_tuning("fused_deal", int(a[5:]))
 lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, 129, (shape[0],), generator=g)).to(dev)
 xs = [torch.randn(*shape, device=dev) for _ in range(4)]
 dbg = torch.zeros(260 * 8, dtype=torch.int64, device=dev)
@@ -36,6 +39,10 @@ s = d[2:]
 for k, name in [(0, "start"), (7, "prefix sums"), (1, "mapped"), (2, "A1 done (wave 0)"), (3, "arrived"), (4, "scale seen"), (5, "after barrier"), (6, "end")]:
     v = us(s[:, k])
     print(f"streaming {name:>18}: min {float(v.min()):7.2f}  median {float(v.median()):7.2f}  max {float(v.max()):7.2f}")
+xcd = (torch.arange(254) + 2) % 8
+for k, name in [(0, "start"), (1, "mapped"), (2, "A1 done (wave 0)"), (3, "arrived"), (6, "end")]:
+    v = us(s[:, k])
+    print(f"by XCD {name:>18} (median):", [round(float(v[xcd == x].median()), 2) for x in range(8)])
 arr = us(s[:, 3])
 print("arrival by XCD (median/max):", [(round(float(arr[(torch.arange(254) + 2) % 8 == x].median()), 1), round(float(arr[(torch.arange(254) + 2) % 8 == x].max()), 1)) for x in range(8)])
 order = arr.argsort(descending=True)[:12]

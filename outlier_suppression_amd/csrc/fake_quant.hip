@@ -20,7 +20,8 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
 static int g_fq_max_blocks = 8192;
-static int g_fq_nt = 3;          // bit 0: loads, bit 1: stores
+static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
+static int g_stream_wt = 1;      // osq_set_tuning("stream_wt", 0): nt stores instead of write-through ones in the LSQ backward and the GELU fake-quant (measured no gain, or a loss, in the LayerNorm site)
 static int g_bwd_blocks = kMaxBlocks;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n))
 
 template <bool WRITE_Q>
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float s = p.scale, z = p.zp;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
     int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const WtStore ywt(y, (NT & 4) ? n4 : 0), qwt(xq, (NT & 4) && WRITE_Q ? n4 : 0);      // NT & 4: write-through stores (n4 < 2^28)
     // main body: UNROLL independent 16-byte loads, then arithmetic, then stores
     for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
         float4 v[UNROLL];
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
             float4 o, q;
             if (GELU) v[u] = make_float4(gelu_erf(v[u].x), gelu_erf(v[u].y), gelu_erf(v[u].z), gelu_erf(v[u].w));
             fq4<WRITE_Q>(v[u], o, q, s, z, qmin, qmax);
-            if (NT & 2) store_stream(&y[i + u * stride], o); else y[i + u * stride] = o;
-            if (WRITE_Q) { if (NT & 2) store_stream(&xq[i + u * stride], q); else xq[i + u * stride] = q; }
+            if (NT & 4) ywt.put(i + u * stride, o); else if (NT & 2) store_stream(&y[i + u * stride], o); else y[i + u * stride] = o;
+            if (WRITE_Q) { if (NT & 4) qwt.put(i + u * stride, q); else if (NT & 2) store_stream(&xq[i + u * stride], q); else xq[i + u * stride] = q; }
         }
     }
     for (; i < n4; i += stride) {
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
     const float* __restrict__ xt, const float* __restrict__ gyt, float* __restrict__ dxt, int tail,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
     float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp,
-    double* __restrict__ partials, unsigned int* __restrict__ counter) {
+    double* __restrict__ partials, unsigned int* __restrict__ counter, int wt) {
+    const WtStore dwt(dx, wt ? n4 : 0);                   // wt: grad_x leaves through write-through stores (n4 < 2^28)
     const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
     const float s = p.scale, z = p.zp;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -307,13 +310,13 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
         o.y = bwd_elem(a0.y, b0.y, s, z, qmin, qmax, acc);
         o.z = bwd_elem(a0.z, b0.z, s, z, qmin, qmax, acc);
         o.w = bwd_elem(a0.w, b0.w, s, z, qmin, qmax, acc);
-        store_stream(&dx[i], o);
+        if (wt) dwt.put(i, o); else store_stream(&dx[i], o);
         if (two) {
             o.x = bwd_elem(a1.x, b1.x, s, z, qmin, qmax, acc);
             o.y = bwd_elem(a1.y, b1.y, s, z, qmin, qmax, acc);
             o.z = bwd_elem(a1.z, b1.z, s, z, qmin, qmax, acc);
             o.w = bwd_elem(a1.w, b1.w, s, z, qmin, qmax, acc);
-            store_stream(&dx[i + stride], o);
+            if (wt) dwt.put(i + stride, o); else store_stream(&dx[i + stride], o);
         }
         t_ds += static_cast<double>(acc.ds_mul) + static_cast<double>(acc.ds_div);
         t_dz += static_cast<double>(acc.dz);
@@ -420,6 +423,8 @@ __global__ void lsq_sanitize_kernel(float* __restrict__ scale, float* __restrict
     }
 }
 
+bool stream_write_through() { return g_stream_wt != 0; }
+
 static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -456,8 +461,9 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
                           n4, x + n4 * 4, y + n4 * 4, x_quant ? x_quant + n4 * 4 : nullptr, tail, scale, zero_point,       \
                           zp_type, mode, grad_factor, qmin, qmax)
 #define OSQ_FQ_NT(WQ, U)                                                   \
-    switch (g_fq_nt) { case 0: OSQ_FQ(WQ, U, 0); break; case 1: OSQ_FQ(WQ, U, 1); break; \
-                       case 2: OSQ_FQ(WQ, U, 2); break; default: OSQ_FQ(WQ, U, 3); }
+    switch (n4 <= kWtMaxFloat4 ? g_fq_nt : (g_fq_nt & 3)) {                                             \
+        case 0: OSQ_FQ(WQ, U, 0); break; case 1: OSQ_FQ(WQ, U, 1); break; case 2: OSQ_FQ(WQ, U, 2); break; \
+        case 3: OSQ_FQ(WQ, U, 3); break; case 4: OSQ_FQ(WQ, U, 4); break; default: OSQ_FQ(WQ, U, 5); }
         if (x_quant) { OSQ_FQ_NT(true, 4) }
         else if (g_fq_unroll == 2) { OSQ_FQ_NT(false, 2) }
         else if (g_fq_unroll == 8) { OSQ_FQ_NT(false, 8) }
@@ -493,10 +499,13 @@ extern "C" int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t 
     const int64_t n4 = n / 4;
     const int tail = static_cast<int>(n - n4 * 4);
     const int grid = grid_for(n4 > 0 ? n4 : 1, kThreads * 2, g_fq_max_blocks);
-    hipLaunchKernelGGL((fq_tensor_vec_kernel<false, 2, 3, true>), dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), static_cast<float4*>(nullptr), n4,
-                       x + n4 * 4, y + n4 * 4, static_cast<float*>(nullptr), tail, scale, zero_point, zp_type, mode,
-                       grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max));
+#define OSQ_GELU_FQ(NT)                                                                                                          \
+    hipLaunchKernelGGL((fq_tensor_vec_kernel<false, 2, NT, true>), dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), \
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), static_cast<float4*>(nullptr), n4,        \
+                       x + n4 * 4, y + n4 * 4, static_cast<float*>(nullptr), tail, scale, zero_point, zp_type, mode,               \
+                       grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max))
+    if (stream_write_through() && n4 <= kWtMaxFloat4) OSQ_GELU_FQ(5); else OSQ_GELU_FQ(3);
+#undef OSQ_GELU_FQ
     return check_launch("gelu_fake_quant_per_tensor");
 }
 
@@ -597,7 +606,8 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
                        grad_out + n4 * 4, grad_x + n4 * 4, tail, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax,
-                       grad_scale, grad_zero_point, ws.doubles(kFamLsqBackward), ws.counter(kFamLsqBackward));
+                       grad_scale, grad_zero_point, ws.doubles(kFamLsqBackward), ws.counter(kFamLsqBackward),
+                       (stream_write_through() && n4 <= kWtMaxFloat4) ? 1 : 0);
     return check_launch("lsq_backward_per_tensor");
 }
 
@@ -645,7 +655,8 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }
-    else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 3, "fq_nt must be 0..3"); osq::g_fq_nt = value; }
+    else if (k == "stream_wt") { osq::g_stream_wt = value != 0; }
+    else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 5, "fq_nt must be 0..5"); osq::g_fq_nt = value; }
     else if (osq::set_observer_tuning(key, value)) { }
     else if (osq::set_msefast_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }

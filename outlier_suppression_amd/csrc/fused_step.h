@@ -109,7 +109,9 @@ __device__ __forceinline__ v4u32 as_v4u32(const float4& f) {
 // picks up the NEXT element's v_div_scale result in its first data register for the last four lanes of every row --
 // measured here as y.x == scale in ~5 % of the rows, different ones on every run.
 __device__ __forceinline__ void store_row16(const v4u32& data, __amdgpu_buffer_rsrc_t rsrc, unsigned int lane_off, unsigned int row_off) {
-    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, lane_off + row_off, 0, 2 /* nt */);
+    // sc1 = write-through: nothing of the 96 MiB of y stays dirty in the L2s for the end of the launch to write back
+    // (nt stores: 40.9 us per step, plain 41.5, sc1 or sc0 sc1 38.9, nt sc1 40.5; tools/ab_step.py on one box)
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, lane_off + row_off, 0, 16 /* sc1 */);
 }
 
 // development aid (-DOSQ_FINAL_TIMING, `make dbg`): thread 0 of every workgroup stamps the 100 MHz wall clock
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, static_cast<int>(tensor_bytes), 0x00020000);
     const unsigned int lane_off = static_cast<unsigned int>(lane) * 16u;
     constexpr unsigned int kRowBytes = H4 * 16u;
-    constexpr int kNt = 2;                                // aux: non-temporal (streamed once)
+    constexpr int kNt = 2;                                // aux: non-temporal (streamed once).  Plain, sc0 or sc1 loads instead: 50 us per step against 38.5
     // this wave's LDS slots: float4 (slot s, step u, lane) at keep[((wv * SL + s) * NV + u) * 64 + lane]
     v4u32* const keep_w = keep + static_cast<unsigned int>(wv) * (SL * NV * OSQ_WAVE) + lane;
 

@@ -164,6 +164,24 @@ __device__ __forceinline__ void store_stream(float4* p, const float4& o) {
     __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
 }
 
+// 16-byte WRITE-THROUGH (sc1) stores into a tensor of less than 4 GiB, addressed base (SGPR descriptor) + 32-bit byte offset.
+// A kernel that streams a large output with plain or nt stores leaves dirty lines in the XCDs' L2s and pays for their
+// write-back at its end (MI355X_MICROARCH.md, boundary row: + B / 6 TB/s for B dirty bytes); write-through stores leave
+// nothing behind.  Measured: the fused observe + fake-quant step 40.9 -> 38.9 us.  The offset goes into the VGPR operand
+// (see store_row16 in fused_step.h for why not into soffset).
+typedef unsigned int osq_v4u32 __attribute__((ext_vector_type(4)));
+struct WtStore {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ WtStore(float4* base, int64_t n4)
+        : rs(__builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>(static_cast<unsigned int>(n4 * 16)), 0x00020000)) {}
+    __device__ __forceinline__ void put(int64_t i, const float4& o) const {
+        osq_v4u32 w;
+        w.x = __float_as_uint(o.x); w.y = __float_as_uint(o.y); w.z = __float_as_uint(o.z); w.w = __float_as_uint(o.w);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, static_cast<unsigned int>(i) * 16u, 0, 16 /* sc1 */);
+    }
+};
+constexpr int64_t kWtMaxFloat4 = (1ll << 28) - 1;      // 4 GiB - 16 B
+
 // ---- wave64 / block reductions -------------------------------------------------------
 
 // DPP cross-lane moves run at VALU rate (no LDS crossbar round trip like ds_bpermute).

@@ -53,8 +53,8 @@ typedef enum osq_param_mode {
      * IN PLACE the way LSQFakeQuantize / LSQPlusFakeQuantize.forward do while their observer is off
      * (fake_quant.py:152-153, 188-191: scale.abs_(); scale.clamp_(min=finfo(float32).eps); LSQ+ also
      * zero_point.clamp_(quant_min, quant_max)), then quantise with the repaired values -- the same
-     * result as osq_lsq_sanitize followed by the plain call, in one launch.  `scale` (and a float32
-     * `zero_point`) are written through despite their const qualifier. */
+     * result as osq_lsq_sanitize followed by the plain call, in one launch.  These entry points therefore take
+     * `scale` / `zero_point` without a const qualifier; without the flag they only read them. */
     OSQ_PARAM_SANITIZE = 16
 } osq_param_mode;
 
@@ -120,7 +120,7 @@ int osq_timing_elapsed_us(void* start, void* stop, float* us);
  * (LSQFakeQuantize / LSQPlusFakeQuantize.forward, fake_quant.py:159-167 / 199-208).
  * x, y: n contiguous fp32.  x_quant (nullable): the clamped integer tensor, fp32 storage. */
 int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t n,
-                              const float* scale, const void* zero_point, int zp_type,
+                              float* scale, void* zero_point, int zp_type,
                               int mode, float grad_factor, int quant_min, int quant_max,
                               osq_stream stream);
 
@@ -129,7 +129,7 @@ int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t 
  * with torch's exact (erf) GELU, bit-identical to F.gelu followed by osq_fake_quant_per_tensor.  x, y: n
  * contiguous fp32, 16-byte aligned (else OSQ_ERR_UNSUPPORTED).  Inference only. */
 int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t n,
-                                   const float* scale, const void* zero_point, int zp_type,
+                                   float* scale, void* zero_point, int zp_type,
                                    int mode, float grad_factor, int quant_min, int quant_max,
                                    osq_stream stream);
 
@@ -138,7 +138,7 @@ int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t n,
 int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,
                                       const int64_t sizes[4], const int64_t x_strides[4],
                                       const int64_t y_strides[4],
-                                      const float* scale, const void* zero_point, int zp_type,
+                                      float* scale, void* zero_point, int zp_type,
                                       int mode, float grad_factor, int quant_min, int quant_max,
                                       osq_stream stream);
 
@@ -474,7 +474,7 @@ int osq_gamma_residual(const float* input, const float* hidden, const float* gam
 int osq_residual_layernorm_fake_quant(const float* x, const float* hidden, const float* gamma,
                                       const float* weight, const float* bias, double eps,
                                       float* y, int64_t rows, int64_t cols,
-                                      const float* scale, const void* zero_point, int zp_type,
+                                      float* scale, void* zero_point, int zp_type,
                                       int mode, float grad_factor, int quant_min, int quant_max,
                                       osq_stream stream);
 

@@ -50,7 +50,7 @@ template <bool WRITE_Q, int UNROLL, int NT, bool GELU = false>
 __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
     const float4* __restrict__ x, float4* __restrict__ y, float4* __restrict__ xq, int64_t n4,
     const float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ xqt, int tail,
-    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float* scale_p, void* zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
     const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const float s = p.scale, z = p.zp;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_vec_kernel(
 template <bool WRITE_Q>
 __global__ __launch_bounds__(kThreads) void fq_tensor_scalar_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, int64_t n,
-    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float* scale_p, void* zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
     const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -109,7 +109,7 @@ struct Strided4 {
 template <bool WRITE_Q>
 __global__ __launch_bounds__(kThreads) void fq_tensor_strided_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xq, Strided4 d, int64_t n,
-    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float* scale_p, void* zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
     const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -139,7 +139,7 @@ struct Strided4v {
 
 __global__ __launch_bounds__(kThreads) void fq_tensor_strided_vec_kernel(
     const float4* __restrict__ x, float4* __restrict__ y, Strided4v d, int64_t n4,
-    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float* scale_p, void* zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
     const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -437,7 +437,7 @@ static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
 using namespace osq;
 
 extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quant, int64_t n,
-                                         const float* scale, const void* zero_point, int zp_type,
+                                         float* scale, void* zero_point, int zp_type,
                                          int mode, float grad_factor, int quant_min, int quant_max,
                                          osq_stream stream) {
     OSQ_REQUIRE(n >= 0 && (n == 0 || (x && y)) && scale && zero_point, "fake_quant_per_tensor: null pointer or n < 0");
@@ -485,7 +485,7 @@ extern "C" int osq_fake_quant_per_tensor(const float* x, float* y, float* x_quan
 /* y = fake_quantize(gelu(x)): the intermediate-activation site of a transformer block
  * (model/quant_bert.py:277-280: dense -> GELU -> intermediate_act_fn_post_act_fake_quantize) in one pass. */
 extern "C" int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t n,
-                                              const float* scale, const void* zero_point, int zp_type,
+                                              float* scale, void* zero_point, int zp_type,
                                               int mode, float grad_factor, int quant_min, int quant_max,
                                               osq_stream stream) {
     OSQ_REQUIRE(n >= 0 && (n == 0 || (x && y)) && scale && zero_point, "gelu_fake_quant_per_tensor: null pointer or n < 0");
@@ -512,7 +512,7 @@ extern "C" int osq_gelu_fake_quant_per_tensor(const float* x, float* y, int64_t 
 extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,
                                                  const int64_t sizes[4], const int64_t x_strides[4],
                                                  const int64_t y_strides[4],
-                                                 const float* scale, const void* zero_point, int zp_type,
+                                                 float* scale, void* zero_point, int zp_type,
                                                  int mode, float grad_factor, int quant_min, int quant_max,
                                                  osq_stream stream) {
     OSQ_REQUIRE(sizes && x_strides && y_strides && scale && zero_point, "fake_quant_per_tensor_strided: null pointer");

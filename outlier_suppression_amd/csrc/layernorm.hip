@@ -47,8 +47,8 @@ struct LnArgs {
     int64_t rows;
     int cols4;
     float inv_cols, eps;
-    const float* scale;       // nullable: no fake-quant
-    const void* zero_point;
+    float* scale;             // nullable: no fake-quant (written only under OSQ_PARAM_SANITIZE)
+    void* zero_point;
     int zp_type, mode;
     float grad_factor, qmin, qmax;
 };
@@ -138,7 +138,7 @@ using namespace osq;
 extern "C" int osq_residual_layernorm_fake_quant(const float* x, const float* hidden, const float* gamma,
                                                  const float* weight, const float* bias, double eps,
                                                  float* y, int64_t rows, int64_t cols,
-                                                 const float* scale, const void* zero_point, int zp_type,
+                                                 float* scale, void* zero_point, int zp_type,
                                                  int mode, float grad_factor, int quant_min, int quant_max,
                                                  osq_stream stream) {
     OSQ_REQUIRE(rows >= 0 && cols > 0, "residual_layernorm_fake_quant: bad shape");

@@ -393,20 +393,38 @@ __global__ __launch_bounds__(kThreads) void token_minmax_generic_kernel(const fl
 // (quantization/deferred.py) and reduced together: wave = one token of one site, found by bisection over the
 // table's running token counts; padded tokens are skipped without a read; any layout (16-byte loads when the
 // innermost feature axis is contiguous and aligned).
+constexpr int kMultiLdsSites = 512;            // running token counts of that many sites are bisected in LDS
 __global__ __launch_bounds__(kThreads) void token_minmax_multi_kernel(const osq_site_desc* __restrict__ descs,
                                                                       const int64_t* __restrict__ tok_end, int n_sites,
                                                                       int64_t total_tokens) {
+    // A wave's token costs a chain of dependent reads before its data load leaves: the bisection (7 steps for 96 sites),
+    // the site's descriptor, the sample's length.  Out of global memory that chain was ~5 us per 3 KiB token (2.6 TB/s at
+    // full occupancy); the table now sits in LDS and the descriptor is read through the scalar cache (wave-uniform index).
+    __shared__ int64_t s_end[kMultiLdsSites];
+    const bool in_lds = n_sites <= kMultiLdsSites;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < n_sites; k += kThreads) s_end[k] = tok_end[k];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     for (int64_t g = wave0; g < total_tokens; g += nwaves) {
         int lo = 0, hi = n_sites - 1;                 // first site whose tok_end exceeds g
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (tok_end[mid] > g) hi = mid; else lo = mid + 1;
+        if (in_lds) {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_end[mid] > g) hi = mid; else lo = mid + 1;
+            }
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tok_end[mid] > g) hi = mid; else lo = mid + 1;
+            }
         }
+        lo = __builtin_amdgcn_readfirstlane(lo);      // the wave's token is one: the descriptor load is a scalar load
         const osq_site_desc d = descs[lo];
-        const int64_t tok = g - (lo ? tok_end[lo - 1] : 0);
+        const int64_t tok = g - (lo ? (in_lds ? s_end[lo - 1] : tok_end[lo - 1]) : 0);
         const int64_t b = tok / d.view.tokens, t = tok - b * d.view.tokens;
         if (d.lengths && t >= d.lengths[b]) continue;
         const float* base = d.x + b * d.view.stride_batch + t * d.view.stride_token;
@@ -424,8 +442,19 @@ __global__ __launch_bounds__(kThreads) void token_minmax_multi_kernel(const osq_
                 }
                 for (; j < F4; j += OSQ_WAVE) acc.add4(load_stream(row + j));
             } else {
-                for (int64_t j = lane; j < F4; j += OSQ_WAVE) {
-                    const int64_t o = j / inner4, i = j - o * inner4;
+                // head-split views ([B,h,T,64] and its transposes): three independent loads per trip here too
+                const int ii = inner4;
+                int64_t j = lane;
+                for (; j + 2 * OSQ_WAVE < F4; j += 3 * OSQ_WAVE) {
+                    const int64_t j1 = j + OSQ_WAVE, j2 = j + 2 * OSQ_WAVE;
+                    const int64_t o0 = j / ii, o1 = j1 / ii, o2 = j2 / ii;
+                    const float4 a = load_stream(reinterpret_cast<const float4*>(base + o0 * d.view.stride_outer) + (j - o0 * ii));
+                    const float4 c = load_stream(reinterpret_cast<const float4*>(base + o1 * d.view.stride_outer) + (j1 - o1 * ii));
+                    const float4 e = load_stream(reinterpret_cast<const float4*>(base + o2 * d.view.stride_outer) + (j2 - o2 * ii));
+                    acc.add4(a); acc.add4(c); acc.add4(e);
+                }
+                for (; j < F4; j += OSQ_WAVE) {
+                    const int64_t o = j / ii, i = j - o * ii;
                     acc.add4(load_stream(reinterpret_cast<const float4*>(base + o * d.view.stride_outer) + i));
                 }
             }
@@ -1509,8 +1538,6 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
 // A whole quantizer call in the calibrate-and-quantize state (fake_quant.py:107-126 / 178-208 with both flags on)
 // for a masked per-tensor activation.  Dense [B, T, H] rows: ONE persistent launch (fused_step.h); otherwise
 // observe (two launches) then fake-quant with the refreshed parameters.
-extern "C" int osq_fake_quant_per_tensor(const float*, float*, float*, int64_t, const float*, const void*, int, int, float,
-                                         int, int, osq_stream);
 
 namespace osq {
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ QParams effective_params(float scale, float zp, int m
 // whether a thread sees the raw or the already repaired word) and thread 0 of workgroup 0 writes them back.
 constexpr float kLsqEps = 1.1920928955078125e-07f;     // torch.finfo(torch.float32).eps, the modules' `eps` buffer
 
-__device__ __forceinline__ QParams tensor_params(const float* scale_p, const void* zp_p, int zp_type, int mode, float g,
+__device__ __forceinline__ QParams tensor_params(float* scale_p, void* zp_p, int zp_type, int mode, float g,
                                                  float qmin, float qmax) {
     float s = scale_p[0], z = load_zp(zp_p, zp_type);
     const int base = mode & OSQ_PARAM_MODE_MASK;
@@ -58,8 +58,8 @@ __device__ __forceinline__ QParams tensor_params(const float* scale_p, const voi
             z = (z > qmax) ? qmax : z;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const_cast<float*>(scale_p)[0] = s;
-            if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) static_cast<float*>(const_cast<void*>(zp_p))[0] = z;
+            scale_p[0] = s;
+            if (base == OSQ_PARAM_LSQPLUS && zp_type == OSQ_ZP_FLOAT32) static_cast<float*>(zp_p)[0] = z;
         }
     }
     return effective_params(s, z, base, g);

@@ -242,8 +242,8 @@ def kernel_table(dev, xs, lengths, reps=20):
         l32 = torch.randint(8, 129, (32,), device=dev)
         for tag, view, sp in (("32x12x128x64 (q/v view of [B,T,h,d])", mem.permute(0, 2, 1, 3), 2),
                               ("32x12x64x128 (key view, strided)", mem.permute(0, 2, 3, 1), 3)):
-            add_ev(f"site {tag}: fake_quant_forward", ev_timed(lambda i: ops.fake_quant_per_tensor(view, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)),
-                   8 * mem.numel())
+            add(f"site {tag}: fake_quant_forward", timed(_hip.TIME_FAKE_QUANT_STRIDED, lambda i: ops.fake_quant_per_tensor(
+                view, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * mem.numel())
             vv = int(l32.sum().item()) * 12 * 64
             add(f"site {tag}: token_minmax (masked)", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(view, sp, l32)), 4 * vv)
         # weights: per-channel fake-quant (6-bit symmetric, ch_axis 0) and per-channel MinMax observer (+ qparams), one launch each
@@ -252,11 +252,12 @@ def kernel_table(dev, xs, lengths, reps=20):
             ws_, wz_ = torch.full((shp[0],), 0.01, device=dev), torch.zeros(shp[0], dtype=torch.int32, device=dev)
             wmn, wmx = torch.full((shp[0],), float("inf"), device=dev), torch.full((shp[0],), float("-inf"), device=dev)
             tag = "x".join(str(d) for d in shp)
-            add_ev(f"weight {tag}: fake_quant per-channel", ev_timed(lambda i: ops.fake_quant_per_channel(w, ws_, wz_, 0, -32, 31)), 8 * w.numel())
-            add_ev(f"weight {tag}: MinMaxObserver per-channel (+qparams)",
-                   ev_timed(lambda i: ops.observe_channels(w, 0, ops.UPDATE_RUNNING, 0, wmn, wmx, -32, 31, True, ops.QParamSink(ws_, wz_))), 4 * w.numel())
+            add(f"weight {tag}: fake_quant per-channel", timed(_hip.TIME_FAKE_QUANT_CHANNEL, lambda i: ops.fake_quant_per_channel(
+                w, ws_, wz_, 0, -32, 31)), 8 * w.numel())
+            add(f"weight {tag}: MinMaxObserver per-channel (+qparams)", timed(_hip.TIME_OBSERVE_CHANNELS, lambda i: ops.observe_channels(
+                w, 0, ops.UPDATE_RUNNING, 0, wmn, wmx, -32, 31, True, ops.QParamSink(ws_, wz_))), 4 * w.numel())
             if shp[0] <= 3072:
-                us = ev_timed(lambda i: ops.msefast_rows(w, 0, -8, 7, True, "no", False))
+                us = timed(_hip.TIME_MSEFAST_ROWS, lambda i: ops.msefast_rows(w, 0, -8, 7, True, "no", False))
                 rows[f"weight {tag}: MSEFast 4-bit symmetric per-channel (one bounded-Brent search per row)"] = {
                     "avg_us": round(us, 2), "bound": "compute (row in registers, ~15 loss evaluations per row)",
                     "algorithmic_MB": round(4 * w.numel() / 1e6, 1), "rows": shp[0]}
@@ -660,6 +661,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (0 for profiler runs)")
+    ap.add_argument("--preroll", type=float, default=0.25, help="seconds of untimed graph replays directly before the timed one")
     ap.add_argument("--buffers", type=int, default=4, help="distinct input tensors cycled through (4 x 96 MiB > 256 MiB Infinity Cache)")
     ap.add_argument("--eager", action="store_true", help="time the eager loop of module calls instead of the captured graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -771,9 +773,16 @@ def main():
     gc.collect()
     gc.disable()                               # no collector pauses inside the timed region
     if graph is not None:
-        # untimed: the collector pass above leaves the GPU idle for tens of milliseconds and its clocks fall back
-        # (MI355X_MICROARCH.md, DVFS); the timed region should start on a device that is already running this work
+        # untimed: capture and the collector pass above leave the GPU idle for tens of milliseconds and its clocks fall
+        # back (MI355X_MICROARCH.md, DVFS); a few replays do not bring them back (tools/region_probe.py: the same
+        # 20-step replay reads 41.5 us per step in the first milliseconds and 40.3 after ~50 ms of this work).  The
+        # timed region should measure the device in the state it runs this work in: replay for --preroll seconds
         with torch.no_grad():
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.preroll:
+                for _ in range(4):
+                    graph.replay()
+                torch.cuda.synchronize()
             for _ in range(3):
                 graph.replay()
     barrier()
@@ -810,13 +819,17 @@ def main():
         check_status(graph_ws)
     # the same K steps as an eager loop (untimed region): GPU time per step and host enqueue time per step
     with torch.no_grad():
-        torch.cuda.synchronize()
-        te = time.perf_counter()
-        for i in range(args.steps):
-            y = step(i)
-        eager_host = time.perf_counter() - te
-        torch.cuda.synchronize()
-        eager_dt = time.perf_counter() - te
+        eager_runs = []
+        for _ in range(5):                     # median of five K-step loops (a single 1 ms loop is at the mercy of its first call)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for i in range(args.steps):
+                y = step(i)
+            eh = time.perf_counter() - te
+            torch.cuda.synchronize()
+            eager_runs.append((time.perf_counter() - te, eh))
+        eager_runs.sort()
+        eager_dt, eager_host = eager_runs[len(eager_runs) // 2]
     del y
     check_status(_hip.workspace(dev))
 

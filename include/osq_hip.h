@@ -105,7 +105,12 @@ typedef enum osq_timed_kernel {
     OSQ_TIME_TOKEN_MINMAX = 4,   /* osq_token_minmax / first launch of osq_observe_tokens */
     OSQ_TIME_TOKEN_SELECT = 5,   /* two-workgroup launch of osq_token_range_finalize      */
     OSQ_TIME_LAYERNORM = 6,      /* osq_residual_layernorm_fake_quant                     */
-    OSQ_TIME_FUSED_STEP = 7      /* one-launch form of osq_observe_tokens_fake_quant      */
+    OSQ_TIME_FUSED_STEP = 7,     /* one-launch form of osq_observe_tokens_fake_quant      */
+    OSQ_TIME_FAKE_QUANT_STRIDED = 8,  /* 16-byte form of osq_fake_quant_per_tensor_strided (head-split views) */
+    OSQ_TIME_FAKE_QUANT_CHANNEL = 9,  /* row form of osq_fake_quant_per_channel (weights, ch_axis 0)          */
+    OSQ_TIME_OBSERVE_CHANNELS = 10,   /* osq_observe_channels                                                */
+    OSQ_TIME_TOKEN_MINMAX_MULTI = 11, /* osq_token_minmax_multi                                              */
+    OSQ_TIME_MSEFAST_ROWS = 12        /* osq_msefast_rows (the per-row search launch)                        */
 } osq_timed_kernel;
 int osq_timing_events_create(void** start, void** stop);
 int osq_timing_events_destroy(void* start, void* stop);

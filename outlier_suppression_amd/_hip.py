@@ -19,6 +19,7 @@ PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
 PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
 TIME_LAYERNORM, TIME_FUSED_STEP = 6, 7
+TIME_FAKE_QUANT_STRIDED, TIME_FAKE_QUANT_CHANNEL, TIME_OBSERVE_CHANNELS, TIME_TOKEN_MINMAX_MULTI, TIME_MSEFAST_ROWS = 8, 9, 10, 11, 12
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
 

@@ -46,7 +46,7 @@ extern "C" int osq_timing_events_destroy(void* start, void* stop) {
 }
 
 extern "C" int osq_time_next_launch(int which, void* start, void* stop) {
-    OSQ_REQUIRE(which >= OSQ_TIME_NONE && which <= OSQ_TIME_FUSED_STEP, "time_next_launch: unknown kernel family");
+    OSQ_REQUIRE(which >= OSQ_TIME_NONE && which <= OSQ_TIME_MSEFAST_ROWS, "time_next_launch: unknown kernel family");
     OSQ_REQUIRE((start == nullptr) == (stop == nullptr), "time_next_launch: give both events or neither");
     osq::g_time_which = start ? which : 0;
     osq::g_time_start = static_cast<hipEvent_t>(start);

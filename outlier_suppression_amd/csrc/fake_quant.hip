@@ -132,26 +132,56 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_strided_kernel(
 // other stride a multiple of 4, aligned bases): the head-split views of attention -- [B,h,T,d] seen through
 // [B,T,h,d] memory (model/quant_bert.py:128-150) -- read in 256-byte runs and written densely, so that the
 // fake-quant also delivers the contiguous operand the following batched matmul would otherwise copy out.
+struct MagicDiv {                           // n / d for n < 2^31: (n * m) >> k, exact (m = ceil(2^k / d), k = 31 + ceil(log2 d))
+    unsigned int d, m, k;
+};
+__device__ __forceinline__ unsigned int magic_div(unsigned int n, const MagicDiv& v) {
+    return static_cast<unsigned int>((static_cast<unsigned long long>(n) * v.m) >> v.k);
+}
 struct Strided4v {
-    unsigned int size1, size2, size3v;      // sizes of axes 1, 2 and axis 3 in float4 units (axis 0 is implied)
-    int64_t xs[3], ys[3];                   // strides of axes 0..2 in float4 units
+    MagicDiv size1, size2, size3v;          // sizes of axes 1, 2 and axis 3 in float4 units (axis 0 is implied)
+    unsigned int xs[3], ys[3];              // strides of axes 0..2 in float4 units (< 2^32, checked by the launcher)
 };
 
+// One index = three divisions by launch constants: as hardware-emulated 32-bit divisions they were the kernel (15.8 us
+// for a [32,12,128,64] view whose dense form takes 4.4 us: ~100 VALU instructions per float4 on 16-lane SIMDs);
+// multiply-shift by host-made reciprocals takes three instructions each.
+__device__ __forceinline__ void strided4v_offsets(unsigned int i, const Strided4v& d, unsigned long long& xo,
+                                                  unsigned long long& yo) {
+    const unsigned int r2 = magic_div(i, d.size3v), c3 = i - r2 * d.size3v.d;
+    const unsigned int r1 = magic_div(r2, d.size2), c2 = r2 - r1 * d.size2.d;
+    const unsigned int c0 = magic_div(r1, d.size1), c1 = r1 - c0 * d.size1.d;
+    xo = static_cast<unsigned long long>(c0) * d.xs[0] + static_cast<unsigned long long>(c1) * d.xs[1] +
+         static_cast<unsigned long long>(c2) * d.xs[2] + c3;
+    yo = static_cast<unsigned long long>(c0) * d.ys[0] + static_cast<unsigned long long>(c1) * d.ys[1] +
+         static_cast<unsigned long long>(c2) * d.ys[2] + c3;
+}
+
 __global__ __launch_bounds__(kThreads) void fq_tensor_strided_vec_kernel(
-    const float4* __restrict__ x, float4* __restrict__ y, Strided4v d, int64_t n4,
+    const float4* __restrict__ x, float4* __restrict__ y, Strided4v d, unsigned int n4,
     float* scale_p, void* zp_p, int zp_type, int mode, float g,
     float qmin, float qmax) {
     const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
-        const unsigned int iu = static_cast<unsigned int>(i);          // n4 < 2^31 checked by the launcher
-        const unsigned int r2 = iu / d.size3v, c3 = iu - r2 * d.size3v;
-        const unsigned int r1 = r2 / d.size2, c2 = r2 - r1 * d.size2;
-        const unsigned int c0 = r1 / d.size1, c1 = r1 - c0 * d.size1;
-        const float4 v = load_stream(&x[c0 * d.xs[0] + c1 * d.xs[1] + c2 * d.xs[2] + c3]);
+    const unsigned int stride = gridDim.x * kThreads;               // n4 + 2 * stride < 2^32 (launcher)
+    unsigned int i = blockIdx.x * kThreads + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {                      // two independent 16-byte loads in flight
+        unsigned long long xa, ya, xb, yb;
+        strided4v_offsets(i, d, xa, ya);
+        strided4v_offsets(i + stride, d, xb, yb);
+        const float4 va = load_stream(&x[xa]);
+        const float4 vb = load_stream(&x[xb]);
+        float4 oa, ob, q;
+        fq4<false>(va, oa, q, p.scale, p.zp, qmin, qmax);
+        fq4<false>(vb, ob, q, p.scale, p.zp, qmin, qmax);
+        store_stream(&y[ya], oa);
+        store_stream(&y[yb], ob);
+    }
+    if (i < n4) {
+        unsigned long long xa, ya;
+        strided4v_offsets(i, d, xa, ya);
         float4 o, q;
-        fq4<false>(v, o, q, p.scale, p.zp, qmin, qmax);
-        store_stream(&y[c0 * d.ys[0] + c1 * d.ys[1] + c2 * d.ys[2] + c3], o);
+        fq4<false>(load_stream(&x[xa]), o, q, p.scale, p.zp, qmin, qmax);
+        store_stream(&y[ya], o);
     }
 }
 
@@ -425,6 +455,16 @@ __global__ void lsq_sanitize_kernel(float* __restrict__ scale, float* __restrict
 
 bool stream_write_through() { return g_stream_wt != 0; }
 
+static inline MagicDiv make_magic(int64_t d) {       // 1 <= d < 2^31
+    MagicDiv v;
+    unsigned int l = 0;
+    while ((1ull << l) < static_cast<unsigned long long>(d)) ++l;
+    v.d = static_cast<unsigned int>(d);
+    v.k = 31 + l;
+    v.m = static_cast<unsigned int>(((1ull << v.k) + d - 1) / d);   // <= 2^32 - 1 for d >= 2; d == 1: 2^31
+    return v;
+}
+
 static inline int grid_for(int64_t work_items, int per_block, int max_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -527,19 +567,25 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
     OSQ_REQUIRE(x && y, "fake_quant_per_tensor_strided: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
-    const bool vec = !x_quant && x_strides[3] == 1 && y_strides[3] == 1 && sizes[3] % 4 == 0 && aligned16(x) && aligned16(y) &&
-                     n / 4 < (1ll << 31) && sizes[1] < (1ll << 31) && sizes[2] < (1ll << 31) &&
-                     x_strides[0] % 4 == 0 && x_strides[1] % 4 == 0 && x_strides[2] % 4 == 0 &&
-                     y_strides[0] % 4 == 0 && y_strides[1] % 4 == 0 && y_strides[2] % 4 == 0;
+    bool vec = !x_quant && x_strides[3] == 1 && y_strides[3] == 1 && sizes[3] % 4 == 0 && aligned16(x) && aligned16(y) &&
+               n / 4 < (1ll << 30) && sizes[1] < (1ll << 31) && sizes[2] < (1ll << 31);
+    for (int k = 0; k < 3 && vec; ++k)
+        vec = x_strides[k] % 4 == 0 && y_strides[k] % 4 == 0 && x_strides[k] >= 0 && y_strides[k] >= 0 &&
+              x_strides[k] / 4 < (1ll << 32) && y_strides[k] / 4 < (1ll << 32);
     if (vec) {
         Strided4v dv;
-        dv.size1 = static_cast<unsigned int>(sizes[1]);
-        dv.size2 = static_cast<unsigned int>(sizes[2]);
-        dv.size3v = static_cast<unsigned int>(sizes[3] / 4);
-        for (int k = 0; k < 3; ++k) { dv.xs[k] = x_strides[k] / 4; dv.ys[k] = y_strides[k] / 4; }
-        const int vgrid = grid_for(n / 4, kThreads, g_fq_max_blocks);
-        hipLaunchKernelGGL(fq_tensor_strided_vec_kernel, dim3(vgrid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
-                           reinterpret_cast<float4*>(y), dv, n / 4, scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+        dv.size1 = make_magic(sizes[1]);
+        dv.size2 = make_magic(sizes[2]);
+        dv.size3v = make_magic(sizes[3] / 4);
+        for (int k = 0; k < 3; ++k) {
+            dv.xs[k] = static_cast<unsigned int>(x_strides[k] / 4);
+            dv.ys[k] = static_cast<unsigned int>(y_strides[k] / 4);
+        }
+        const int vgrid = grid_for(n / 4, kThreads * 2, g_fq_max_blocks);
+        const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_STRIDED);
+        hipExtLaunchKernelGGL(fq_tensor_strided_vec_kernel, dim3(vgrid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<float4*>(y), dv, static_cast<unsigned int>(n / 4), scale, zero_point, zp_type, mode,
+                           grad_factor, qmin, qmax);
         return check_launch("fake_quant_per_tensor_strided(vec)");
     }
     const int grid = grid_for(n, kThreads, kMaxBlocks);
@@ -570,12 +616,13 @@ extern "C" int osq_fake_quant_per_channel(const float* x, float* y, float* x_qua
         const float4* x4 = reinterpret_cast<const float4*>(x);
         float4* y4 = reinterpret_cast<float4*>(y);
         float4* q4 = reinterpret_cast<float4*>(x_quant);
+        const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_CHANNEL);
         if (x_quant)
-            hipLaunchKernelGGL(fq_channel_rows_kernel<true>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, rows, channels,
-                               static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+            hipExtLaunchKernelGGL(fq_channel_rows_kernel<true>, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, x4, y4, q4, rows,
+                                  channels, static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
         else
-            hipLaunchKernelGGL(fq_channel_rows_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x4, y4, q4, rows, channels,
-                               static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
+            hipExtLaunchKernelGGL(fq_channel_rows_kernel<false>, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, x4, y4, q4, rows,
+                                  channels, static_cast<int>(inner / 4), scale, zero_point, zp_type, mode, grad_factor, qmin, qmax);
     } else {
         const int grid = grid_for(n, kThreads, kMaxBlocks);
         if (x_quant)

@@ -19,6 +19,7 @@
 // reference's torch mean is an fp32 sum whose order depends on the machine's vector width).
 #include <stdlib.h>
 #include <string>
+#include <hip/hip_ext.h>
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -1108,8 +1109,9 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = static_cast<int>((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     const int c = static_cast<int>(cols);
-#define OSQ_ROWS(M) hipLaunchKernelGGL(msefast_rows_kernel<M>, dim3(grid), dim3(kThreads), 0, st, w, rows, c, quant_min, \
-                                       quant_max, symmetric, one_side, two_d, best_min, best_max, nfev)
+    const TimingHook th = take_timing_hook(OSQ_TIME_MSEFAST_ROWS);
+#define OSQ_ROWS(M) hipExtLaunchKernelGGL(msefast_rows_kernel<M>, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, w, rows, c, \
+                                          quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev)
     if (cols <= 64 * 4) OSQ_ROWS(4);
     else if (cols <= 64 * 16) OSQ_ROWS(16);
     else if (cols <= 64 * 48) OSQ_ROWS(48);

@@ -1417,8 +1417,9 @@ extern "C" int osq_observe_channels(const float* x, int64_t outer, int64_t chann
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (outer == 1 && inner % 4 == 0 && aligned16(x) && inner / 4 < (1 << 30)) {
         const int grid = grid_for(channels, kWavesPerBlock, kMaxBlocks * 4);
-        hipLaunchKernelGGL(observe_rows_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
-                           channels, static_cast<int>(inner / 4), fin);
+        const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_CHANNELS);
+        hipExtLaunchKernelGGL(observe_rows_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0,
+                              reinterpret_cast<const float4*>(x), channels, static_cast<int>(inner / 4), fin);
     } else {
         hipLaunchKernelGGL(observe_channels_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads), 0, st, x, outer,
                            channels, inner, fin);
@@ -1466,8 +1467,9 @@ extern "C" int osq_token_minmax_multi(const osq_site_desc* descs, const int64_t*
     if (n_sites == 0 || total_tokens == 0) return OSQ_OK;
     OSQ_REQUIRE(descs && tok_end, "token_minmax_multi: null table");
     const int grid = grid_for(total_tokens, kWavesPerBlock, kMaxBlocks * 8);
-    hipLaunchKernelGGL(token_minmax_multi_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), descs, tok_end,
-                       n_sites, total_tokens);
+    const TimingHook th = take_timing_hook(OSQ_TIME_TOKEN_MINMAX_MULTI);
+    hipExtLaunchKernelGGL(token_minmax_multi_kernel, dim3(grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), th.start, th.stop, 0,
+                          descs, tok_end, n_sites, total_tokens);
     return check_launch("token_minmax_multi");
 }
 

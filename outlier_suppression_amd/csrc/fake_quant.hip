@@ -581,8 +581,8 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
             dv.xs[k] = static_cast<unsigned int>(x_strides[k] / 4);
             dv.ys[k] = static_cast<unsigned int>(y_strides[k] / 4);
         }
-        const int vgrid = grid_for(n / 4, kThreads * 2, g_fq_max_blocks);
         const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_STRIDED);
+        const int vgrid = grid_for(n / 4, kThreads * 2, g_fq_max_blocks);
         hipExtLaunchKernelGGL(fq_tensor_strided_vec_kernel, dim3(vgrid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                            reinterpret_cast<float4*>(y), dv, static_cast<unsigned int>(n / 4), scale, zero_point, zp_type, mode,
                            grad_factor, qmin, qmax);

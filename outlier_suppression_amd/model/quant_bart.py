@@ -22,7 +22,8 @@ import torch
 from torch import nn
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm, activation_fake_quant, residual_layernorm
+from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
+                              residual_layernorm, split_heads_fake_quant)
 
 
 def shift_tokens_right(input_ids, pad_token_id, decoder_start_token_id):
@@ -104,17 +105,15 @@ class QuantizedBartAttention(QuantizedModule):
         if qoutput:
             self.out_proj_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def _shape(self, t, seq_len, bsz):
-        return t.view(bsz, seq_len, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
-
     def forward(self, hidden_states, key_value_states=None, attention_mask=None, observation_mask=None):
         bsz, tgt_len, _ = hidden_states.shape
         source = hidden_states if key_value_states is None else key_value_states
-        q = self.query_post_act_fake_quantize(self.q_proj(hidden_states) * self.scaling, observation_mask, 1)
-        k = self._shape(self.key_post_act_fake_quantize(self.k_proj(source), observation_mask, 1), -1, bsz)
-        v = self._shape(self.value_post_act_fake_quantize(self.v_proj(source), observation_mask, 1), -1, bsz)
+        heads = self.num_heads
+        q = split_heads_fake_quant(self.query_post_act_fake_quantize, self.q_proj(hidden_states) * self.scaling, heads, observation_mask)
+        k = split_heads_fake_quant(self.key_post_act_fake_quantize, self.k_proj(source), heads, observation_mask)
+        v = split_heads_fake_quant(self.value_post_act_fake_quantize, self.v_proj(source), heads, observation_mask)
         proj = (bsz * self.num_heads, -1, self.head_dim)
-        q, k, v = self._shape(q, tgt_len, bsz).view(*proj), k.view(*proj), v.view(*proj)
+        q, k, v = q.view(*proj), k.view(*proj), v.view(*proj)
         src_len = k.shape[1]
         w = torch.bmm(q, k.transpose(1, 2))
         if attention_mask is not None:
@@ -122,8 +121,8 @@ class QuantizedBartAttention(QuantizedModule):
         w = nn.functional.softmax(w, dim=-1)
         probs = nn.functional.dropout(w, p=self.dropout, training=self.training)
         probs = self.attention_probs_post_act_fake_quantize(probs, observation_mask, 2)
-        out = torch.bmm(probs, v).view(bsz, self.num_heads, tgt_len, self.head_dim).transpose(1, 2)
-        out = self.context_post_act_fake_quantize(out.reshape(bsz, tgt_len, self.embed_dim), observation_mask, 1)
+        out = merge_heads_fake_quant(self.context_post_act_fake_quantize,
+                                     torch.bmm(probs, v).view(bsz, self.num_heads, tgt_len, self.head_dim), observation_mask)
         out = self.out_proj(out)
         if self.qoutput:
             out = self.out_proj_post_act_fake_quantize(out, observation_mask, 1)

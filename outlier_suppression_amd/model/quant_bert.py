@@ -21,7 +21,8 @@ from torch import nn
 from ..quant_model_checks import _no_labels
 
 from ..quantization import QuantizedModule, Quantizer
-from ..util_layernorm import GammaResidual, QuantizedLayerNorm, activation_fake_quant, residual_layernorm
+from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
+                              residual_layernorm)
 
 
 class QuantizedBertEmbeddings(QuantizedModule):
@@ -89,11 +90,8 @@ class QuantizedBertSelfAttention(QuantizedModule):
         probs = self.dropout(nn.functional.softmax(scores, dim=-1))
         probs = self.attention_probs_post_act_fake_quantize(probs, observation_mask, 2)
         v = self.value_permute_post_act_fake_quantize(v, observation_mask, 2)
-        ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).contiguous()
-        ctx = ctx.view(ctx.shape[0], ctx.shape[1], self.all_head_size)
-        if self.qoutput:
-            ctx = self.context_view_post_act_fake_quantize(ctx, observation_mask, 1)
-        return ctx
+        return merge_heads_fake_quant(self.context_view_post_act_fake_quantize if self.qoutput else None,
+                                      torch.matmul(probs, v), observation_mask)
 
 
 class _DenseResidualNorm(QuantizedModule):

@@ -153,3 +153,41 @@ def activation_fake_quant(act_fn, quantizer, hidden_states, observation_mask=Non
     if q is not None:
         hidden_states = q(hidden_states, observation_mask, 1)
     return hidden_states
+
+
+def _plain_quantizing(q, x):
+    """The quantizer only fake-quantises (observer off), per tensor, on the device, and nobody wants a gradient: its
+    result depends on the VALUES of x alone, so x may be handed over as any view of its memory."""
+    return (q is not None and not torch.is_grad_enabled() and q.fake_quant_enabled == 1 and q.observer_enabled != 1
+            and q.ch_axis == -1 and x.is_cuda and x.dtype == torch.float32 and x.numel() and q.scale.is_cuda)
+
+
+def merge_heads_fake_quant(quantizer, ctx, observation_mask=None):
+    """``quantizer(ctx.permute(0, 2, 1, 3).contiguous().view(B, T, h*d), observation_mask, 1)`` for ctx [B,h,T,d] -- the
+    context site (quant_bert.py:184-188, quant_bart.py:262-268).  In the plain quantising state the permuted VIEW goes to
+    the strided fake-quant kernel, which writes the merged layout itself: one pass instead of copy + fake-quant, same bits."""
+    b, h, t, d = ctx.shape
+    if _plain_quantizing(quantizer, ctx) and ctx.is_contiguous() and d % 4 == 0:
+        y = quantizer(ctx.permute(0, 2, 1, 3))
+        if y.is_contiguous():
+            return y.view(b, t, h * d)
+    ctx = ctx.permute(0, 2, 1, 3).contiguous().view(b, t, h * d)
+    if quantizer is not None:
+        ctx = quantizer(ctx, observation_mask, 1)
+    return ctx
+
+
+def split_heads_fake_quant(quantizer, x, heads, observation_mask=None):
+    """``quantizer(x, observation_mask, 1).view(B, T, h, d).transpose(1, 2).contiguous()`` for x [B,T,h*d]
+    (quant_bart.py:226-243): in the plain quantising state the head-split view is quantised straight into the
+    [B,h,T,d] layout (one pass, same bits)."""
+    b, t, width = x.shape
+    d = width // heads
+    if _plain_quantizing(quantizer, x) and x.is_contiguous() and d % 4 == 0:
+        y = quantizer(x.view(b, t, heads, d).transpose(1, 2))
+        if y.is_contiguous():
+            return y
+    if quantizer is not None:
+        x = quantizer(x, observation_mask, 1)
+    return x.view(b, t, heads, d).transpose(1, 2).contiguous()
+

@@ -1243,3 +1243,48 @@ def test_batched_rethreshold_with_per_quantizer_lengths(dev):
         ops.token_range_finalize_batched(tmin, tmax, n_q, n_b, B, T, lens_q[:, :2].contiguous(), flags, 0.8, cur)
     with pytest.raises(ValueError):
         ops.token_minmax(torch.randn(B, T, 32, device=dev), 1, lens_q[0, 0], out=(tmin[0, 0, :16], tmax[0, 0, :16]))
+
+
+def test_head_layout_fake_quant_helpers(dev):
+    """merge_heads_fake_quant / split_heads_fake_quant (the context site quant_bert.py:184-188 and BART's head split
+    quant_bart.py:226-243): in the plain quantising state the strided kernel writes the target layout itself; bit-equal
+    to copy + fake-quant, for fixed (int32 zero-point) and learnable (fp32, repaired in the launch) quantizers, head sizes
+    64 / 16 / 12 (the last one not a multiple of 16 bytes per row piece times four: general path) and an odd token count;
+    with the observer on the two-step form runs and the statistics advance."""
+    from types import SimpleNamespace as NS
+    from outlier_suppression_amd.quantization import Quantizer
+    from outlier_suppression_amd.util_layernorm import merge_heads_fake_quant, split_heads_fake_quant
+    gen = torch.Generator().manual_seed(5)
+    for kind in ("FixedFakeQuantize", "LSQPlusFakeQuantize"):
+        for (b, h, t, d) in ((4, 12, 128, 64), (2, 4, 37, 16), (3, 2, 5, 12), (1, 16, 1024, 64)):
+            q = Quantizer(None, NS(quantizer=kind, observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)).to(dev)
+            ctx = (torch.randn(b, h, t, d, generator=gen) * 3).to(dev)
+            lengths = torch.randint(1, t + 1, (b,), generator=gen).to(dev)
+            q.enable_observer(); q.disable_fake_quant()
+            with torch.no_grad():
+                flat = ctx.permute(0, 2, 1, 3).contiguous().view(b, t, h * d)
+                assert merge_heads_fake_quant(q, ctx, lengths).data_ptr() != ctx.data_ptr()
+                cnt = q.observer.cnt
+                q.disable_observer(); q.enable_fake_quant()
+                if kind == "LSQPlusFakeQuantize":
+                    q.scale.data.neg_()                               # the launch repairs it (fake_quant.py:188-191)
+                ref = q(flat.clone(), lengths, 1)
+                scale_after = q.scale.detach().clone()
+                if kind == "LSQPlusFakeQuantize":
+                    q.scale.data.neg_()
+                y = merge_heads_fake_quant(q, ctx, lengths)
+                assert y.shape == (b, t, h * d) and y.is_contiguous() and torch.equal(y, ref)
+                assert torch.equal(q.scale.detach(), scale_after)
+                heads = split_heads_fake_quant(q, flat, h, lengths)
+                assert heads.shape == (b, h, t, d) and heads.is_contiguous()
+                assert torch.equal(heads, ref.view(b, t, h, d).transpose(1, 2))
+                assert q.observer.cnt == cnt
+                q.enable_observer()
+                y2 = merge_heads_fake_quant(q, ctx, lengths)          # both flags on: the general path, statistics advance
+                assert q.observer.cnt == cnt + 1 and y2.shape == (b, t, h * d)
+            # under autograd the two-step form runs and gradients reach the parameters
+            q.disable_observer()
+            if kind == "LSQPlusFakeQuantize":
+                out = merge_heads_fake_quant(q, ctx, lengths)
+                out.sum().backward()
+                assert q.scale.grad is not None

@@ -14,16 +14,25 @@ scale = torch.tensor([0.05], device=dev)
 zp = torch.tensor([31.0], device=dev)
 
 
-def timed(fn, iters=60, warm=8):
-    for _ in range(warm):
+import ctypes
+lib = _hip.load()
+
+
+def timed(fn, which, iters=40, warm=6):
+    """the kernel's own run time: events on its dispatch packet (osq_time_next_launch)"""
+    out = []
+    for i in range(iters + warm):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b))
+        lib.osq_time_next_launch(which, a, b)
         fn()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    torch.cuda.synchronize()
-    for a, b in ev:
-        a.record(); fn(); b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
-    return ts[len(ts) // 2], ts[0]
+        us = ctypes.c_float()
+        lib.osq_timing_elapsed_us(a, b, ctypes.byref(us))
+        lib.osq_timing_events_destroy(a, b)
+        if i >= warm:
+            out.append(us.value)
+    out.sort()
+    return out[len(out) // 2], out[0]
 
 
 for B, T, h, d in ((32, 128, 12, 64), (32, 384, 12, 64), (4, 1024, 16, 64), (256, 128, 12, 64)):
@@ -41,6 +50,8 @@ for B, T, h, d in ((32, 128, 12, 64), (32, 384, 12, 64), (4, 1024, 16, 64), (256
     y1 = ops.fake_quant_per_tensor(mems[0].view(B, T, h, d).permute(0, 2, 1, 3), scale, zp, 0, 63, ops.PARAM_LSQPLUS, 0.01)
     y2 = ops.fake_quant_per_tensor(mems[0].view(B, T, h, d).permute(0, 2, 3, 1), scale, zp, 0, 63, ops.PARAM_LSQPLUS, 0.01)
     ok = torch.equal(y1, ref.permute(0, 2, 1, 3)) and torch.equal(y2, ref.permute(0, 2, 3, 1)) and y1.is_contiguous()
-    for name, fn in (("dense", dense), ("q/v view", qv), ("key view", key)):
-        med, mn = timed(fn)
-        print(f"[{B},{T},{h},{d}] {name:9s}: median {med:7.2f} us  min {mn:7.2f} us -> {nbytes / med / 1e3:7.0f} GB/s   bit-equal {ok}", flush=True)
+    rows = [("dense", dense, _hip.TIME_FAKE_QUANT, None)]
+    rows += [("q/v view", qv, _hip.TIME_FAKE_QUANT_STRIDED, None), ("key view", key, _hip.TIME_FAKE_QUANT_STRIDED, None)]
+    for name, fn, which, knob in rows:
+        med, mn = timed(fn, which)
+        print(f"[{B},{T},{h},{d}] {name:32s}: median {med:7.2f} us  min {mn:7.2f} us -> {nbytes / med / 1e3:7.0f} GB/s   bit-equal {ok}", flush=True)

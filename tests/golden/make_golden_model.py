@@ -83,8 +83,8 @@ def quantizer_table(model, QuantizeBase):
     return names, scales, zps
 
 
-def main():
-    QB, GM, TWC, ST, QuantizeBase = import_reference()
+def tiny_bert_cls():
+    """The seeded tiny BERT classifier and its calibration batches (shared by main and main_plain)."""
     from transformers import BertConfig, BertForSequenceClassification
     torch.set_num_threads(1)
     torch.manual_seed(20240929)
@@ -119,6 +119,12 @@ def main():
 
     with torch.no_grad():
         out["logits_hf_fp"] = np.stack([fp(**b).logits.numpy() for b in batches])
+    return fp, batches, out
+
+
+def main():
+    QB, GM, TWC, ST, QuantizeBase = import_reference()
+    fp, batches, out = tiny_bert_cls()
 
     a_q = Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
@@ -442,9 +448,54 @@ def main_variant(kind):
           "full:", np.abs(out["logits_full_quant"] - out["logits_wrapped_fp"]).max())
 
 
+def main_plain():
+    """The plain calibration flows (ptq_glue_quant.py:234-246, the `else` branch: weight calibration on the first batch,
+    activation calibration over all batches, enable_quantization) for the `quant:` sections the reference ships besides
+    twc_fine_gamma -- exp/bert_ptq/{minmax,mse,quantile}/cola/config.yaml -- and for BASELINE configs[3] (4-bit per-channel
+    MSEFast weights, 6-bit AvgMSEFast activations), on the tiny classifier of main() (same seeds: weights and batches are the
+    ones bert_tiny_pipeline.npz already holds).  Stores what the reference produced: every quantizer's scale / zero_point and
+    observer statistics after calibration, and the fully quantized logits."""
+    QB, GM, TWC, ST, QuantizeBase = import_reference()
+    fp, batches, base = tiny_bert_cls()
+    out = {"input_ids": base["input_ids"], "attention_mask": base["attention_mask"], "logits_hf_fp": base["logits_hf_fp"]}
+    w6 = Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+
+    def act(observer):
+        return Cfg(quantizer="FixedFakeQuantize", observer=observer, bit=6, symmetric=False, ch_axis=-1)
+    variants = {"minmax": (act("AvgMinMaxObserver"), w6), "mse": (act("AvgMSEFastObserver"), w6),
+                "quantile": (act("AvgQuantileObserver"), w6),
+                "w4a6_msefast": (act("AvgMSEFastObserver"),
+                                 Cfg(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0))}
+    out["variants"] = np.array(list(variants))
+    for name, (a_q, w_q) in variants.items():
+        model = QB.QuantizedBertForSequenceClassification(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
+                                                          is_remove_padding=True).eval()
+        with torch.no_grad():
+            ST.enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+            model(**batches[0])
+            ST.enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
+            for b in batches:
+                model(**b)
+            names, scales, zps = quantizer_table(model, QuantizeBase)
+            out[f"{name}::q_names"] = np.array(names)
+            for i, (s_, z_) in enumerate(zip(scales, zps)):
+                out[f"{name}::scale::{i}"], out[f"{name}::zp::{i}"] = s_, z_
+            for i, (n, m) in enumerate((n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase)):
+                out[f"{name}::min::{i}"] = m.observer.min_val.detach().reshape(-1).to(torch.float64).numpy()
+                out[f"{name}::max::{i}"] = m.observer.max_val.detach().reshape(-1).to(torch.float64).numpy()
+            ST.enable_quantization(model)
+            out[f"{name}::logits_full_quant"] = np.stack([model(**b)[0].numpy() for b in batches])
+        print(name, len(names), "quantizers; logit drift", np.abs(out[f"{name}::logits_full_quant"] - base["logits_hf_fp"]).max())
+    path = os.path.join(OUT, "bert_tiny_plain_ptq.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bart":
         main_bart()
+    elif len(sys.argv) > 1 and sys.argv[1] == "plain":
+        main_plain()
     elif len(sys.argv) > 1 and sys.argv[1] in ("bert-qa", "roberta-cls"):
         main_variant(sys.argv[1])
     else:

@@ -160,3 +160,25 @@ def test_msefast_equals_reference_when_the_loss_is_summed_like_torch(ref):
                 assert float(st.min_val) == float(ob.min_val) and float(st.max_val) == float(ob.max_val), (sym, shape, it)
     finally:
         OB.MEAN_LIKE_TORCH = old
+
+
+def test_shipped_quant_sections_equal_the_reference_yaml():
+    """ptq.SHIPPED_QUANT_SECTIONS against the `quant:` section of every config.yaml under the reference's exp/ (15 files,
+    four distinct sections): same keys and values."""
+    import glob
+    import yaml
+    from outlier_suppression_amd import ptq
+    files = sorted(glob.glob(os.path.join(REF, "exp", "**", "config.yaml"), recursive=True))
+    assert len(files) >= 15
+
+    def plain(ns):
+        return {k: (plain(v) if hasattr(v, "__dict__") else v) for k, v in vars(ns).items()}
+    seen = set()
+    for f in files:
+        quant = yaml.safe_load(open(f))["quant"]
+        kind = os.path.relpath(f, os.path.join(REF, "exp")).split(os.sep)[1]
+        assert kind in ptq.SHIPPED_QUANT_SECTIONS, f
+        assert plain(ptq.SHIPPED_QUANT_SECTIONS[kind]) == quant, f
+        assert plain(ptq.namespace(quant)) == quant
+        seen.add(kind)
+    assert seen == set(ptq.SHIPPED_QUANT_SECTIONS)

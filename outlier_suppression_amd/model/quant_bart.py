@@ -21,6 +21,7 @@ as in the reference driver (ptq_summ_quant.py:137-153).
 import torch
 from torch import nn
 
+from ..quant_model_checks import _no_labels
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
                               residual_layernorm, split_heads_fake_quant)
@@ -315,3 +316,85 @@ class QuantizedBartForConditionalGeneration(QuantizedModule):
         dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
                               observation_mask=obs, decoder_observation_mask=dec_obs)
         return (self.lm_head(dec) + self.final_logits_bias, enc)
+
+
+class QuantizedBartClassificationHead(QuantizedModule):
+    """quant_bart.py:505-529: the sentence representation, the tanh layer's output (and the logits) are quantizer sites;
+    flat [B, H] tensors -- no mask, no sequence axis."""
+
+    def __init__(self, org_module, w_qconfig, a_qconfig, qoutput=True, backend="academic"):
+        super().__init__(backend)
+        self.qoutput = qoutput
+        self.getitem_post_act_fake_quantize = Quantizer(None, a_qconfig)
+        self.dense = Quantizer(org_module.dense, w_qconfig)
+        self.dropout = org_module.dropout
+        self.dropout_post_act_fake_quantize = Quantizer(None, a_qconfig)
+        self.out_proj = Quantizer(org_module.out_proj, w_qconfig)
+        if qoutput:
+            self.out_proj_post_act_fake_quantize = Quantizer(None, a_qconfig)
+
+    def forward(self, hidden_states):
+        hidden_states = self.getitem_post_act_fake_quantize(self.dropout(hidden_states))
+        hidden_states = self.dropout(torch.tanh(self.dense(hidden_states)))
+        hidden_states = self.out_proj(self.dropout_post_act_fake_quantize(hidden_states))
+        if self.qoutput:
+            hidden_states = self.out_proj_post_act_fake_quantize(hidden_states)
+        return hidden_states
+
+
+def _observation_masks(is_remove_padding, attention_mask, decoder_attention_mask):
+    """quant_bart.py:1064-1072 / 1205-1213 / 1334-1342."""
+    if not is_remove_padding:
+        return None, None
+    obs = attention_mask.sum(1)
+    return obs, (obs if decoder_attention_mask is None else decoder_attention_mask.sum(1))
+
+
+class QuantizedBartForSequenceClassification(QuantizedModule):
+    """quant_bart.py:1167-1289: the decoder state at the last <eos> token through the quantized classification head."""
+
+    def __init__(self, org_module, w_qconfig, a_qconfig, qoutput=True, backend="academic", is_remove_padding=False):
+        super().__init__(backend)
+        self.is_remove_padding = is_remove_padding
+        self.qoutput = qoutput
+        self.config = org_module.config
+        self.model = QuantizedBartModel(org_module.model, w_qconfig, a_qconfig, qoutput=False, backend=backend)
+        self.classification_head = QuantizedBartClassificationHead(org_module.classification_head, w_qconfig, a_qconfig,
+                                                                   qoutput=qoutput, backend=backend)
+
+    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, **unused):
+        _no_labels(unused)
+        obs, dec_obs = _observation_masks(self.is_remove_padding, attention_mask, decoder_attention_mask)
+        dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
+                              observation_mask=obs, decoder_observation_mask=dec_obs)
+        eos_mask = input_ids.eq(self.config.eos_token_id)
+        if len(torch.unique_consecutive(eos_mask.sum(1))) > 1:
+            raise ValueError("All examples must have the same number of <eos> tokens.")
+        sentence = dec[eos_mask, :].view(dec.size(0), -1, dec.size(-1))[:, -1, :]
+        return (self.classification_head(sentence), enc)
+
+
+class QuantizedBartForQuestionAnswering(QuantizedModule):
+    """quant_bart.py:1292-1408: start / end logits from the (quantized) decoder output."""
+
+    def __init__(self, org_module, w_qconfig, a_qconfig, qoutput=True, backend="academic", is_remove_padding=False):
+        super().__init__(backend)
+        self.is_remove_padding = is_remove_padding
+        self.qoutput = qoutput
+        self.num_labels = org_module.num_labels
+        self.config = org_module.config
+        self.model = QuantizedBartModel(org_module.model, w_qconfig, a_qconfig, qoutput=True, backend=backend)
+        self.qa_outputs = Quantizer(org_module.qa_outputs, w_qconfig)
+        if qoutput:
+            self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
+
+    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, **unused):
+        _no_labels(unused)
+        obs, dec_obs = _observation_masks(self.is_remove_padding, attention_mask, decoder_attention_mask)
+        dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
+                              observation_mask=obs, decoder_observation_mask=dec_obs)
+        logits = self.qa_outputs(dec)
+        if self.qoutput:
+            logits = self.qa_outputs_post_act_fake_quantize(logits)
+        start, end = logits.split(1, dim=-1)
+        return start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous(), enc

@@ -192,3 +192,37 @@ def test_token_view_matches_reference_permutation():
     # BART quirk: [B*h, T, S] with a length-B mask only covers the first B rows (observer.py:82)
     v = ops.token_view(torch.zeros(8, 5, 5), 1, n_lengths=2)
     assert v.batch == 2
+
+
+def test_quantize_model_takes_the_reference_config_form():
+    """quant_model.quantize_model(fp_model, config) -- the reference's call (solver/quant_model.py:31-50) with a parsed
+    config (nested dicts as yaml.safe_load gives them, or attribute namespaces): defaults filled in, model_type / task_type
+    written back, same wrapper as the explicit form."""
+    from types import SimpleNamespace as NS
+    import transformers as T
+    from outlier_suppression_amd.quant_model import quantize_model, get_model_task_type
+    from outlier_suppression_amd.model.quant_bert import QuantizedBertForQuestionAnswering
+    from outlier_suppression_amd.quantization.fake_quant import LSQPlusFakeQuantize, FixedFakeQuantize
+    cfg = T.BertConfig(vocab_size=50, hidden_size=16, num_hidden_layers=1, num_attention_heads=2, intermediate_size=32,
+                       max_position_embeddings=20)
+    fp = T.BertForQuestionAnswering(cfg)
+    a_q = dict(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = dict(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    config = {"quant": {"a_qconfig": a_q, "w_qconfig": w_q, "calibrate": 256}, "model": {},
+              "data": NS(dataset_name="squad_v2")}
+    model = quantize_model(fp, config)
+    assert isinstance(model, QuantizedBertForQuestionAnswering) and model.is_remove_padding is True
+    assert config["model"] == {"model_type": "bert", "task_type": "squad_v2"}
+    assert config["quant"]["backend"] == "academic" and config["quant"]["ln"]["delay"] is False
+    acts = [m for n, m in model.named_modules() if n.endswith("post_act_fake_quantize")]
+    weights = [m for n, m in model.named_modules() if n.endswith("weight_fake_quant")]
+    assert acts and all(isinstance(m, LSQPlusFakeQuantize) and m.bit == 6 for m in acts)
+    assert weights and all(isinstance(m, FixedFakeQuantize) and m.ch_axis == 0 for m in weights)
+    ns = NS(quant=NS(a_qconfig=NS(**a_q), w_qconfig=NS(**w_q), ln=NS(delay=True)), model=NS(), data=NS(dataset_name="squad"))
+    model2 = quantize_model(fp, ns)
+    assert [n for n, _ in model2.named_modules()] == [n for n, _ in model.named_modules()]
+    assert ns.model.task_type == "squad" and ns.quant.ln.delay is True
+    assert get_model_task_type("robertaforsequenceclassification", NS(dataset_name="mnli")) == ("glue", "roberta")
+    assert get_model_task_type("bartforconditionalgeneration", NS(dataset_name="xsum")) == ("summ", "bart")
+    with pytest.raises(NotImplementedError):
+        get_model_task_type("bertforsequenceclassification", NS(dataset_name="imdb"))

@@ -82,7 +82,8 @@ def test_same_tree_names_and_fp_logits(ref, case):
         assert torch.equal(a, b)
 
 
-def test_bart_same_tree_names_and_fp_logits(ref):
+@pytest.mark.parametrize("task", ["summ", "cls", "qa"])
+def test_bart_same_tree_names_and_fp_logits(ref, task):
     M, QB, RQ, RefQuantizeBase = ref
     import transformers as T
     from torch import nn
@@ -98,7 +99,11 @@ def test_bart_same_tree_names_and_fp_logits(ref):
                        decoder_attention_heads=2, encoder_ffn_dim=64, decoder_ffn_dim=64, max_position_embeddings=40,
                        dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, pad_token_id=1, bos_token_id=0,
                        eos_token_id=2, decoder_start_token_id=2)
-    fp = T.BartForConditionalGeneration(cfg).eval()
+    hf_cls, name, n_head = {"summ": (T.BartForConditionalGeneration, "QuantizedBartForConditionalGeneration", 1),
+                            "cls": (T.BartForSequenceClassification, "QuantizedBartForSequenceClassification", 4),
+                            "qa": (T.BartForQuestionAnswering, "QuantizedBartForQuestionAnswering", 1)}[task]
+    cfg.num_labels = 3 if task == "cls" else 2
+    fp = hf_cls(cfg).eval()
 
     def plain(e):      # the 4.18-era layout the reference wrappers expect: plain nn.Embedding + embed_scale on the stack
         p = nn.Embedding(e.num_embeddings, e.embedding_dim, padding_idx=e.padding_idx)
@@ -113,13 +118,12 @@ def test_bart_same_tree_names_and_fp_logits(ref):
     fp.model.decoder.max_target_positions = 40
     a_q = M.Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = M.Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    theirs = RB.QuantizedBartForConditionalGeneration(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
-                                                      is_remove_padding=True).eval()
-    ours = OB.QuantizedBartForConditionalGeneration(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic",
-                                                    is_remove_padding=True).eval()
+    theirs = getattr(RB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
+    ours = getattr(OB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
     ref_q = [n for n, m in theirs.named_modules() if isinstance(m, RefQuantizeBase)]
     our_q = [n for n, m in ours.named_modules() if isinstance(m, QuantizeBase)]
-    assert our_q == ref_q and len(our_q) == 2 * 8 + 2 * 14 + 2 + 2 * 6 + 2 * 10 + 3 + 2 + 1
+    body_q = 2 * 8 + 2 * 14 + 2 + 2 * 6 + 2 * 10 + 3 + 2
+    assert our_q == ref_q and len(our_q) in (body_q + n_head, body_q + n_head - 1), len(our_q)
     assert [n for n, _ in ours.named_modules()] == [n for n, _ in theirs.named_modules()]
     ids = torch.randint(3, 100, (3, 12))
     L = torch.tensor([12, 7, 4])
@@ -129,8 +133,17 @@ def test_bart_same_tree_names_and_fp_logits(ref):
     DL = torch.tensor([6, 3, 5])
     dmask = (torch.arange(6)[None] < DL[:, None]).long()
     dids = dids * dmask + (1 - dmask)
+    if task == "cls":      # the head reads the decoder state at the last <eos>; the decoder input is the shifted source
+        ids[torch.arange(3), L - 1] = cfg.eos_token_id
+        kw = dict(input_ids=ids, attention_mask=mask)
+    else:
+        kw = dict(input_ids=ids, attention_mask=mask, decoder_input_ids=dids, decoder_attention_mask=dmask)
     with torch.no_grad():
-        r = theirs(input_ids=ids, attention_mask=mask, decoder_input_ids=dids, decoder_attention_mask=dmask,
-                   use_cache=False, return_dict=False)
-        o = ours(input_ids=ids, attention_mask=mask, decoder_input_ids=dids, decoder_attention_mask=dmask)
+        r = theirs(use_cache=False, return_dict=False, **kw)
+        o = ours(**kw)
     assert torch.equal(r[0], o[0])
+    if task == "qa":
+        assert torch.equal(r[1], o[1])
+    if task != "summ":     # logits only: a loss request is refused, not silently dropped (quant_model_checks.py)
+        with pytest.raises(NotImplementedError):
+            ours(labels=torch.zeros(3, dtype=torch.long), **kw)

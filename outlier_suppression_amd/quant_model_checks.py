@@ -1,7 +1,6 @@
 """What this package's own task-model wrappers do NOT do, said loudly.
 
-The reference's task models return HF ``ModelOutput``s with a loss when ``labels`` are given and build extra
-``output_post_act_fake_quantize`` sites for ``backend='tensorrt'`` (model/quant_bert.py).  The wrappers here exist for
+The reference's task models return HF ``ModelOutput``s with a loss when ``labels`` are given.  The wrappers here exist for
 calibration and quantised inference of the hot path: they return plain tuples of logits.  A training / evaluation loop
 that passes ``labels`` would otherwise read the first logits tensor as its loss -- refuse instead."""
 
@@ -14,8 +13,8 @@ def _no_labels(kwargs):
 
 
 def require_academic(backend):
-    if backend != "academic":
-        raise NotImplementedError(
-            f"backend={backend!r}: only the 'academic' quantizer placement is built by this package's model classes; the "
-            "reference's model files (which add output_post_act_fake_quantize sites for 'tensorrt') run on this package "
-            "through the sys.modules shim (INTEGRATION.md section 1)")
+    """'academic' and 'tensorrt' (the reference's extra residual-branch sites, quant_bert.py:204-216, quant_bart.py:305-307,
+    401-404) are the placements the reference's model files know; anything else is refused rather than silently treated
+    as 'academic'."""
+    if backend not in ("academic", "tensorrt"):
+        raise NotImplementedError(f"backend={backend!r}: the quantizer placements are 'academic' and 'tensorrt'")

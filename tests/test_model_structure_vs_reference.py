@@ -42,8 +42,9 @@ def _patch(model, attr):
 CASES = ["bert-cls", "bert-qa", "roberta-cls", "roberta-qa"]
 
 
+@pytest.mark.parametrize("backend", ["academic", "tensorrt"])
 @pytest.mark.parametrize("case", CASES)
-def test_same_tree_names_and_fp_logits(ref, case):
+def test_same_tree_names_and_fp_logits(ref, case, backend):
     M, QB, RQ, RefQuantizeBase = ref
     import transformers as T
     from outlier_suppression_amd.model import quant_bert as OB, quant_roberta as OR
@@ -65,8 +66,10 @@ def test_same_tree_names_and_fp_logits(ref, case):
     fp = _patch(hf_cls(cfg).eval(), attr)
     a_q = M.Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = M.Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    theirs = ref_cls(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
-    ours = our_cls(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
+    theirs = ref_cls(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend=backend, is_remove_padding=True).eval()
+    ours = our_cls(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend=backend, is_remove_padding=True).eval()
+    if backend == "tensorrt":       # two more sites per layer: the residual branches (quant_bert.py:204-216, 291-303)
+        n_quant += 2 * cfg.num_hidden_layers
     ref_q = [n for n, m in theirs.named_modules() if isinstance(m, RefQuantizeBase)]
     our_q = [n for n, m in ours.named_modules() if isinstance(m, QuantizeBase)]
     assert len(our_q) == n_quant and our_q == ref_q
@@ -82,8 +85,9 @@ def test_same_tree_names_and_fp_logits(ref, case):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("backend", ["academic", "tensorrt"])
 @pytest.mark.parametrize("task", ["summ", "cls", "qa"])
-def test_bart_same_tree_names_and_fp_logits(ref, task):
+def test_bart_same_tree_names_and_fp_logits(ref, task, backend):
     M, QB, RQ, RefQuantizeBase = ref
     import transformers as T
     from torch import nn
@@ -118,11 +122,11 @@ def test_bart_same_tree_names_and_fp_logits(ref, task):
     fp.model.decoder.max_target_positions = 40
     a_q = M.Cfg(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = M.Cfg(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    theirs = getattr(RB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
-    ours = getattr(OB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend="academic", is_remove_padding=True).eval()
+    theirs = getattr(RB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend=backend, is_remove_padding=True).eval()
+    ours = getattr(OB, name)(copy.deepcopy(fp), w_q, a_q, qoutput=False, backend=backend, is_remove_padding=True).eval()
     ref_q = [n for n, m in theirs.named_modules() if isinstance(m, RefQuantizeBase)]
     our_q = [n for n, m in ours.named_modules() if isinstance(m, QuantizeBase)]
-    body_q = 2 * 8 + 2 * 14 + 2 + 2 * 6 + 2 * 10 + 3 + 2
+    body_q = 2 * 8 + 2 * 14 + 2 + 2 * 6 + 2 * 10 + 3 + 2 + (2 * 2 + 2 * 3 if backend == "tensorrt" else 0)
     assert our_q == ref_q and len(our_q) in (body_q + n_head, body_q + n_head - 1), len(our_q)
     assert [n for n, _ in ours.named_modules()] == [n for n, _ in theirs.named_modules()]
     ids = torch.randint(3, 100, (3, 12))

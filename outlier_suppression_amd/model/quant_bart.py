@@ -21,7 +21,7 @@ as in the reference driver (ptq_summ_quant.py:137-153).
 import torch
 from torch import nn
 
-from ..quant_model_checks import _no_labels
+from ..quant_model_checks import classification_loss, lm_loss, span_loss, with_loss
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
                               residual_layernorm, split_heads_fake_quant)
@@ -331,7 +331,8 @@ class QuantizedBartForConditionalGeneration(QuantizedModule):
             decoder_input_ids = shift_tokens_right(labels, self.config.pad_token_id, self.config.decoder_start_token_id)
         dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
                               observation_mask=obs, decoder_observation_mask=dec_obs)
-        return (self.lm_head(dec) + self.final_logits_bias, enc)
+        logits = self.lm_head(dec) + self.final_logits_bias
+        return with_loss(lm_loss(logits, labels, self.config.vocab_size), (logits, enc))
 
 
 class QuantizedBartClassificationHead(QuantizedModule):
@@ -378,8 +379,8 @@ class QuantizedBartForSequenceClassification(QuantizedModule):
         self.classification_head = QuantizedBartClassificationHead(org_module.classification_head, w_qconfig, a_qconfig,
                                                                    qoutput=qoutput, backend=backend)
 
-    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, labels=None,
+                **unused):
         obs, dec_obs = _observation_masks(self.is_remove_padding, attention_mask, decoder_attention_mask)
         dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
                               observation_mask=obs, decoder_observation_mask=dec_obs)
@@ -387,7 +388,8 @@ class QuantizedBartForSequenceClassification(QuantizedModule):
         if len(torch.unique_consecutive(eos_mask.sum(1))) > 1:
             raise ValueError("All examples must have the same number of <eos> tokens.")
         sentence = dec[eos_mask, :].view(dec.size(0), -1, dec.size(-1))[:, -1, :]
-        return (self.classification_head(sentence), enc)
+        logits = self.classification_head(sentence)
+        return with_loss(classification_loss(self.config, self.config.num_labels, logits, labels), (logits, enc))
 
 
 class QuantizedBartForQuestionAnswering(QuantizedModule):
@@ -404,8 +406,8 @@ class QuantizedBartForQuestionAnswering(QuantizedModule):
         if qoutput:
             self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None,
+                start_positions=None, end_positions=None, **unused):
         obs, dec_obs = _observation_masks(self.is_remove_padding, attention_mask, decoder_attention_mask)
         dec, enc = self.model(input_ids, attention_mask, decoder_input_ids, decoder_attention_mask,
                               observation_mask=obs, decoder_observation_mask=dec_obs)
@@ -413,4 +415,5 @@ class QuantizedBartForQuestionAnswering(QuantizedModule):
         if self.qoutput:
             logits = self.qa_outputs_post_act_fake_quantize(logits)
         start, end = logits.split(1, dim=-1)
-        return start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous(), enc
+        start, end = start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous()
+        return with_loss(span_loss(start, end, start_positions, end_positions), (start, end, enc))

@@ -18,7 +18,7 @@ import math
 import torch
 from torch import nn
 
-from ..quant_model_checks import _no_labels
+from ..quant_model_checks import classification_loss, span_loss, with_loss
 
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
@@ -239,14 +239,13 @@ class QuantizedBertForSequenceClassification(QuantizedModule):
         if qoutput:
             self.classifier_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, labels=None, **unused):
         obs = _observation_mask(attention_mask, self.is_remove_padding)
         _, pooled = self.bert(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.classifier(self.dropout_post_act_fake_quantize(self.dropout(pooled)))
         if self.qoutput:
             logits = self.classifier_post_act_fake_quantize(logits)
-        return (logits,)
+        return with_loss(classification_loss(self.config, self.num_labels, logits, labels), (logits,))
 
 
 class QuantizedBertForQuestionAnswering(QuantizedModule):
@@ -261,12 +260,13 @@ class QuantizedBertForQuestionAnswering(QuantizedModule):
         if qoutput:
             self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, start_positions=None,
+                end_positions=None, **unused):
         obs = _observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.bert(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.qa_outputs(seq)
         if self.qoutput:
             logits = self.qa_outputs_post_act_fake_quantize(logits)
         start, end = logits.split(1, dim=-1)
-        return start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous()
+        start, end = start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous()
+        return with_loss(span_loss(start, end, start_positions, end_positions), (start, end))

@@ -10,7 +10,7 @@ Sub-module names follow the reference (``roberta.*``, ``classifier.dense`` ...),
 """
 import torch
 
-from ..quant_model_checks import _no_labels
+from ..quant_model_checks import classification_loss, span_loss, with_loss
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import QuantizedLayerNorm
 from . import quant_bert as B
@@ -163,11 +163,11 @@ class QuantizedRobertaForSequenceClassification(QuantizedModule):
         self.classifier = QuantizedRobertaClassificationHead(org_module.classifier, w_qconfig, a_qconfig, qoutput=qoutput,
                                                              backend=backend)
 
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, labels=None, **unused):
         obs = B._observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.roberta(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
-        return (self.classifier(seq),)
+        logits = self.classifier(seq)
+        return with_loss(classification_loss(self.config, self.num_labels, logits, labels), (logits,))
 
 
 class QuantizedRobertaForQuestionAnswering(QuantizedModule):
@@ -182,12 +182,13 @@ class QuantizedRobertaForQuestionAnswering(QuantizedModule):
         if qoutput:
             self.qa_outputs_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
-    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, **unused):
-        _no_labels(unused)
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, start_positions=None,
+                end_positions=None, **unused):
         obs = B._observation_mask(attention_mask, self.is_remove_padding)
         seq, _ = self.roberta(input_ids, attention_mask, token_type_ids, position_ids, observation_mask=obs)
         logits = self.qa_outputs(seq)
         if self.qoutput:
             logits = self.qa_outputs_post_act_fake_quantize(logits)
         start, end = logits.split(1, dim=-1)
-        return start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous()
+        start, end = start.squeeze(-1).contiguous(), end.squeeze(-1).contiguous()
+        return with_loss(span_loss(start, end, start_positions, end_positions), (start, end))

@@ -83,6 +83,15 @@ def test_same_tree_names_and_fp_logits(ref, case, backend):
         o = ours(input_ids=ids, attention_mask=mask)
     for a, b in zip(r[:len(o)], o):
         assert torch.equal(a, b)
+    # with labels the tuple starts with the loss, computed as the reference does (quant_model_checks.py)
+    if case.endswith("qa"):
+        lab = dict(start_positions=torch.tensor([1, 0, 30]), end_positions=torch.tensor([[3], [2], [5]]))
+    else:
+        lab = dict(labels=torch.randint(0, cfg.num_labels, (3,)))
+    with torch.no_grad():
+        rl = theirs(input_ids=ids, attention_mask=mask, return_dict=False, **lab)
+        ol = ours(input_ids=ids, attention_mask=mask, **lab)
+    assert rl[0].dim() == 0 and torch.equal(rl[0], ol[0]) and torch.equal(rl[1], ol[1])
 
 
 @pytest.mark.parametrize("backend", ["academic", "tensorrt"])
@@ -148,6 +157,14 @@ def test_bart_same_tree_names_and_fp_logits(ref, task, backend):
     assert torch.equal(r[0], o[0])
     if task == "qa":
         assert torch.equal(r[1], o[1])
-    if task != "summ":     # logits only: a loss request is refused, not silently dropped (quant_model_checks.py)
-        with pytest.raises(NotImplementedError):
-            ours(labels=torch.zeros(3, dtype=torch.long), **kw)
+    # with labels the tuple starts with the loss, computed as the reference does (quant_model_checks.py)
+    if task == "summ":
+        lab = dict(labels=torch.randint(3, 100, (3, 6)))
+    elif task == "cls":
+        lab = dict(labels=torch.tensor([0, 2, 1]))
+    else:
+        lab = dict(start_positions=torch.tensor([1, 0, 9]), end_positions=torch.tensor([3, 2, 40]))
+    with torch.no_grad():
+        rl = theirs(use_cache=False, return_dict=False, **kw, **lab)
+        ol = ours(**kw, **lab)
+    assert rl[0].dim() == 0 and torch.equal(rl[0], ol[0]) and torch.equal(rl[1], ol[1])

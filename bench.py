@@ -338,7 +338,7 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         if world > 1:
             dist.barrier()
 
-    def run(search):
+    def run(search, strict_learn=False):
         nonlocal model
         model = quantize_model(fp, w_q, a_q).to(dev)      # deep copy of the FP model, as quant_model.py:44-48: fp stays pristine
         phases = {}
@@ -371,7 +371,7 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
             ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
         sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
         # N > 1: every Adam step is split inside the batch (32/N samples per rank, averaged gradients)
-        TWC.learn_scale_sharded(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
+        (TWC.learn_scale if strict_learn else TWC.learn_scale_sharded)(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
         sync(); phases["learn_scale"] = time.perf_counter() - t0
         return time.perf_counter() - t_start, phases, ratio
 
@@ -390,6 +390,11 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
                            f"sequential Adam, every step data-parallel inside the batch ({B // world} samples per rank, "
                            "one all-reduce of the 196 gradients per step)" if B % world == 0 else "replicated on every rank"),
            "n_gpus": world}
+    if world > 1:
+        # bit-for-bit parity with the sequential reference needs learn-scale replicated on every rank; the line
+        # above ran the rounding-close data-parallel variant, this is the strict one on the same warm process
+        strict_wall, strict_phases, _ = run(search, strict_learn=True)
+        out["strict_replicated_learn_scale"] = {"wall_s": round(strict_wall, 3), "learn_scale_s": round(strict_phases["learn_scale"], 3)}
     return out
 
 
@@ -842,9 +847,11 @@ def main():
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         _hip.check(lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b)), "timing_events_create")
         pairs.append((a, b))
+    fused_on = os.environ.get("OSQ_FUSED_STEP", "1") != "0"      # off: ranks sharing one GPU (test hook) run three launches
+    probe_family = _hip.TIME_FUSED_STEP if fused_on else _hip.TIME_FAKE_QUANT
     with torch.no_grad():
         for i in range(n_probe):
-            lib.osq_time_next_launch(_hip.TIME_FUSED_STEP, *pairs[i])
+            lib.osq_time_next_launch(probe_family, *pairs[i])
             q(xs[i % len(xs)], lengths, 1)
     torch.cuda.synchronize()
     k_ms = []
@@ -855,14 +862,15 @@ def main():
         lib.osq_timing_events_destroy(a, b)
     k_ms.sort()
     k_avg_ms = sum(k_ms) / len(k_ms)
-    achieved = bytes_step / (k_avg_ms * 1e-3) / 1e9
+    probe_bytes = bytes_step if fused_on else 8 * n_elem
+    achieved = probe_bytes / (k_avg_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
             table_j = json.load(open(tpath))      # PMC passes of tools/collect_profiles.sh, committed under profiles/
             traffic = next((v.get("hbm_bytes_per_launch") for k, v in table_j.items()
-                            if k.startswith("observe_fq_fused_kernel") and isinstance(v, dict)), None)
+                            if k.startswith("observe_fq_fused_kernel" if fused_on else "fq_tensor_vec_kernel") and isinstance(v, dict)), None)
             traffic_source = "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
         except Exception:
             traffic = None
@@ -898,7 +906,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BERT-base activation [256,128,768] fp32, AvgPruneMinMaxObserver(p=0.95, lengths randint(8,129)) "
                                "-> running average -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]; configs[1] site shape",
-                   "launches_per_step": 1, "buffers_cycled": len(xs),
+                   "launches_per_step": 1 if fused_on else 3, "buffers_cycled": len(xs),
                    "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
                    "hbm_bytes_per_step": 8 * n_elem,
                    "launch": launch_mode,
@@ -906,12 +914,13 @@ def main():
                    "host_enqueue_ms_per_step": round(eager_host / args.steps * 1e3, 5),
                    "three_launch_path_ms_per_step": round(three_ms, 5),
                    "pct_hbm_peak": round(100.0 * value * GIB / 1e9 / (HBM_PEAK_GBS * world), 2)},
-        "roofline": {"bound": "hbm", "kernel": "observe_fq_fused_kernel<3> (per-token extrema + token-wise clipping + running mean + "
-                                                "qparams + fake-quant, one persistent launch; 4 B per observed elem + 8 B per elem)",
+        "roofline": {"bound": "hbm", "kernel": ("observe_fq_fused_kernel<3> (per-token extrema + token-wise clipping + running mean + "
+                                                "qparams + fake-quant, one persistent launch; 4 B per observed elem + 8 B per elem)")
+                     if fused_on else "fq_tensor_vec_kernel (fake-quant forward of the three-launch path, 8 B per elem)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "avg_launch_us": round(k_avg_ms * 1e3, 2), "median_launch_us": round(k_ms[len(k_ms) // 2] * 1e3, 2),
-                     "launches_timed": len(k_ms), "algorithmic_bytes_per_launch": bytes_step},
+                     "launches_timed": len(k_ms), "algorithmic_bytes_per_launch": probe_bytes},
     }
     if rank == 0 and not args.no_kernel_table:
         out["kernels"] = kernel_table(dev, xs, lengths)

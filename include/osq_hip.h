@@ -85,7 +85,7 @@ size_t      osq_workspace_bytes(void);
 
 /* Performance / path-selection knobs (results never change):
  *   "fq_unroll" 2|4|8 independent 16-byte loads per lane, "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 =
- *   streaming loads/stores of the dense fake-quant; "bwd_blocks" grid cap of the dense LSQ backward;
+ *   streaming loads/stores of the dense fake-quant; "bwd_blocks" grid cap of the dense LSQ backward, "ln_blocks" of the LayerNorm site;
  *   "obs_blocks" grid cap of osq_observe_flat (768: power-of-two grids put a thread's strided loads on the
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register

@@ -22,7 +22,8 @@ static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, n
 static int g_fq_max_blocks = 8192;
 static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
 static int g_stream_wt = 1;      // osq_set_tuning("stream_wt", 0): nt stores instead of write-through ones in the LSQ backward and the GELU fake-quant (measured no gain, or a loss, in the LayerNorm site)
-static int g_bwd_blocks = kMaxBlocks;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n))
+static int g_bwd_blocks = 1792;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n)); tools/bwd_ab.py on MI355X, [256,128,768]:
+                                  // 2048 (every wave slot of the chip): 60.3 us, 1792 (7 workgroups per CU): 53.1, 1536: 53.7, 1024: 55.0, 512: 65.2
 
 template <bool WRITE_Q>
 __device__ __forceinline__ void fq4(const float4& v, float4& y, float4& q, float s, float z, float qmin, float qmax) {
@@ -647,7 +648,7 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     const float qmin = static_cast<float>(quant_min), qmax = static_cast<float>(quant_max);
     const int64_t n4 = n / 4;
     const int tail = static_cast<int>(n - n4 * 4);
-    const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
+    const int grid = grid_for(n4, kThreads * 2, g_bwd_blocks);
     Workspace ws(workspace);
     const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
@@ -706,6 +707,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 5, "fq_nt must be 0..5"); osq::g_fq_nt = value; }
     else if (osq::set_observer_tuning(key, value)) { }
     else if (osq::set_msefast_tuning(key, value)) { }
+    else if (osq::set_layernorm_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
     return OSQ_OK;
 }

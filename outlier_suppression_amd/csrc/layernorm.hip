@@ -14,6 +14,7 @@
 //     a = input*gamma; r = a + hidden; t = (r - mean) * rstd; t = t*w; t = t + b; then quantize_value.
 // The normalisation is not bit-comparable with torch's own kernel (Welford on the GPU, a different
 // blocked summation on the CPU): callers that need the eager sequence keep using it (autograd passes do).
+#include <string>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
 #include "osq_host.h"
@@ -22,6 +23,8 @@ namespace osq {
 
 constexpr int kLnThreads = 256;
 constexpr int kLnWaves = kLnThreads / OSQ_WAVE;
+static int g_ln_blocks = 1024;      // grid cap (osq_set_tuning("ln_blocks", n)); rows are grid-strided above it.  tools/bwd_ab.py on MI355X,
+                                    // [256,128,768]: one row per wave (8192 workgroups) 58.2 us, 2048: 51.6, 1024: 51.2, 768: 51.1, 512: 60.0; [32,384,768]: 23.6 -> 21.1
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add_f32(float v) {
@@ -131,6 +134,11 @@ __global__ __launch_bounds__(kLnThreads) void residual_layernorm_fq_kernel(LnArg
     }
 }
 
+bool set_layernorm_tuning(const char* key, int value) {
+    if (std::string(key) == "ln_blocks" && value >= 1) { g_ln_blocks = value; return true; }
+    return false;
+}
+
 }  // namespace osq
 
 using namespace osq;
@@ -158,7 +166,7 @@ extern "C" int osq_residual_layernorm_fake_quant(const float* x, const float* hi
              static_cast<float>(1.0 / static_cast<double>(cols)), static_cast<float>(eps), scale, zero_point, zp_type, mode,
              grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max)};
     int64_t blocks = (rows + kLnWaves - 1) / kLnWaves;
-    if (blocks > 4 * kMaxBlocks) blocks = 4 * kMaxBlocks;
+    if (blocks > g_ln_blocks) blocks = g_ln_blocks;
     const dim3 grid(static_cast<unsigned>(blocks));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int per_lane = (a.cols4 + OSQ_WAVE - 1) / OSQ_WAVE;

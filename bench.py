@@ -576,6 +576,7 @@ def quantized_forward_times(dev):
     from outlier_suppression_amd.quant_model import quantize_model
     from outlier_suppression_amd.quantization import enable_calibration_woquantization, enable_quantization, disable_all
     from outlier_suppression_amd.quantization import weight_cache as WC
+    from outlier_suppression_amd import _hip
     torch.manual_seed(0)
     a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
@@ -620,6 +621,18 @@ def quantized_forward_times(dev):
         n = WC.prepare_weights(model)
         torch.cuda.synchronize()
     refresh = (time.perf_counter() - t0) * 1e3
+    # the launch alone (the wall-clock above is mostly the host walking 77 modules and comparing their keys)
+    _, w_table, w_ends, w_views, w_rows = WC._PLAN[model]
+    w_lib, w_ts = _hip.load(), []
+    for _ in range(9):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        _hip.check(w_lib.osq_fake_quant_weights_multi(w_table.data_ptr(), w_ends.data_ptr(), len(w_views), w_rows, _hip.stream_ptr(dev)), "weights_multi")
+        eb.record()
+        torch.cuda.synchronize()
+        w_ts.append(ea.elapsed_time(eb) * 1e3)
+    w_us = sorted(w_ts)[len(w_ts) // 2]
+    w_bytes = 8 * sum(v.numel() for v in w_views)
     # observer pass (token_wise_clipping.py:12-19, 29-47: observers on, fake-quant off) of one [32,128] batch: every
     # masked site its own two launches, against the sites of the forward recorded and reduced together
     from outlier_suppression_amd import token_wise_clipping as TWC
@@ -657,7 +670,8 @@ def quantized_forward_times(dev):
             "observer_launches_per_masked_site_now": round(info.get("launches_per_forward", 0) / n_sites, 4),
             "weight_fake_quant_per_operator_every_forward_ms": round(per_op, 3), "weight_launches_per_forward_then": 77,
             "weights_kept_ms": round(kept, 3), "weight_launches_per_forward_now": 0,
-            "one_launch_refresh_of_all_weights_ms": round(refresh, 3), "tensors_in_that_launch": n}
+            "one_launch_refresh_of_all_weights_ms": round(refresh, 3), "tensors_in_that_launch": n,
+            "that_launch_us": round(w_us, 1), "that_launch_MB": round(w_bytes / 1e6, 1), "that_launch_frac_of_8TBps": round(w_bytes / w_us / 1e6 / 8.0, 3)}
 
 
 def main():

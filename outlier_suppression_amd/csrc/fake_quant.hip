@@ -251,42 +251,59 @@ __global__ __launch_bounds__(kThreads) void fq_channel_generic_kernel(
 // bisection over the table's running row counts; per-row (scale, zero_point) as in fq_channel_rows_kernel
 // (channels == 1: the per-tensor form).  The host keeps the result while weight and parameters are unchanged
 // (quantization/weight_cache.py), so a frozen model pays this launch once, not per forward.
+constexpr int kMultiLdsWeights = 1024;         // running row counts of that many tensors are bisected in LDS
 __global__ __launch_bounds__(kThreads) void fq_weights_multi_kernel(const osq_weight_desc* __restrict__ descs,
                                                                     const int64_t* __restrict__ row_end, int n,
                                                                     int64_t total_rows) {
+    // A wave's row costs a chain of dependent reads before its data load leaves: the bisection (7 steps for 77 tensors),
+    // the descriptor, the row's scale and zero point.  Out of global memory that chain made the launch latency-bound
+    // (BERT-base: 880 MB in 0.89 ms = 1 TB/s); the table sits in LDS and the descriptor comes through the scalar cache
+    // (wave-uniform index), as in token_minmax_multi_kernel.
+    __shared__ int64_t s_end[kMultiLdsWeights];
+    const bool in_lds = n <= kMultiLdsWeights;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < n; k += kThreads) s_end[k] = row_end[k];
+        __syncthreads();
+    }
+    const int64_t* ends = in_lds ? s_end : row_end;
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kThreads / OSQ_WAVE);
     for (int64_t g = wave; g < total_rows; g += nwaves) {
         int lo = 0, hi = n - 1;                       // first tensor whose row_end exceeds g
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (row_end[mid] > g) hi = mid; else lo = mid + 1;
+        if (in_lds) {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_end[mid] > g) hi = mid; else lo = mid + 1;
+            }
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (row_end[mid] > g) hi = mid; else lo = mid + 1;
+            }
         }
+        lo = __builtin_amdgcn_readfirstlane(lo);      // the wave's row is one: the descriptor load is a scalar load
         const osq_weight_desc d = descs[lo];
-        const int64_t r = g - (lo ? row_end[lo - 1] : 0);
+        const int64_t r = g - (lo ? ends[lo - 1] : 0);
         const int64_t c = d.channels == 1 ? 0 : r % d.channels;
-        const QParams p = effective_params(d.scale[c], load_zp(d.zero_point, d.zp_type, c), d.mode, d.grad_factor);
-        const float qmin = static_cast<float>(d.quant_min), qmax = static_cast<float>(d.quant_max);
         const int inner4 = static_cast<int>(d.inner / 4);
         const float4* xr = reinterpret_cast<const float4*>(d.x) + r * inner4;
         float4* yr = reinterpret_cast<float4*>(d.y) + r * inner4;
-        int j = lane;
-        for (; j + (kUnroll - 1) * OSQ_WAVE < inner4; j += kUnroll * OSQ_WAVE) {
+        // the row's first loads leave before the parameters are known (768 columns = 3 loads per lane = one trip)
+        for (int j = lane; j < inner4; j += kUnroll * OSQ_WAVE) {
             float4 v[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = xr[j + u * OSQ_WAVE];
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u * OSQ_WAVE < inner4) v[u] = load_stream(&xr[j + u * OSQ_WAVE]);
+            const QParams p = effective_params(d.scale[c], load_zp(d.zero_point, d.zp_type, c), d.mode, d.grad_factor);
+            const float qmin = static_cast<float>(d.quant_min), qmax = static_cast<float>(d.quant_max);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                float4 o, q;
-                fq4<false>(v[u], o, q, p.scale, p.zp, qmin, qmax);
-                yr[j + u * OSQ_WAVE] = o;
-            }
-        }
-        for (; j < inner4; j += OSQ_WAVE) {
-            float4 o, q;
-            fq4<false>(xr[j], o, q, p.scale, p.zp, qmin, qmax);
-            yr[j] = o;
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u * OSQ_WAVE < inner4) {
+                    float4 o, q;
+                    fq4<false>(v[u], o, q, p.scale, p.zp, qmin, qmax);
+                    yr[j + u * OSQ_WAVE] = o;         // plain stores: the result is the next GEMM's operand
+                }
         }
     }
 }

@@ -70,7 +70,7 @@ class ObserverBase(nn.Module):
         if self.min_val.device != device:
             self.min_val = self.min_val.to(device)
             self.max_val = self.max_val.to(device)
-        if channels is not None and self.min_val.numel() != channels:
+        if channels is not None and tuple(self.min_val.shape) != (channels,):     # [C] also for C == 1 (torch.min(0-dim, [1]) is [1])
             self.min_val = self.min_val.reshape(-1)[:1].expand(channels).contiguous()
             self.max_val = self.max_val.reshape(-1)[:1].expand(channels).contiguous()
 

@@ -1,0 +1,222 @@
+"""Randomised differential test: the module API on the GPU against the oracle over layouts, sizes and value patterns no
+hand-written case lists -- odd shapes (T < 4, 1..7 features), permuted and offset (16-byte-misaligned) views, empty and
+full samples, one-sided and constant tensors, heavy duplicates (quantised values), 4 / 6 / 8 bit, both symmetries, the
+three running-statistic observers, Fixed and LSQ+ quantizers, forward and LSQ+ backward.  Seeded: the cases are the same
+in every run; OSQ_FUZZ_CASES=<n> lengthens the walk (default 800 cases, a few seconds)."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("OSQ_FUZZ_CASES", "800"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from outlier_suppression_amd import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+def _draw_shape(rng):
+    kind = rng.choice(["bth", "bhtd", "bhdt", "bh", "probs"])
+    small = rng.random() < 0.5
+    B = int(rng.integers(1, 6 if small else 12))
+    T = int(rng.integers(1, 9 if small else 70))
+    if kind == "bth":
+        H = int(rng.choice([1, 2, 3, 5, 7, 8, 12, 64, 100, 256, 260, 768]))
+        return kind, (B, T, H), 1
+    if kind == "bh":
+        return kind, (B, int(rng.choice([1, 3, 8, 33, 768]))), -1
+    h = int(rng.integers(1, 5))
+    d = int(rng.choice([1, 2, 4, 6, 8, 16, 64]))
+    if kind == "bhtd":
+        return kind, (B, h, T, d), 2
+    if kind == "bhdt":
+        return kind, (B, h, d, T), 3
+    return kind, (B, h, T, T), 2
+
+
+def _draw_values(rng, shape, pattern):
+    x = rng.standard_normal(shape).astype(np.float32)
+    if pattern == "outlier":
+        x[..., 0] *= 25.0
+    elif pattern == "positive":
+        x = np.abs(x) + np.float32(0.01)
+    elif pattern == "negative":
+        x = -np.abs(x) - np.float32(0.01)
+    elif pattern == "constant":
+        x[...] = np.float32(rng.choice([0.0, 1.5, -2.25]))
+    elif pattern == "duplicates":
+        x = np.round(x * 2.0).astype(np.float32) / np.float32(2.0)
+    elif pattern == "tiny":
+        x *= np.float32(1e-6)
+    elif pattern == "huge":
+        x *= np.float32(1e6)
+    return x
+
+
+def _as_view(rng, x_np, kind, dev):
+    """The same values behind a different memory layout: dense, a permuted view ([B,T,h,d] memory seen head-split, as
+    the attention blocks hand it over), or a slice of a larger buffer that starts 4 bytes off a 16-byte boundary."""
+    x = torch.from_numpy(x_np)
+    how = rng.choice(["dense", "permuted", "offset"])
+    if how == "permuted" and x.dim() == 4 and kind in ("bhtd", "bhdt"):
+        if kind == "bhtd":
+            mem = x.permute(0, 2, 1, 3).contiguous().to(dev)          # [B,T,h,d] memory
+            return mem.permute(0, 2, 1, 3), how
+        mem = x.permute(0, 3, 1, 2).contiguous().to(dev)              # [B,T,h,d] memory, key view [B,h,d,T]
+        return mem.permute(0, 2, 3, 1), how
+    if how == "offset":
+        buf = torch.zeros(x.numel() + 1, device=dev)
+        buf[1:] = x.reshape(-1).to(dev)
+        return buf[1:].view(x.shape), how
+    return x.to(dev), "dense"
+
+
+def test_quantizer_calls_vs_oracle(eq32, dev):
+    from oracle import observer_oracle as OB, fake_quant_oracle as FQ
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(20260930)
+    observers = {"AvgPruneMinMaxObserver": OB.observe_avg_prune_minmax, "AvgMinMaxObserver": OB.observe_avg_minmax,
+                 "MinMaxObserver": OB.observe_minmax}
+    seen = set()
+    for case in range(N_CASES):
+        kind, shape, seq_pos = _draw_shape(rng)
+        observer = str(rng.choice(list(observers)))
+        quantizer = str(rng.choice(["FixedFakeQuantize", "LSQPlusFakeQuantize"]))
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        percentile = float(rng.choice([1.0, 0.99, 0.9, 0.71, 0.5]))
+        name = "layer.attention_probs_post_act_fake_quantize.observer" if kind == "probs" and rng.random() < 0.7 \
+            else "layer.x_post_act_fake_quantize.observer"
+        masked = seq_pos != -1 and rng.random() < 0.8
+        q = Quantizer(None, NS(quantizer=quantizer, observer=observer, bit=bit, symmetric=sym, ch_axis=-1)).to(dev)
+        q.observer.set_name(name)
+        if hasattr(q.observer, "set_percentile"):
+            q.observer.set_percentile(percentile)
+        q.enable_observer()
+        q.enable_fake_quant()
+        st = OB.ObserverState(bit=bit, symmetric=sym, name=name)
+        st.percentile = percentile
+        tag = (case, kind, shape, seq_pos, observer, quantizer, bit, sym, percentile, masked)
+        for it in range(int(rng.integers(1, 4))):
+            pattern = str(rng.choice(["normal", "outlier", "positive", "negative", "constant", "duplicates", "tiny", "huge"]))
+            x_np = _draw_values(rng, shape, pattern)
+            x, how = _as_view(rng, x_np, kind, dev)
+            seen.add((kind, how, pattern))
+            L_np = None
+            if masked:
+                Tn = shape[seq_pos]
+                L_np = rng.integers(0, Tn + 1, (shape[0],)).astype(np.int64)
+                L_np[int(rng.integers(0, shape[0]))] = Tn if rng.random() < 0.7 else max(1, Tn // 2)
+            with torch.no_grad():
+                y = q(x, None if L_np is None else torch.from_numpy(L_np).to(dev), seq_pos)
+            observers[observer](st, x_np, L_np, seq_pos)
+            assert eq32(q.observer.min_val.cpu().numpy(), st.min_val) and eq32(q.observer.max_val.cpu().numpy(), st.max_val), \
+                (tag, it, how, pattern, q.observer.min_val.item(), st.min_val, q.observer.max_val.item(), st.max_val)
+            scale, zp = st.qparams()
+            assert np.float32(q.scale.item()) == np.float32(scale) and np.float32(q.zero_point.item()) == np.float32(zp), \
+                (tag, it, how, pattern, q.scale.item(), scale, q.zero_point.item(), zp)
+            if quantizer == "LSQPlusFakeQuantize":
+                g = FQ.lsqplus_grad_factor(x_np.size, q.quant_max)
+                _, ref = FQ.fake_quantize_learnableplus_per_tensor(x_np, scale, zp, q.quant_min, q.quant_max, g)
+            else:
+                _, ref = FQ.fake_quantize_per_tensor_affine(x_np, scale, zp, q.quant_min, q.quant_max)
+            assert y.shape == x.shape and eq32(y.cpu().numpy(), ref), (tag, it, how, pattern)
+        if quantizer == "LSQPlusFakeQuantize":
+            # frozen parameters, autograd on: dx bit for bit, the two parameter gradients to summation order
+            q.disable_observer()
+            xg = x.detach().clone().requires_grad_(True)
+            gy_np = rng.standard_normal(shape).astype(np.float32)
+            s0, z0 = q.scale.detach().cpu().numpy().copy(), q.zero_point.detach().cpu().numpy().copy()
+            out = q(xg, None, seq_pos)
+            out.backward(torch.from_numpy(gy_np).to(dev))
+            s_rep = np.maximum(np.abs(s0), np.float32(1.1920928955078125e-07)).astype(np.float32)     # fake_quant.py:188-191
+            z_rep = np.clip(z0, np.float32(q.quant_min), np.float32(q.quant_max)).astype(np.float32)
+            g = FQ.lsqplus_grad_factor(x_np.size, q.quant_max)
+            dx, ds, dz = FQ.lsqplus_backward_per_tensor(x_np, gy_np, s_rep, z_rep, q.quant_min, q.quant_max, g)
+            assert eq32(xg.grad.cpu().numpy(), dx), (tag, "dx")
+            # fp32 partial sums on the device, float64 in the oracle: the bound is relative to the sum of the terms' magnitudes
+            mag = float(np.abs(gy_np).sum()) * g
+            assert abs(q.scale.grad.item() - ds) <= 2e-5 * abs(ds) + 2e-6 * mag * float(2 ** bit), (tag, "dscale", q.scale.grad.item(), ds)
+            assert abs(q.zero_point.grad.item() - dz) <= 2e-5 * abs(dz) + 2e-6 * mag * float(s_rep[0]), \
+                (tag, "dzp", q.zero_point.grad.item(), dz)
+    kinds = {k for k, _, _ in seen}
+    assert kinds == {"bth", "bhtd", "bhdt", "bh", "probs"} and {h for _, h, _ in seen} == {"dense", "permuted", "offset"}
+
+
+def test_weight_operators_vs_oracle(eq32, dev):
+    """Per-channel side: Quantizer(nn.Linear / nn.Conv2d / nn.Embedding) with MinMaxObserver on ch_axis 0 (odd row lengths,
+    one-row and one-column weights, 4-D kernels), both symmetries, and the functional per-channel fake-quant on an inner
+    channel axis (the generic kernel)."""
+    from oracle import observer_oracle as OB, fake_quant_oracle as FQ
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(777)
+    for case in range(max(40, N_CASES // 4)):
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        kind = str(rng.choice(["linear", "conv", "embedding"]))
+        if kind == "linear":
+            mod = torch.nn.Linear(int(rng.choice([1, 3, 4, 7, 64, 100, 768])), int(rng.integers(1, 40)))
+        elif kind == "conv":
+            mod = torch.nn.Conv2d(int(rng.integers(1, 5)), int(rng.integers(1, 9)), int(rng.choice([1, 3])))
+        else:
+            mod = torch.nn.Embedding(int(rng.integers(2, 50)), int(rng.choice([2, 5, 8, 96])))
+        w_np = (rng.standard_normal(tuple(mod.weight.shape)) * rng.choice([0.02, 1.0, 30.0])).astype(np.float32)
+        if rng.random() < 0.3:
+            w_np[0] = np.abs(w_np[0])                              # a one-sided row
+        if rng.random() < 0.2:
+            w_np[-1] = 0.0                                         # a constant row: scale floor 1e-8
+        with torch.no_grad():
+            mod.weight.copy_(torch.from_numpy(w_np))
+        qm = Quantizer(mod, NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=bit, symmetric=sym, ch_axis=0)).to(dev)
+        fq = qm.weight_fake_quant
+        fq.enable_observer()
+        fq.enable_fake_quant()
+        with torch.no_grad():
+            wq = fq(qm.weight)
+        st = OB.ObserverState(bit=bit, symmetric=sym, ch_axis=0)
+        OB.observe_minmax(st, w_np)
+        scale, zp = st.qparams()
+        tag = (case, kind, w_np.shape, bit, sym)
+        assert eq32(fq.observer.min_val.cpu().numpy(), st.min_val) and eq32(fq.observer.max_val.cpu().numpy(), st.max_val), tag
+        assert eq32(fq.scale.cpu().numpy(), scale) and np.array_equal(fq.zero_point.cpu().numpy(), zp), tag
+        _, ref = FQ.fake_quantize_per_channel_affine(w_np, scale, zp, 0, fq.quant_min, fq.quant_max)
+        assert eq32(wq.cpu().numpy(), ref), tag
+        # inner channel axis, functional form
+        shape = tuple(int(v) for v in rng.integers(1, 7, size=int(rng.integers(2, 5))))
+        ax = int(rng.integers(0, len(shape)))
+        x_np = rng.standard_normal(shape).astype(np.float32)
+        s_np = (np.abs(rng.standard_normal(shape[ax])) * 0.05 + 1e-3).astype(np.float32)
+        z_np = rng.integers(fq.quant_min, fq.quant_max + 1, shape[ax]).astype(np.int32)
+        y = ops.fake_quant_per_channel(torch.from_numpy(x_np).to(dev), torch.from_numpy(s_np).to(dev), torch.from_numpy(z_np).to(dev),
+                                       ax, fq.quant_min, fq.quant_max)
+        _, ref = FQ.fake_quantize_per_channel_affine(x_np, s_np, z_np, ax, fq.quant_min, fq.quant_max)
+        assert eq32(y.cpu().numpy(), ref), (tag, shape, ax)
+
+
+def test_msefast_rows_vs_oracle(dev):
+    """MSEFastObserver per output channel (observer.py:496-517): every row's search equals the oracle's bounded Brent
+    iterate for iterate -- the same (min, max) bit for bit -- over random row lengths, one-sided and mixed rows, 4 / 6 / 8 bit."""
+    from oracle import observer_oracle as OB
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    rng = np.random.default_rng(4242)
+    for case in range(max(6, N_CASES // 40)):
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        rows, cols = int(rng.integers(1, 12)), int(rng.choice([4, 12, 64, 100, 768]))
+        w_np = (rng.standard_normal((rows, cols)) * rng.choice([0.05, 1.0])).astype(np.float32)
+        if rng.random() < 0.4:
+            w_np = np.abs(w_np) + np.float32(1e-3)                 # one_side_dist 'pos' (decided on the whole tensor)
+        ob = MSEFastObserver(bit=bit, symmetric=sym, ch_axis=0).to(dev)
+        ob(torch.from_numpy(w_np).to(dev))
+        st = OB.ObserverState(bit=bit, symmetric=sym, ch_axis=0)
+        OB.observe_msefast(st, w_np)
+        got_min, got_max = ob.min_val.cpu().numpy(), ob.max_val.cpu().numpy()
+        assert np.array_equal(got_min.astype(np.float32), np.asarray(st.min_val, dtype=np.float32)) and \
+            np.array_equal(got_max.astype(np.float32), np.asarray(st.max_val, dtype=np.float32)), (case, bit, sym, rows, cols, got_min, st.min_val)

@@ -25,7 +25,7 @@ def dev():
 
 
 def _draw_shape(rng):
-    kind = rng.choice(["bth", "bhtd", "bhdt", "bh", "probs"])
+    kind = rng.choice(["bth", "bhtd", "bhdt", "bh", "probs", "probs3d"])
     small = rng.random() < 0.5
     B = int(rng.integers(1, 6 if small else 12))
     T = int(rng.integers(1, 9 if small else 70))
@@ -34,6 +34,8 @@ def _draw_shape(rng):
         return kind, (B, T, H), 1
     if kind == "bh":
         return kind, (B, int(rng.choice([1, 3, 8, 33, 768]))), -1
+    if kind == "probs3d":          # BART: [B*h, T, S] probabilities with a length-B mask (remove_padding's zip stops after B rows)
+        return kind, (B * int(rng.integers(1, 5)), T, int(rng.integers(1, 40))), 1
     h = int(rng.integers(1, 5))
     d = int(rng.choice([1, 2, 4, 6, 8, 16, 64]))
     if kind == "bhtd":
@@ -93,7 +95,7 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
         quantizer = str(rng.choice(["FixedFakeQuantize", "LSQPlusFakeQuantize"]))
         bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
         percentile = float(rng.choice([1.0, 0.99, 0.9, 0.71, 0.5]))
-        name = "layer.attention_probs_post_act_fake_quantize.observer" if kind == "probs" and rng.random() < 0.7 \
+        name = "layer.attention_probs_post_act_fake_quantize.observer" if kind in ("probs", "probs3d") and rng.random() < 0.7 \
             else "layer.x_post_act_fake_quantize.observer"
         masked = seq_pos != -1 and rng.random() < 0.8
         q = Quantizer(None, NS(quantizer=quantizer, observer=observer, bit=bit, symmetric=sym, ch_axis=-1)).to(dev)
@@ -113,8 +115,9 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
             L_np = None
             if masked:
                 Tn = shape[seq_pos]
-                L_np = rng.integers(0, Tn + 1, (shape[0],)).astype(np.int64)
-                L_np[int(rng.integers(0, shape[0]))] = Tn if rng.random() < 0.7 else max(1, Tn // 2)
+                n_mask = shape[0] if kind != "probs3d" else max(1, shape[0] // int(rng.integers(1, 5)))
+                L_np = rng.integers(0, Tn + 1, (n_mask,)).astype(np.int64)
+                L_np[int(rng.integers(0, n_mask))] = Tn if rng.random() < 0.7 else max(1, Tn // 2)
             with torch.no_grad():
                 y = q(x, None if L_np is None else torch.from_numpy(L_np).to(dev), seq_pos)
             observers[observer](st, x_np, L_np, seq_pos)
@@ -148,7 +151,7 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
             assert abs(q.zero_point.grad.item() - dz) <= 2e-5 * abs(dz) + 2e-6 * mag * float(s_rep[0]), \
                 (tag, "dzp", q.zero_point.grad.item(), dz)
     kinds = {k for k, _, _ in seen}
-    assert kinds == {"bth", "bhtd", "bhdt", "bh", "probs"} and {h for _, h, _ in seen} == {"dense", "permuted", "offset"}
+    assert kinds == {"bth", "bhtd", "bhdt", "bh", "probs", "probs3d"} and {h for _, h, _ in seen} == {"dense", "permuted", "offset"}
 
 
 def test_weight_operators_vs_oracle(eq32, dev):
@@ -220,3 +223,83 @@ def test_msefast_rows_vs_oracle(dev):
         got_min, got_max = ob.min_val.cpu().numpy(), ob.max_val.cpu().numpy()
         assert np.array_equal(got_min.astype(np.float32), np.asarray(st.min_val, dtype=np.float32)) and \
             np.array_equal(got_max.astype(np.float32), np.asarray(st.max_val, dtype=np.float32)), (case, bit, sym, rows, cols, got_min, st.min_val)
+
+
+def test_token_selection_vs_oracle(eq32, dev):
+    """Token-wise clipping at many token counts (1 .. 70 000 slots: register path, one- and two-workgroup finalisers, the
+    wide three-launch path above 32768) on few features, with the value patterns that stress a selection: two or three
+    distinct values, all equal, all-negative per-token maxima, heavy ties round the percentile, extreme percentiles."""
+    from oracle import observer_oracle as OB
+    from outlier_suppression_amd.quantization.observer import AvgPruneMinMaxObserver
+    rng = np.random.default_rng(99)
+    for case in range(max(30, N_CASES // 8)):
+        big = rng.random() < 0.25
+        B = int(rng.integers(1, 65 if big else 9))
+        T = int(rng.integers(1, 1100 if big else 40))
+        H = int(rng.choice([1, 2, 4, 8]))
+        seq_pos = 1
+        p = float(rng.choice([1.0, 0.999, 0.97, 0.9, 0.5, 0.01, 0.0]))
+        pattern = str(rng.choice(["normal", "two", "three", "equal", "negative", "ties", "outlier"]))
+        x = rng.standard_normal((B, T, H)).astype(np.float32)
+        if pattern == "two":
+            x = np.where(x > 0.3, np.float32(2.0), np.float32(-1.0)).astype(np.float32)
+        elif pattern == "three":
+            x = np.sign(np.round(x)).astype(np.float32) * np.float32(0.75)
+        elif pattern == "equal":
+            x[...] = np.float32(-3.5 if rng.random() < 0.5 else 0.25)
+        elif pattern == "negative":
+            x = -np.abs(x) - np.float32(0.5)
+        elif pattern == "ties":
+            x = np.round(x * 4.0).astype(np.float32) / np.float32(4.0)
+        elif pattern == "outlier":
+            x[:, ::7, 0] *= np.float32(40.0)
+        L = rng.integers(0, T + 1, (B,)).astype(np.int64)
+        if rng.random() < 0.3:
+            L[...] = T
+        L[int(rng.integers(0, B))] = T
+        ob = AvgPruneMinMaxObserver(bit=6, symmetric=False).to(dev)
+        ob.set_name("layer.x_post_act_fake_quantize.observer")
+        ob.set_percentile(p)
+        st = OB.ObserverState(bit=6, symmetric=False, name=ob.name)
+        st.percentile = p
+        for it in range(2):
+            xi = x if it == 0 else (x * np.float32(1.5) + np.float32(0.125)).astype(np.float32)
+            ob(torch.from_numpy(xi).to(dev), torch.from_numpy(L).to(dev), seq_pos)
+            OB.observe_avg_prune_minmax(st, xi, L, seq_pos)
+            assert eq32(ob.min_val.cpu().numpy(), st.min_val) and eq32(ob.max_val.cpu().numpy(), st.max_val), \
+                (case, (B, T, H), p, pattern, it, ob.min_val.item(), st.min_val, ob.max_val.item(), st.max_val)
+
+
+def test_fused_step_vs_three_launches_random(dev):
+    """The one-launch observe + fake-quant step against the launch-per-stage path on random eligible shapes (features a
+    multiple of 256), lengths with empty samples, random percentiles, occasionally a NaN among the valid tokens."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(31337)
+    try:
+        for case in range(max(12, N_CASES // 40)):
+            B, T = int(rng.integers(1, 97)), int(rng.integers(4, 200))
+            H = int(rng.choice([256, 512, 768, 1024, 1280, 3072, 4096]))
+            p = float(rng.choice([1.0, 0.95, 0.71, 0.5]))
+            x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32))
+            x[..., 5] *= 18.0
+            L = torch.from_numpy(rng.integers(0, T + 1, (B,)).astype(np.int64))
+            L[int(rng.integers(0, B))] = T
+            if rng.random() < 0.1:
+                x[0, 0, 1] = float("nan")
+            res = {}
+            for fused in (1, 0):
+                ops.set_tuning("fused_step", fused)
+                q = Quantizer(None, NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)).to(dev)
+                q.observer.set_name("layer.x_post_act_fake_quantize.observer")
+                q.observer.set_percentile(p)
+                q.enable_observer(); q.enable_fake_quant()
+                with torch.no_grad():
+                    ys = [q(x.to(dev) * (1.0 + 0.5 * it), L.to(dev), 1).cpu() for it in range(2)]
+                res[fused] = (ys, q.observer.min_val.cpu(), q.observer.max_val.cpu(), q.scale.detach().cpu(), q.zero_point.detach().cpu())
+            a, b = res[1], res[0]
+            for u, v in zip(a[0] + list(a[1:]), b[0] + list(b[1:])):
+                assert torch.equal(torch.nan_to_num(u, nan=12345.0), torch.nan_to_num(v, nan=12345.0)) and \
+                    torch.equal(torch.isnan(u), torch.isnan(v)), (case, (B, T, H), p)
+    finally:
+        ops.set_tuning("fused_step", 1)

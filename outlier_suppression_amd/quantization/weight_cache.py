@@ -11,7 +11,13 @@ as long as
     call that lets a kernel write them: observation, parameter repair, statistics replay) is unchanged,
   * observer off, fake-quant on, no gradient wanted;
 
-and ``prepare_weights(model)`` refreshes every stale entry of a model in ONE launch (``osq_fake_quant_weights_multi``)
+What the key cannot see: in-place edits through ``.data`` (``w.weight.data *= g`` as in the reference's
+gamma_migration.py:71, ``p.data.copy_(...)``) -- torch gives ``.data`` its own version counter, so ``weight._version`` does
+not move.  In the reference's flows such edits happen before any quantized forward (FP targets and the migration run with
+the quantizers off, nothing is cached yet); code that edits weights this way AFTER a quantized forward calls
+``invalidate(model)`` (or sets ``enabled = False``).  This package's own ``gamma_migration`` bumps ``ops.weight_epoch``.
+
+``prepare_weights(model)`` refreshes every stale entry of a model in ONE launch (``osq_fake_quant_weights_multi``)
 over a pointer table that is itself kept while the pointers stay the same.  Same arithmetic as the per-module launch:
 bit-identical weights, hence bit-identical logits.
 """

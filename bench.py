@@ -398,6 +398,61 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
     return out
 
 
+def calibration_plain(dev, rank, world):
+    """BASELINE configs[0]: BERT-base CoLA PTQ with the plain MinMax flow (exp/bert_ptq/minmax/cola/config.yaml: W6 per-channel
+    MinMaxObserver, A6 AvgMinMaxObserver + FixedFakeQuantize, no token-wise clipping, no gamma migration), 256 samples = 8 x
+    [32,128], through ptq.run (ptq_glue_quant.py:228-251).  N > 1: the observer pass is sharded (calibration.calibrate_sharded:
+    batch b on rank b mod N, one all-gather of the per-batch statistics, replay in batch order -- bit-identical)."""
+    import logging
+    from types import SimpleNamespace as NS
+    import torch.distributed as dist
+    import transformers as T
+    from outlier_suppression_amd import calibration, ptq
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, enable_quantization
+    logging.getLogger("transformer").setLevel(logging.WARNING)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(100)
+    fp = T.BertForSequenceClassification(T.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).eval().to(dev)
+    batches = []
+    for _ in range(8):
+        L = torch.randint(8, 129, (32,), generator=g)
+        mask = (torch.arange(128)[None, :] < L[:, None]).long()
+        ids = torch.randint(1000, 29000, (32, 128), generator=g) * mask
+        batches.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev), "token_type_ids": torch.zeros_like(ids).to(dev)})
+    section = ptq.SHIPPED_QUANT_SECTIONS["minmax"]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    res = {}
+    for rep in range(2):                       # the second run is the steady state (allocator, library handles)
+        model = quantize_model(fp, section.w_qconfig, section.a_qconfig).to(dev)
+        sync()
+        t0 = time.perf_counter()
+        if world == 1:
+            with torch.no_grad():
+                fp_in, fp_out = ptq.prepare_input_output(model, batches)
+                t1 = time.perf_counter()
+                model = ptq.run(model, fp_in, fp_out, section, NS(model_type="bert", task_type="glue"))
+        else:
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+                model(**batches[0])
+                enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
+                mine = calibration.shard_batches(len(batches), rank, world)
+                calibration.calibrate_sharded(model, [batches[b] for b in mine], lambda m, b: m(**b), n_batches=len(batches))
+                enable_quantization(model)
+        sync()
+        res = {"wall_s": round(time.perf_counter() - t0, 4), "fp_outputs_s": round(t1 - t0, 4)}
+    return {"config": "configs[0]: BERT-base CoLA PTQ, plain MinMax flow W6A6 (exp/bert_ptq/minmax), 256 samples (8 x [32,128]), "
+                      "random-init weights, synthetic ids", **res, "n_gpus": world,
+            "observer_pass": "every site of a forward reduced together (quantization/deferred.py)" if world == 1 else
+                             "sharded over ranks, one all-gather of the per-batch statistics"}
+
+
 def calibration_extra(dev, rank, world, which):
     """Calibration wall-clock (SURVEY.md section 8d Metric 2) of BASELINE configs[2], [3], [4] at the reference's sizes,
     random-init weights and synthetic ids; clock: batches resident on device -> every quantizer has its final
@@ -688,7 +743,7 @@ def main():
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel timing table")
     ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
-    ap.add_argument("--calib-configs", default="1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured")
+    ap.add_argument("--calib-configs", default="0,1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -940,6 +995,11 @@ def main():
         out["kernels"] = kernel_table(dev, xs, lengths)
     if not args.no_calib:
         wanted = {int(c) for c in args.calib_configs.split(",") if c.strip()}
+        if 0 in wanted:
+            try:
+                out["calibration_config0"] = calibration_plain(dev, rank, world)
+            except Exception as e:
+                out["calibration_config0"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if 1 in wanted:
             out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
         for which in (2, 3, 4):

@@ -467,7 +467,8 @@ def calibration_extra(dev, rank, world, which):
          (exp/xsum/twc_fine_gamma/config.yaml:44; BASELINE names bart-large), 64 x ([4, 1024] source, [4, 62] target),
          30 candidates, learn-scale 3 epochs (ptq_summ_quant.py:124-154).
     N > 1: the grid search is sharded (batch b on rank b mod N); the statistics / loss tables are all-gathered per candidate
-    (calibration.gather_batch_table); learn-scale and the MSEFast searches run replicated (sequential Adam / float64
+    (calibration.gather_batch_table); learn-scale runs data-parallel inside each batch when the batch divides over the ranks
+    (TWC.learn_scale_sharded: configs 2 at batch 8, config 4's batches of 4 up to 4 ranks); the MSEFast searches run replicated (float64
     per-observer state), which the line says."""
     import logging
     from types import SimpleNamespace as NS
@@ -614,7 +615,10 @@ def calibration_extra(dev, rank, world, which):
         out.update({"wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
                     "collective_s": round(gather_s[0], 4), "best_percentile": ratio, "twc_candidates": grid["iters"],
                     "search": "cached per-token extrema, one re-threshold launch per candidate and geometry group, sharded over ranks",
-                    "learn_scale": "sequential Adam, replicated on every rank" if world > 1 else "sequential Adam, one process",
+                    "learn_scale": ("sequential Adam, one process" if world == 1 else
+                                    ("sequential Adam, every step data-parallel inside the batch (kept-token targets sliced per rank, gradients summed)"
+                                     if all(next(iter(b.values())).shape[0] % world == 0 for b in learn_in)
+                                     else "sequential Adam, replicated on every rank (the batch does not divide over the ranks)")),
                     "n_gpus": world})
         return out
     finally:

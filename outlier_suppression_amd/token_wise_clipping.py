@@ -153,15 +153,29 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
 
     Same mathematics as ``learn_scale``; summation order differs (per-rank partial sums), so the learned
     parameters agree to float rounding (~1e-6 relative), not bit for bit -- the single-GPU run itself is
-    only within that of the reference.  Falls back to the replicated loop when the task is not "glue"
-    or the batch does not divide evenly.
+    only within that of the reference.  The masked tasks (SQuAD's two heads over the attended tokens, summarisation over
+    the valid decoder tokens) sum squared errors locally, divide by the full batch's element count and SUM the gradients.
+    Falls back to the replicated loop when the batch does not divide evenly (BART's batches of 4 on 8 ranks).
     """
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     sizes = {next(iter(b.values())).shape[0] for b in fp_input}
-    if world == 1 or task_type != "glue" or any(sz % world for sz in sizes):
+    if world == 1 or task_type not in ("glue", "squad", "squad_v2", "summ") or any(sz % world for sz in sizes):
         return learn_scale(trainer, fp_input, fp_output, config_quant_learn)
+    masked_task = task_type != "glue"
+    # Masked tasks (token_wise_clipping.py:38-43): the targets are rows of the KEPT tokens of the whole batch and the MSE's
+    # denominator is their number -- a rank's samples hold a data-dependent share of them.  Per batch, once, outside the
+    # optimisation loop: where this rank's rows start, how many there are, and the full-batch denominator; the local loss
+    # is then (local sum of squares) / (full-batch element count) and the full-batch gradient is the SUM over the ranks.
+    spans = []
+    if masked_task:
+        key = "decoder_attention_mask" if task_type == "summ" else "attention_mask"
+        for batch in fp_input:
+            counts = (batch[key] == 1).sum(1).cpu()
+            per = counts.numel() // world
+            lo, hi = rank * per, (rank + 1) * per
+            spans.append((int(counts[:lo].sum()), int(counts[lo:hi].sum()), int(counts.sum())))
     model = trainer.model
     disable_all(model)
     logger.info("*** begin learn the scale now! (intra-batch data parallel over %d ranks) ***", world)
@@ -190,7 +204,18 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
                 lo, hi = rank * per, (rank + 1) * per
                 local = {k: v[lo:hi] for k, v in batch.items()}
                 opt.zero_grad()
-                loss = batch_loss(model(**local), local, fp_output[i][lo:hi])
+                if not masked_task:
+                    loss = batch_loss(model(**local), local, fp_output[i][lo:hi])
+                else:
+                    off, n_loc, n_tot = spans[i]
+                    out = model(**local)
+                    if task_type == "summ":
+                        got = out[0][local["decoder_attention_mask"] == 1, :]
+                        loss = (got - fp_output[i][off:off + n_loc]).square().sum() / (n_tot * got.shape[-1])
+                    else:
+                        keep = local["attention_mask"] == 1
+                        loss = ((out[0][keep] - fp_output[i][0][off:off + n_loc]).square().sum() +
+                                (out[1][keep] - fp_output[i][1][off:off + n_loc]).square().sum()) / n_tot
                 loss.backward()
                 flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
                 if staged:
@@ -199,7 +224,8 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
                     flat = host.to(flat.device)
                 else:
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-                flat /= world
+                if not masked_task:
+                    flat /= world
                 for p, g, shp in zip(params, torch.split(flat, counts), shapes):
                     p.grad = g.reshape(shp)
                 opt.step()

@@ -150,3 +150,101 @@ def test_two_ranks_equal_one(tmp_path):
     np.testing.assert_allclose(l2[0]["zp"], l1["zp"], rtol=2e-5, atol=2e-5)
     moved = np.abs(l1["scale"] - base["scale"]).max()
     assert np.abs(l2[0]["scale"] - l1["scale"]).max() < 1e-2 * moved   # far below the size of the learned update
+
+
+def _run_masked(rank, world, port, out_dir, task):
+    """learn_scale_sharded on the masked tasks: tiny BERT-QA (two heads over the attended tokens) / tiny BART (valid decoder
+    tokens), every Adam step split inside the batch over `world` ranks sharing the test GPU."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import transformers as T
+    from outlier_suppression_amd import token_wise_clipping as TWC
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
+    from outlier_suppression_amd.quantization.state import set_observer_name
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    torch.manual_seed(11)
+    gen = torch.Generator().manual_seed(5)
+    dev = torch.device("cuda:0")
+    B, Tn = 4, 12
+    if task == "squad":
+        fp = T.BertForQuestionAnswering(T.BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                                     intermediate_size=64, max_position_embeddings=40, hidden_dropout_prob=0.0,
+                                                     attention_probs_dropout_prob=0.0, type_vocab_size=2)).eval().to(dev)
+    else:
+        fp = T.BartForConditionalGeneration(T.BartConfig(vocab_size=120, d_model=32, encoder_layers=2, decoder_layers=2,
+                                                         encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=64,
+                                                         decoder_ffn_dim=64, max_position_embeddings=40, dropout=0.0,
+                                                         attention_dropout=0.0, activation_dropout=0.0)).eval().to(dev)
+    batches = []
+    for _ in range(3):
+        L = torch.randint(3, Tn + 1, (B,), generator=gen)
+        L[0] = Tn
+        mask = (torch.arange(Tn)[None, :] < L[:, None]).long()
+        ids = torch.randint(5, 115, (B, Tn), generator=gen) * mask + (1 - mask)
+        b = {"input_ids": ids.to(dev), "attention_mask": mask.to(dev)}
+        if task == "squad":
+            b["token_type_ids"] = torch.zeros_like(ids).to(dev)
+        else:
+            DL = torch.randint(2, 8, (B,), generator=gen)
+            DL[1] = 7
+            dm = (torch.arange(7)[None, :] < DL[:, None]).long()
+            b["decoder_input_ids"] = (torch.randint(5, 115, (B, 7), generator=gen) * dm + (1 - dm)).to(dev)
+            b["decoder_attention_mask"] = dm.to(dev)
+        batches.append(b)
+    a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    model = quantize_model(fp, w_q, a_q).to(dev)
+    TWC.task_type, TWC.model_type = task, ("bert" if task == "squad" else "bart")
+    with torch.no_grad():
+        if task == "squad":
+            fp_output = []
+            for b in batches:
+                o = model(**b)
+                keep = b["attention_mask"] == 1
+                fp_output.append([o[0][keep].detach(), o[1][keep].detach()])
+        else:
+            fp_output = [model(**b)[0][b["decoder_attention_mask"] == 1, :].detach() for b in batches]
+    enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+    with torch.no_grad():
+        model(**batches[0])
+    disable_all(model)
+    set_observer_name(model)
+    TWC.set_ratio(model, 0.9)
+    TWC.calibrate(model, batches)
+    qs = [m for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+    before = np.stack([q.scale.detach().cpu().numpy() for q in qs])
+    TWC.learn_scale_sharded(NS(model=model), batches, fp_output, {"lr": 1e-3, "epoch": 2})
+    np.savez(os.path.join(out_dir, f"{task}_w{world}_r{rank}.npz"), before=before,
+             scale=np.stack([q.scale.detach().cpu().numpy() for q in qs]),
+             zp=np.stack([q.zero_point.detach().cpu().numpy() for q in qs]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("task,port", [("squad", 29751), ("summ", 29761)])
+def test_masked_learn_scale_two_ranks_equal_one(tmp_path, task, port):
+    """The fine stage of the QA and summarisation entry points (ptq_qa_quant.py:262-277, ptq_summ_quant.py) data-parallel
+    inside the batch: kept-token targets sliced by per-sample counts, losses over the full batch's denominator, gradients
+    summed -- the learned parameters agree with the sequential loop to float rounding; the ranks agree bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    mp.spawn(_run_masked, args=(1, 0, str(tmp_path), task), nprocs=1, join=True)
+    mp.spawn(_run_masked, args=(2, port, str(tmp_path), task), nprocs=2, join=True)
+    mp.spawn(_run_masked, args=(4, port + 2, str(tmp_path), task), nprocs=4, join=True)
+    one = np.load(tmp_path / f"{task}_w1_r0.npz")
+    assert not np.array_equal(one["scale"], one["before"])
+    moved = np.abs(one["scale"] - one["before"]).max()
+    for world in (2, 4):
+        rs = [np.load(tmp_path / f"{task}_w{world}_r{r}.npz") for r in range(world)]
+        assert all(np.array_equal(rs[0]["scale"], r["scale"]) and np.array_equal(rs[0]["zp"], r["zp"]) for r in rs[1:])
+        assert np.array_equal(rs[0]["before"], one["before"])
+        assert np.abs(rs[0]["scale"] - one["scale"]).max() <= 0.02 * moved, (world, np.abs(rs[0]["scale"] - one["scale"]).max(), moved)
+        # Adam normalises every gradient by its own running magnitude: a parameter whose gradient is rounding noise moves by
+        # a fraction of lr either way, so the bound is in steps (6 steps of lr = 1e-3), not relative to the value
+        assert np.abs(rs[0]["zp"] - one["zp"]).max() <= 0.05 * 6 * 1e-3, (world, np.abs(rs[0]["zp"] - one["zp"]).max())

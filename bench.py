@@ -468,7 +468,7 @@ def calibration_extra(dev, rank, world, which):
          30 candidates, learn-scale 3 epochs (ptq_summ_quant.py:124-154).
     N > 1: the grid search is sharded (batch b on rank b mod N); the statistics / loss tables are all-gathered per candidate
     (calibration.gather_batch_table); learn-scale runs data-parallel inside each batch when the batch divides over the ranks
-    (TWC.learn_scale_sharded: configs 2 at batch 8, config 4's batches of 4 up to 4 ranks); the MSEFast searches run replicated (float64
+    (TWC.learn_scale_sharded: configs 2 at batch 8; config 4's batches of 4 on 8 ranks: one sample on each of the first four); the MSEFast searches run replicated (float64
     per-observer state), which the line says."""
     import logging
     from types import SimpleNamespace as NS
@@ -618,7 +618,9 @@ def calibration_extra(dev, rank, world, which):
                     "learn_scale": ("sequential Adam, one process" if world == 1 else
                                     ("sequential Adam, every step data-parallel inside the batch (kept-token targets sliced per rank, gradients summed)"
                                      if all(next(iter(b.values())).shape[0] % world == 0 for b in learn_in)
-                                     else "sequential Adam, replicated on every rank (the batch does not divide over the ranks)")),
+                                     else ("sequential Adam, the batch's samples on the first ranks, one each, zero gradients from the others"
+                                           if all(world % next(iter(b.values())).shape[0] == 0 for b in learn_in)
+                                           else "sequential Adam, replicated on every rank (the batch does not divide over the ranks)"))),
                     "n_gpus": world})
         return out
     finally:

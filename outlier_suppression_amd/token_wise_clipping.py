@@ -155,14 +155,23 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
     parameters agree to float rounding (~1e-6 relative), not bit for bit -- the single-GPU run itself is
     only within that of the reference.  The masked tasks (SQuAD's two heads over the attended tokens, summarisation over
     the valid decoder tokens) sum squared errors locally, divide by the full batch's element count and SUM the gradients.
-    Falls back to the replicated loop when the batch does not divide evenly (BART's batches of 4 on 8 ranks).
+    A batch smaller than the group (BART's batches of 4 on 8 ranks) gives its samples to the first ranks, one each; the
+    others exchange zero gradients.  Falls back to the replicated loop for any other uneven split.
     """
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     sizes = {next(iter(b.values())).shape[0] for b in fp_input}
-    if world == 1 or task_type not in ("glue", "squad", "squad_v2", "summ") or any(sz % world for sz in sizes):
+    # a batch either divides over the ranks, or it is smaller than the group and divides the group's size: then its B samples
+    # go to the first B ranks, one each, and the others take part in the gradient exchange with zeros (BART: batches of 4 on 8 ranks)
+    if world == 1 or task_type not in ("glue", "squad", "squad_v2", "summ") or len(sizes) != 1 or \
+            any(sz % world and not (sz < world and world % sz == 0) for sz in sizes):
         return learn_scale(trainer, fp_input, fp_output, config_quant_learn)
+    bsz = next(iter(sizes))
+    per = bsz // world if bsz % world == 0 else 1
+    lo, hi = min(rank * per, bsz), min((rank + 1) * per, bsz)
+    idle = hi == lo
+    summed = task_type != "glue" or bsz % world != 0      # local sums over the full batch's denominator, gradients SUMMED
     masked_task = task_type != "glue"
     # Masked tasks (token_wise_clipping.py:38-43): the targets are rows of the KEPT tokens of the whole batch and the MSE's
     # denominator is their number -- a rank's samples hold a data-dependent share of them.  Per batch, once, outside the
@@ -173,8 +182,6 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
         key = "decoder_attention_mask" if task_type == "summ" else "attention_mask"
         for batch in fp_input:
             counts = (batch[key] == 1).sum(1).cpu()
-            per = counts.numel() // world
-            lo, hi = rank * per, (rank + 1) * per
             spans.append((int(counts[:lo].sum()), int(counts[lo:hi].sum()), int(counts.sum())))
     model = trainer.model
     disable_all(model)
@@ -183,7 +190,7 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
     for _, q in _act_quantizers(model):
         q.enable_fake_quant()
         q.disable_observer()
-        q.numel_multiplier = world
+        q.numel_multiplier = bsz // per             # full-batch numel = local numel x (samples of the batch / samples here)
         quantizers.append(q)
         if isinstance(q, LSQPlusFakeQuantize):
             params += [q.scale, q.zero_point]
@@ -200,12 +207,18 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
     try:
         for _ in range(config_quant_learn["epoch"]):
             for i, batch in enumerate(fp_input):
-                per = next(iter(batch.values())).shape[0] // world
-                lo, hi = rank * per, (rank + 1) * per
                 local = {k: v[lo:hi] for k, v in batch.items()}
                 opt.zero_grad()
-                if not masked_task:
-                    loss = batch_loss(model(**local), local, fp_output[i][lo:hi])
+                if idle:
+                    loss = None
+                    for q in quantizers:              # the repair every forward applies to the parameters (fake_quant.py:188-191)
+                        q._sanitize()
+                elif not masked_task:
+                    if summed:
+                        got = model(**local)[0]
+                        loss = (got - fp_output[i][lo:hi]).square().sum() / fp_output[i].numel()
+                    else:
+                        loss = batch_loss(model(**local), local, fp_output[i][lo:hi])
                 else:
                     off, n_loc, n_tot = spans[i]
                     out = model(**local)
@@ -216,7 +229,8 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
                         keep = local["attention_mask"] == 1
                         loss = ((out[0][keep] - fp_output[i][0][off:off + n_loc]).square().sum() +
                                 (out[1][keep] - fp_output[i][1][off:off + n_loc]).square().sum()) / n_tot
-                loss.backward()
+                if loss is not None:
+                    loss.backward()
                 flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
                 if staged:
                     host = flat.cpu()
@@ -224,7 +238,7 @@ def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=
                     flat = host.to(flat.device)
                 else:
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-                if not masked_task:
+                if not summed:
                     flat /= world
                 for p, g, shp in zip(params, torch.split(flat, counts), shapes):
                     p.grad = g.reshape(shp)

@@ -237,10 +237,14 @@ def test_masked_learn_scale_two_ranks_equal_one(tmp_path, task, port):
     mp.spawn(_run_masked, args=(1, 0, str(tmp_path), task), nprocs=1, join=True)
     mp.spawn(_run_masked, args=(2, port, str(tmp_path), task), nprocs=2, join=True)
     mp.spawn(_run_masked, args=(4, port + 2, str(tmp_path), task), nprocs=4, join=True)
+    worlds = (2, 4)
+    if task == "summ":          # batches of 4 on 8 ranks: one sample on each of the first four, zeros from the others
+        mp.spawn(_run_masked, args=(8, port + 4, str(tmp_path), task), nprocs=8, join=True)
+        worlds = (2, 4, 8)
     one = np.load(tmp_path / f"{task}_w1_r0.npz")
     assert not np.array_equal(one["scale"], one["before"])
     moved = np.abs(one["scale"] - one["before"]).max()
-    for world in (2, 4):
+    for world in worlds:
         rs = [np.load(tmp_path / f"{task}_w{world}_r{r}.npz") for r in range(world)]
         assert all(np.array_equal(rs[0]["scale"], r["scale"]) and np.array_equal(rs[0]["zp"], r["zp"]) for r in rs[1:])
         assert np.array_equal(rs[0]["before"], one["before"])

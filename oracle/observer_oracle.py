@@ -196,16 +196,21 @@ class ObserverState:
 
     # observer.py:194-202 (also 228-236, 559-567)
     def _avg_update(self, cur_min, cur_max):
-        if self.max_val.size <= 1 and np.isinf(self.max_val).all():
-            mn, mx = np.asarray(cur_min), np.asarray(cur_max)
-        else:
-            c = F32(self.cnt) if self.max_val.dtype == F32 else np.float64(self.cnt)
-            mn = self.min_val * c + cur_min
-            mx = self.max_val * c + cur_max
+        # Each statistic keeps ITS OWN dtype (tensor * python int, tensor / python int): one-sided positive data under
+        # MSEFast leaves min_val a float32 zero beside a float64 max_val (observer.py:491-492), and observer.py:549 casts
+        # the next batch to min_val's dtype -- so such data is searched in fp32 in every batch (checked against the
+        # reference run live: min_val stays torch.float32).
+        first = self.max_val.size <= 1 and np.isinf(self.max_val).all()
+
+        def one(old, cur):
+            if first:
+                return np.asarray(cur)
+            c = F32(self.cnt) if old.dtype == F32 else np.float64(self.cnt)
+            return np.asarray(old * c + cur)
+        mn, mx = one(self.min_val, cur_min), one(self.max_val, cur_max)
         self.cnt += 1
-        d = F32(self.cnt) if np.asarray(mn).dtype == F32 else np.float64(self.cnt)
-        self.min_val = np.asarray(mn / d)
-        self.max_val = np.asarray(mx / d)
+        self.min_val = np.asarray(mn / (F32(self.cnt) if mn.dtype == F32 else np.float64(self.cnt)))
+        self.max_val = np.asarray(mx / (F32(self.cnt) if mx.dtype == F32 else np.float64(self.cnt)))
 
     # observer.py:143-144 (also 535-536)
     def _running_update(self, cur_min, cur_max):

@@ -528,7 +528,7 @@ def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
 
 class MseSearch:
     """One per-tensor MSEFast search between its begin and its commit (state on the device, what the launches need)."""
-    __slots__ = ("state", "x", "view", "lengths", "args", "elems")
+    __slots__ = ("state", "x", "view", "lengths", "args", "elems", "cur", "fp32_2d")
 
 
 def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,

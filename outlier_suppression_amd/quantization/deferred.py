@@ -64,6 +64,7 @@ class DeferredSites:
             self.launches += 1
         for obs, search, two_d, sink, cnt, rule in pending:
             obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink)
+            obs._note_batch_result(search)
         self.flushed_sites += len(pending)
         return len(pending)
 

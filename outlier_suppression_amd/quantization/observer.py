@@ -228,6 +228,27 @@ class MSEFastObserver(ObserverBase):
             mn, mx = cur.tolist()
             self.one_side_dist = "pos" if mn >= 0.0 else "neg" if mx <= 0.0 else "no"
 
+    def _reference_min_is_float64(self, two_d):
+        if not two_d:
+            return self.one_side_dist != "pos"
+        known = self.__dict__.get("_min_f64_known", False)
+        if not known:
+            flag = self.__dict__.get("_min_f64_flag")
+            known = flag is not None and bool(flag.item())        # one 4-byte read per call, only until it is set
+            object.__setattr__(self, "_min_f64_known", known)
+        return known
+
+    def _note_batch_result(self, search):
+        """After the commit of a 2-D search that ran on fp32 input: was this batch's best minimum the data's own minimum
+        (the reference then keeps a float32 min_val) or a searched number (float64 from here on)?  Device-side, no sync."""
+        if not getattr(search, "fp32_2d", False) or self.__dict__.get("_min_f64_known", False):
+            return
+        best = torch.tensor([float("inf"), float("-inf")], dtype=torch.float64, device=search.cur.device)
+        ops.msefast_tensor_commit(search, UPDATE_RUNNING, 0, best[0:1], best[1:2], None)      # running rule on (+inf, -inf): the batch's own result
+        inside = (best[0] != search.cur[0].to(torch.float64)).to(torch.int32).reshape(1)
+        flag = self.__dict__.get("_min_f64_flag")
+        object.__setattr__(self, "_min_f64_flag", inside if flag is None else torch.maximum(flag, inside))
+
     def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
         if observation_mask is not None:
             assert self.ch_axis == -1
@@ -237,21 +258,33 @@ class MSEFastObserver(ObserverBase):
         if self.ch_axis == -1:
             # observer.py:524 / 549: x is cast to min_val's dtype, and min_val is float64 once a per-tensor search has
             # stored its (float64) result -- from the second call on the reference searches on a float64 copy of x
-            float64_input = self.min_val.dtype == torch.float64
+            # WHEN min_val turns float64 is an accident of the reference's Python arithmetic, and parity follows it
+            # (oracle.msefast_search_1d / _2d, pinned against the reference run live):
+            #   * 1-D, non-negative data: min_val is the float32 zero of observer.py:491 in every batch -- never;
+            #   * 1-D otherwise: -torch.tensor(np.float64) -- from the second call on;
+            #   * 2-D: `max(tmp_min - shift, x_min)` (observer.py:479) hands back the float32 extremum when the searched
+            #     range reaches beyond it, so min_val stays float32 until one batch's best minimum lies INSIDE the data --
+            #     kept as a sticky device flag (`_note_batch_result`), read back once per call while it is still unset.
+            # (This package keeps both statistics float64 on the device; the numbers are the same.)
+            first_call = self.min_val.dtype != torch.float64
+            float64_input = (not first_call) and self._reference_min_is_float64(two_d)
             if self.min_val.dtype != torch.float64 or self.min_val.device != x.device:
                 self.min_val = self.min_val.to(device=x.device, dtype=torch.float64)
                 self.max_val = self.max_val.to(device=x.device, dtype=torch.float64)
             if DEFERRED is not None and self.__dict__.get("_defer_ok", False) and x.is_cuda:
                 # an observer pass (fake-quant off): the search joins the other searches of this forward in one launch
                 # (quantization/deferred.py); min_val / max_val / scale move at the flush
-                DEFERRED.add_mse(self, ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
-                                                                self.symmetric, self.one_side_dist, two_d, float64_input),
-                                 two_d, sink)
+                search = ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
+                                                  self.symmetric, self.one_side_dist, two_d, float64_input)
+                search.cur, search.fp32_2d = cur, (two_d and not float64_input)
+                DEFERRED.add_mse(self, search, two_d, sink)
             else:
-                self.last_nfev = ops.msefast_tensor(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
-                                                    self.symmetric, self.one_side_dist, two_d, self.update_rule,
-                                                    self._counter(), self.min_val, self.max_val, sink,
-                                                    float64_input=float64_input)
+                search = ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
+                                                  self.symmetric, self.one_side_dist, two_d, float64_input)
+                search.cur, search.fp32_2d = cur, (two_d and not float64_input)
+                ops.msefast_tensor_run(search, None, two_d)
+                self.last_nfev = ops.msefast_tensor_commit(search, self.update_rule, self._counter(), self.min_val, self.max_val, sink)
+                self._note_batch_result(search)
         else:
             bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
                                                           self.symmetric, self.one_side_dist, two_d)

@@ -303,3 +303,63 @@ def test_fused_step_vs_three_launches_random(dev):
                     torch.equal(torch.isnan(u), torch.isnan(v)), (case, (B, T, H), p)
     finally:
         ops.set_tuning("fused_step", 1)
+
+
+def test_other_observers_vs_oracle(eq32, dev):
+    """The remaining observers of ObserverDict on random small activations (masked and not, odd shapes, one-sided data,
+    several batches): AvgQuantileObserver (torch.histc-exact histogram + clip), MSEObserver / AvgMSEObserver (grid argmin),
+    MSEFastObserver / AvgMSEFastObserver per tensor (bounded Brent, float64 statistics from the second batch on)."""
+    from oracle import observer_oracle as OB
+    from outlier_suppression_amd.quantization.quantized_module import ObserverDict
+    rng = np.random.default_rng(2718)
+    for case in range(max(24, N_CASES // 16)):
+        cls = str(rng.choice(["AvgQuantileObserver", "MSEObserver", "AvgMSEObserver", "MSEFastObserver", "AvgMSEFastObserver"]))
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        B, T, H = int(rng.integers(1, 6)), int(rng.integers(1, 20)), int(rng.choice([1, 3, 8, 33, 64]))
+        masked = rng.random() < 0.6
+        side = str(rng.choice(["both", "both", "pos", "neg"]))
+        kw = {"threshold": float(rng.choice([0.99999, 0.999, 0.9]))} if cls == "AvgQuantileObserver" else {}
+        if cls == "AvgQuantileObserver":
+            sym = False
+        ob = ObserverDict[cls](bit=bit, symmetric=sym, **kw).to(dev)
+        st = OB.ObserverState(bit=bit, symmetric=sym)
+        for it in range(int(rng.integers(1, 4))):
+            x = (rng.standard_normal((B, T, H)) * rng.choice([0.1, 1.0, 20.0])).astype(np.float32)
+            x[..., 0] *= np.float32(6.0)
+            if side == "pos":
+                x = np.abs(x) + np.float32(1e-3)
+            elif side == "neg":
+                x = -np.abs(x) - np.float32(1e-3)
+            L = None
+            if masked:
+                L = rng.integers(1, T + 1, (B,)).astype(np.int64)
+                L[int(rng.integers(0, B))] = T
+            if it == 0:
+                loose = False
+            # observer.py:524 / 549: once min_val is float64 the batch is searched on a float64 copy; the loss is then a
+            # float64 sum whose order is the machine's (torch's in the reference, numpy's in the oracle, the grid's here):
+            # agreement to rounding of the loss (~1e-14 on the result, a Brent step apart at worst), not bit for bit
+            loose = loose or ("MSEFast" in cls and np.asarray(st.min_val).dtype == np.float64)
+            ob(torch.from_numpy(x).to(dev), None if L is None else torch.from_numpy(L).to(dev), 1 if masked else -1)
+            if cls == "AvgQuantileObserver":
+                OB.observe_avg_quantile(st, x, L, 1 if masked else -1, threshold=kw["threshold"])
+            elif cls in ("MSEObserver", "AvgMSEObserver"):
+                OB.observe_mse(st, x, L, 1 if masked else -1, average=cls.startswith("Avg"))
+            else:
+                OB.observe_msefast(st, x, L, 1 if masked else -1, average=cls.startswith("Avg"))
+            tag = (case, cls, bit, sym, (B, T, H), masked, side, it)
+            got_min, got_max = ob.min_val.cpu().numpy(), ob.max_val.cpu().numpy()
+            want_min, want_max = np.asarray(st.min_val), np.asarray(st.max_val)
+            if "MSEFast" in cls:
+                # float64 statistics (scipy's results; the reference's one-sided zero is a float32 zero, here a float64 one);
+                # the search itself is iterate-for-iterate equal, on fp32 or float64 input exactly when the reference's is
+                assert got_min.dtype == np.float64 and got_max.dtype == np.float64
+                if loose:
+                    np.testing.assert_allclose(got_min, want_min.astype(np.float64), rtol=1e-6, atol=0, err_msg=str(tag))
+                    np.testing.assert_allclose(got_max, want_max.astype(np.float64), rtol=1e-6, atol=0, err_msg=str(tag))
+                else:
+                    assert np.array_equal(got_min, want_min.astype(np.float64)) and np.array_equal(got_max, want_max.astype(np.float64)), \
+                        (tag, got_min, want_min, got_max, want_max)
+            else:
+                assert eq32(got_min, want_min.astype(np.float32)) and eq32(got_max, want_max.astype(np.float32)), \
+                    (tag, got_min, want_min, got_max, want_max)

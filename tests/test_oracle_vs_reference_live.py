@@ -158,6 +158,20 @@ def test_msefast_equals_reference_when_the_loss_is_summed_like_torch(ref):
                 ob(x * (it + 1))
                 OB.observe_msefast(st, x.numpy() * (it + 1), average=True)
                 assert float(st.min_val) == float(ob.min_val) and float(st.max_val) == float(ob.max_val), (sym, shape, it)
+        # one-sided data over four batches: the dtype of min_val decides whether the NEXT batch is searched on a float64
+        # copy (observer.py:524 / 549) -- float32 for ever on non-negative data (the zeros_like of :491), float64 from the
+        # second batch on otherwise; both observers, values and dtypes
+        for cls, avg in ((O.MSEFastObserver, False), (O.AvgMSEFastObserver, True)):
+            for side in ("pos", "neg"):
+                ob = cls(bit=6, symmetric=False, ch_axis=-1)
+                st = OB.ObserverState(bit=6, symmetric=False)
+                for it in range(4):
+                    x = torch.randn(3, 7, 16, generator=gen).abs() * (1.0 + 0.3 * it) + 1e-3
+                    x = x if side == "pos" else -x
+                    ob(x)
+                    OB.observe_msefast(st, x.numpy(), average=avg)
+                    assert float(st.min_val) == float(ob.min_val) and float(st.max_val) == float(ob.max_val), (cls.__name__, side, it)
+                    assert str(np.asarray(st.min_val).dtype) == str(ob.min_val.dtype).replace("torch.", ""), (cls.__name__, side, it)
     finally:
         OB.MEAN_LIKE_TORCH = old
 

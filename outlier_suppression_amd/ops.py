@@ -551,6 +551,8 @@ def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max
             view = token_view(x, seq_pos, lengths.numel())
     else:
         view, lengths = None, None
+    if view is None and x.data_ptr() % 16:
+        x = x.clone()          # the flat kernels read 16 bytes per lane: a misaligned buffer (a slice of a larger one) is copied once
     r.x, r.view, r.lengths, r.elems = x, view, lengths, x.numel()
     r.args = (int(quant_min), int(quant_max), int(bool(symmetric)))
     return r

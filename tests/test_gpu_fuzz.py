@@ -337,8 +337,10 @@ def test_other_observers_vs_oracle(eq32, dev):
             if it == 0:
                 loose = False
             # observer.py:524 / 549: once min_val is float64 the batch is searched on a float64 copy; the loss is then a
-            # float64 sum whose order is the machine's (torch's in the reference, numpy's in the oracle, the grid's here):
-            # agreement to rounding of the loss (~1e-14 on the result, a Brent step apart at worst), not bit for bit
+            # float64 sum whose order is the machine's (torch's in the reference, numpy's in the oracle, the grid's here).
+            # Usually ~1e-14 apart; but candidates of a staircase loss tie to that precision, and a tie broken the other way
+            # sends Brent down another path: the oracle alone moves by up to 1.3e-2 between summation orders (DESIGN.md
+            # section 2) -- the bound of tests/test_gpu_parity.py for these calls
             loose = loose or ("MSEFast" in cls and np.asarray(st.min_val).dtype == np.float64)
             ob(torch.from_numpy(x).to(dev), None if L is None else torch.from_numpy(L).to(dev), 1 if masked else -1)
             if cls == "AvgQuantileObserver":
@@ -355,11 +357,77 @@ def test_other_observers_vs_oracle(eq32, dev):
                 # the search itself is iterate-for-iterate equal, on fp32 or float64 input exactly when the reference's is
                 assert got_min.dtype == np.float64 and got_max.dtype == np.float64
                 if loose:
-                    np.testing.assert_allclose(got_min, want_min.astype(np.float64), rtol=1e-6, atol=0, err_msg=str(tag))
-                    np.testing.assert_allclose(got_max, want_max.astype(np.float64), rtol=1e-6, atol=0, err_msg=str(tag))
+                    np.testing.assert_allclose(got_min, want_min.astype(np.float64), rtol=3e-2, atol=0, err_msg=str(tag))
+                    np.testing.assert_allclose(got_max, want_max.astype(np.float64), rtol=3e-2, atol=0, err_msg=str(tag))
                 else:
                     assert np.array_equal(got_min, want_min.astype(np.float64)) and np.array_equal(got_max, want_max.astype(np.float64)), \
                         (tag, got_min, want_min, got_max, want_max)
             else:
                 assert eq32(got_min, want_min.astype(np.float32)) and eq32(got_max, want_max.astype(np.float32)), \
                     (tag, got_min, want_min, got_max, want_max)
+
+
+def test_deferred_forwards_vs_oracle(eq32, dev):
+    """Observer passes as calibrate() runs them: the sites of a forward recorded and reduced together
+    (quantization/deferred.py) -- random groups of sites (layouts, masks, observers, MSEFast searches among them), several
+    forwards, every statistic and parameter against the oracle."""
+    from oracle import observer_oracle as OB
+    from outlier_suppression_amd.quantization import Quantizer
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    rng = np.random.default_rng(60606)
+    fns = {"AvgPruneMinMaxObserver": OB.observe_avg_prune_minmax, "AvgMinMaxObserver": OB.observe_avg_minmax,
+           "MinMaxObserver": OB.observe_minmax}
+    for case in range(max(20, N_CASES // 16)):
+        sites = []
+        for k in range(int(rng.integers(1, 7))):
+            kind, shape, seq_pos = _draw_shape(rng)
+            observer = str(rng.choice(list(fns) + (["AvgMSEFastObserver"] if rng.random() < 0.3 else [])))
+            bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+            name = f"layer{k}.attention_probs_post_act_fake_quantize.observer" if kind in ("probs", "probs3d") else f"layer{k}.x_post_act_fake_quantize.observer"
+            masked = seq_pos != -1 and rng.random() < 0.8
+            q = Quantizer(None, NS(quantizer=str(rng.choice(["FixedFakeQuantize", "LSQPlusFakeQuantize"])), observer=observer,
+                                   bit=bit, symmetric=sym, ch_axis=-1)).to(dev)
+            q.observer.set_name(name)
+            pct = float(rng.choice([1.0, 0.95, 0.71]))
+            if hasattr(q.observer, "set_percentile"):
+                q.observer.set_percentile(pct)
+            q.enable_observer()
+            q.disable_fake_quant()
+            st = OB.ObserverState(bit=bit, symmetric=sym, name=name)
+            st.percentile = pct
+            sites.append([q, st, kind, shape, seq_pos, observer, masked, False])
+        with deferred_observation() as rec:
+            for it in range(int(rng.integers(1, 4))):
+                fed = []
+                for q, st, kind, shape, seq_pos, observer, masked, _ in sites:
+                    x_np = _draw_values(rng, shape, str(rng.choice(["normal", "outlier", "positive", "duplicates"])))
+                    x, _ = _as_view(rng, x_np, kind, dev)
+                    L_np = None
+                    if masked:
+                        Tn = shape[seq_pos]
+                        n_mask = shape[0] if kind != "probs3d" else max(1, shape[0] // int(rng.integers(1, 5)))
+                        L_np = rng.integers(0, Tn + 1, (n_mask,)).astype(np.int64)
+                        L_np[int(rng.integers(0, n_mask))] = Tn
+                    assert q(x, None if L_np is None else torch.from_numpy(L_np).to(dev), seq_pos) is x
+                    fed.append((x_np, L_np))
+                rec.flush()
+                for site, (x_np, L_np) in zip(sites, fed):
+                    q, st, kind, shape, seq_pos, observer, masked, loose = site
+                    tag = (case, it, kind, shape, seq_pos, observer, masked)
+                    if observer == "AvgMSEFastObserver":
+                        # fp32-input batches are bit-equal (also later ones, while the reference's min_val stays float32);
+                        # a float64-input batch agrees to the oracle's own order sensitivity, and so does the mean after it
+                        loose = site[7] = loose or np.asarray(st.min_val).dtype == np.float64
+                        OB.observe_msefast(st, x_np, L_np, seq_pos, average=True)
+                        got = (q.observer.min_val.cpu().numpy(), q.observer.max_val.cpu().numpy())
+                        want = (np.asarray(st.min_val, dtype=np.float64), np.asarray(st.max_val, dtype=np.float64))
+                        if loose:
+                            np.testing.assert_allclose(got[0], want[0], rtol=3e-2, err_msg=str(tag))
+                            np.testing.assert_allclose(got[1], want[1], rtol=3e-2, err_msg=str(tag))
+                        else:
+                            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (tag, got, want)
+                        continue
+                    fns[observer](st, x_np, L_np, seq_pos)
+                    assert eq32(q.observer.min_val.cpu().numpy(), st.min_val) and eq32(q.observer.max_val.cpu().numpy(), st.max_val), tag
+                    scale, zp = st.qparams()
+                    assert np.float32(q.scale.item()) == np.float32(scale) and np.float32(q.zero_point.item()) == np.float32(zp), tag

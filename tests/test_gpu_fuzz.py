@@ -438,3 +438,71 @@ def test_deferred_forwards_vs_oracle(eq32, dev):
                     assert eq32(q.observer.min_val.cpu().numpy(), st.min_val) and eq32(q.observer.max_val.cpu().numpy(), st.max_val), tag
                     scale, zp = st.qparams()
                     assert np.float32(q.scale.item()) == np.float32(scale) and np.float32(q.zero_point.item()) == np.float32(zp), tag
+
+
+def test_gamma_ops_vs_oracle(eq32, dev):
+    """Gamma-Migration arithmetic (gamma_migration.py:70-71, util_layernorm.py:27, 49-52) on odd sizes and misaligned
+    buffers: weight fold in place, beta / gamma, input * gamma + hidden."""
+    from oracle import gamma_oracle as GO
+    from outlier_suppression_amd import ops
+    rng = np.random.default_rng(5150)
+    for case in range(max(40, N_CASES // 8)):
+        rows, cols = int(rng.integers(1, 70)), int(rng.choice([1, 2, 3, 4, 7, 8, 33, 64, 100, 768]))
+        w_np = rng.standard_normal((rows, cols)).astype(np.float32)
+        g_np = (rng.standard_normal(cols) * 0.5 + 1.0).astype(np.float32)
+        b_np = rng.standard_normal(cols).astype(np.float32)
+        w, _ = _as_view(rng, w_np, "bth", dev)
+        w = w.clone() if not w.is_contiguous() else w
+        ops.gamma_fold_(w, torch.from_numpy(g_np).to(dev))
+        assert eq32(w.cpu().numpy(), GO.fold_gamma_into_weight(w_np, g_np)), (case, rows, cols, "fold")
+        assert eq32(ops.gamma_split_bias(torch.from_numpy(b_np).to(dev), torch.from_numpy(g_np).to(dev)).cpu().numpy(),
+                    GO.split_bias(b_np, g_np)), (case, "split")
+        shape = tuple(int(v) for v in rng.integers(1, 6, size=int(rng.integers(1, 3)))) + (cols,)
+        x_np, h_np = rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)
+        x, _ = _as_view(rng, x_np, "bth", dev)
+        h, _ = _as_view(rng, h_np, "bth", dev)
+        for gamma in (None, g_np):
+            got = ops.gamma_residual(x, h, None if gamma is None else torch.from_numpy(gamma).to(dev))
+            assert eq32(got.cpu().numpy(), GO.gamma_residual(x_np, h_np, gamma)), (case, shape, gamma is None)
+
+
+def test_per_channel_learnable_vs_oracle(eq32, dev):
+    """LSQ / LSQ+ quantizers on the channel axis 0 (weights): forward against the oracle's per-channel chain, backward row by
+    row against the per-tensor closed form with the row's parameters and the per-channel grad factor
+    (fake_quant.py:195-206: 1 / sqrt(numel / C * quant_max))."""
+    from oracle import fake_quant_oracle as FQ
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(8086)
+    for case in range(max(20, N_CASES // 16)):
+        C, inner = int(rng.integers(1, 20)), int(rng.choice([1, 3, 4, 8, 33, 64, 200]))
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        w_np = (rng.standard_normal((C, inner)) * rng.choice([0.05, 1.0])).astype(np.float32)
+        lin = torch.nn.Linear(inner, C)
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(w_np))
+        qm = Quantizer(lin, NS(quantizer="LSQPlusFakeQuantize", observer="MinMaxObserver", bit=bit, symmetric=sym, ch_axis=0)).to(dev)
+        fq = qm.weight_fake_quant
+        fq.enable_observer(); fq.enable_fake_quant()
+        with torch.no_grad():
+            fq(qm.weight)                                      # observe: per-row parameters
+        fq.disable_observer()
+        s_np, z_np = fq.scale.detach().cpu().numpy().copy(), fq.zero_point.detach().cpu().numpy().copy()
+        assert s_np.shape == (C,) and z_np.shape == (C,)
+        wg = qm.weight.detach().clone().requires_grad_(True)
+        gy_np = rng.standard_normal((C, inner)).astype(np.float32)
+        out = fq(wg)
+        out.backward(torch.from_numpy(gy_np).to(dev))
+        s_rep = np.maximum(np.abs(s_np), np.float32(1.1920928955078125e-07)).astype(np.float32)
+        z_rep = np.clip(z_np, np.float32(fq.quant_min), np.float32(fq.quant_max)).astype(np.float32)
+        g = FQ.lsqplus_grad_factor(w_np.size, fq.quant_max, channels=C)
+        _, ref = FQ.fake_quantize_learnableplus_per_channel(w_np, s_rep, z_rep, 0, fq.quant_min, fq.quant_max, g)
+        tag = (case, C, inner, bit, sym)
+        assert eq32(out.detach().cpu().numpy(), ref), (tag, "forward")
+        dx_rows, ds_rows, dz_rows = [], [], []
+        for c in range(C):
+            dx, ds, dz = FQ.lsqplus_backward_per_tensor(w_np[c], gy_np[c], s_rep[c:c + 1], z_rep[c:c + 1], fq.quant_min, fq.quant_max, g)
+            dx_rows.append(dx); ds_rows.append(ds); dz_rows.append(dz)
+        assert eq32(wg.grad.cpu().numpy(), np.stack(dx_rows)), (tag, "dx")
+        mag = np.abs(gy_np).sum(1).astype(np.float64) * g
+        assert (np.abs(fq.scale.grad.cpu().numpy() - np.array(ds_rows)) <= 2e-5 * np.abs(ds_rows) + 2e-6 * mag * 2 ** bit).all(), (tag, "dscale")
+        assert (np.abs(fq.zero_point.grad.cpu().numpy() - np.array(dz_rows)) <= 2e-5 * np.abs(dz_rows) + 2e-6 * mag * s_rep).all(), (tag, "dzp")

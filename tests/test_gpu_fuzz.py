@@ -506,3 +506,103 @@ def test_per_channel_learnable_vs_oracle(eq32, dev):
         mag = np.abs(gy_np).sum(1).astype(np.float64) * g
         assert (np.abs(fq.scale.grad.cpu().numpy() - np.array(ds_rows)) <= 2e-5 * np.abs(ds_rows) + 2e-6 * mag * 2 ** bit).all(), (tag, "dscale")
         assert (np.abs(fq.zero_point.grad.cpu().numpy() - np.array(dz_rows)) <= 2e-5 * np.abs(dz_rows) + 2e-6 * mag * s_rep).all(), (tag, "dzp")
+
+
+def test_cached_search_equals_literal_random_models(dev):
+    """find_ratio_cached against the literal find_ratio (token_wise_clipping.py:50-66) on random tiny BERT / RoBERTa / BART
+    models with random batch geometries, masks and grids: same percentile, same per-candidate losses, bit-equal parameters,
+    same switches left behind."""
+    import logging
+    import transformers as T
+    from outlier_suppression_amd import token_wise_clipping as TWC
+    from outlier_suppression_amd.gamma_migration import delay_ln
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
+    from outlier_suppression_amd.quantization.state import set_observer_name
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    rng = np.random.default_rng(1999)
+    a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+
+    class Grab(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.losses = []
+
+        def emit(self, record):
+            m = record.getMessage()
+            if m.startswith("the ratio is"):
+                self.losses.append(float(m.split("the loss is")[1]))
+    saved = (TWC.task_type, TWC.model_type)
+    try:
+        for case in range(max(4, N_CASES // 160)):
+            kind = str(rng.choice(["bert", "roberta", "bart"]))
+            heads = int(rng.choice([1, 2, 4]))
+            hidden = heads * int(rng.choice([8, 16]))
+            layers = int(rng.integers(1, 3))
+            torch.manual_seed(int(rng.integers(0, 10 ** 6)))
+            common = dict(vocab_size=90, max_position_embeddings=48)
+            if kind == "bart":
+                fp = T.BartForConditionalGeneration(T.BartConfig(d_model=hidden, encoder_layers=layers, decoder_layers=layers,
+                                                                 encoder_attention_heads=heads, decoder_attention_heads=heads,
+                                                                 encoder_ffn_dim=2 * hidden, decoder_ffn_dim=2 * hidden, dropout=0.0,
+                                                                 attention_dropout=0.0, activation_dropout=0.0, **common))
+                task = "summ"
+            elif kind == "roberta":
+                fp = T.RobertaForSequenceClassification(T.RobertaConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                                                                        intermediate_size=2 * hidden, hidden_dropout_prob=0.0,
+                                                                        attention_probs_dropout_prob=0.0, type_vocab_size=1, pad_token_id=1,
+                                                                        num_labels=3, **common))
+                task = "glue"
+            else:
+                fp = T.BertForSequenceClassification(T.BertConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                                                                  intermediate_size=2 * hidden, hidden_dropout_prob=0.0,
+                                                                  attention_probs_dropout_prob=0.0, type_vocab_size=2, num_labels=2, **common))
+                task = "glue"
+            fp = fp.eval().to(dev)
+            B, Tn, n_batches = int(rng.integers(1, 6)), int(rng.integers(4, 20)), int(rng.integers(1, 4))
+            Td = int(rng.integers(2, 9))
+            batches = []
+            for _ in range(n_batches):
+                L = rng.integers(1, Tn + 1, (B,)); L[int(rng.integers(0, B))] = Tn
+                mask = (np.arange(Tn)[None, :] < L[:, None]).astype(np.int64)
+                ids = rng.integers(5, 85, (B, Tn)) * mask + (1 - mask)
+                b = {"input_ids": torch.from_numpy(ids).to(dev), "attention_mask": torch.from_numpy(mask).to(dev)}
+                if kind == "bert":
+                    b["token_type_ids"] = torch.zeros_like(b["input_ids"])
+                if kind == "bart":
+                    DL = rng.integers(1, Td + 1, (B,)); DL[int(rng.integers(0, B))] = Td
+                    dm = (np.arange(Td)[None, :] < DL[:, None]).astype(np.int64)
+                    b["decoder_input_ids"] = torch.from_numpy(rng.integers(5, 85, (B, Td)) * dm + (1 - dm)).to(dev)
+                    b["decoder_attention_mask"] = torch.from_numpy(dm).to(dev)
+                batches.append(b)
+            grid = {"iters": int(rng.integers(2, 6)), "step": float(rng.choice([0.01, 0.05, 0.1]))}
+            TWC.task_type, TWC.model_type = task, kind
+            results = []
+            for fn in (TWC.find_ratio, TWC.find_ratio_cached):
+                model = quantize_model(fp, w_q, a_q).to(dev)
+                with torch.no_grad():
+                    if task == "summ":
+                        fp_output = [model(**b)[0][b["decoder_attention_mask"] == 1, :].detach() for b in batches]
+                    else:
+                        fp_output = [model(**b)[0].detach() for b in batches]
+                model = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type=kind, task_type=task))
+                enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+                with torch.no_grad():
+                    model(**batches[0])
+                disable_all(model)
+                set_observer_name(model)
+                h = Grab()
+                TWC.logger.addHandler(h)
+                TWC.logger.setLevel(logging.INFO)
+                ratio = fn(NS(model=model), batches, fp_output, grid)
+                TWC.logger.removeHandler(h)
+                qs = [m for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
+                results.append((ratio, h.losses, [m.scale.detach().clone() for m in qs], [m.zero_point.detach().clone() for m in qs],
+                                [m.observer.cnt for m in qs], [(m.observer_enabled, m.fake_quant_enabled) for m in qs]))
+            (r0, l0, s0, z0, c0, f0), (r1, l1, s1, z1, c1, f1) = results
+            tag = (case, kind, heads, hidden, layers, B, Tn, n_batches, grid)
+            assert r0 == r1 and l0 == l1 and c0 == c1 and f0 == f1, (tag, r0, r1, l0, l1)
+            assert all(torch.equal(a, b) for a, b in zip(s0, s1)) and all(torch.equal(a, b) for a, b in zip(z0, z1)), tag
+    finally:
+        TWC.task_type, TWC.model_type = saved

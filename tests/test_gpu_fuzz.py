@@ -606,3 +606,66 @@ def test_cached_search_equals_literal_random_models(dev):
             assert all(torch.equal(a, b) for a, b in zip(s0, s1)) and all(torch.equal(a, b) for a, b in zip(z0, z1)), tag
     finally:
         TWC.task_type, TWC.model_type = saved
+
+
+def test_state_dict_and_copies(dev):
+    """Calibrated quantizers survive state_dict -> fresh module -> load_state_dict (fake_quant.py:59-97 resizes scale /
+    zero_point to the stored shape) and copy.deepcopy: same keys, dtypes, shapes, values, and the same quantised output."""
+    import copy
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(4711)
+    for case in range(max(30, N_CASES // 16)):
+        weight = rng.random() < 0.4
+        quantizer = str(rng.choice(["FixedFakeQuantize", "LSQFakeQuantize", "LSQPlusFakeQuantize"]))
+        bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
+        if weight:
+            observer = str(rng.choice(["MinMaxObserver", "MSEFastObserver", "LSQPlusObserver"]))
+            if observer == "LSQPlusObserver":
+                sym = True
+            ch_axis = int(rng.choice([0, -1]))
+            x = torch.from_numpy((rng.standard_normal((int(rng.integers(1, 9)), int(rng.choice([4, 12, 64])))) * 0.1).astype(np.float32)).to(dev)
+            args = (x,)
+        else:
+            observer = str(rng.choice(["MinMaxObserver", "AvgMinMaxObserver", "AvgPruneMinMaxObserver", "AvgMSEFastObserver", "AvgQuantileObserver"]))
+            if observer == "AvgQuantileObserver":
+                sym = False
+            ch_axis = -1
+            B, T, H = int(rng.integers(1, 5)), int(rng.integers(2, 12)), int(rng.choice([8, 33, 64]))
+            x = torch.from_numpy(rng.standard_normal((B, T, H)).astype(np.float32)).to(dev)
+            L = torch.from_numpy(rng.integers(1, T + 1, (B,)).astype(np.int64)).to(dev)
+            args = (x, L, 1)
+        cfg = NS(quantizer=quantizer, observer=observer, bit=bit, symmetric=sym, ch_axis=ch_axis)
+        tag = (case, quantizer, observer, bit, sym, ch_axis, tuple(x.shape))
+
+        def build():
+            q = Quantizer(None, cfg).to(dev)
+            q.observer.set_name("layer.x_post_act_fake_quantize.observer")
+            if hasattr(q.observer, "set_percentile"):
+                q.observer.set_percentile(0.9)
+            return q
+        q = build()
+        q.enable_observer(); q.enable_fake_quant()
+        with torch.no_grad():
+            for _ in range(int(rng.integers(1, 3))):
+                q(*args)
+        q.disable_observer()
+        with torch.no_grad():
+            ref = q(*args)
+        sd = q.state_dict()
+        fresh = build()
+        assert set(fresh.state_dict()) == set(sd), tag
+        fresh.load_state_dict(copy.deepcopy(sd))
+        fresh.disable_observer(); fresh.enable_fake_quant()
+        twin = copy.deepcopy(q)
+        for other, what in ((fresh, "loaded"), (twin, "deepcopy")):
+            osd = other.state_dict()
+            for k, v in sd.items():
+                # load_state_dict copies INTO the fresh module's float32 statistic buffers (torch's copy_, in the reference as
+                # well): a float64 MSEFast statistic arrives rounded to float32; everything else keeps its dtype
+                if what == "loaded" and v.dtype == torch.float64:
+                    assert osd[k].dtype == torch.float32 and torch.equal(osd[k].cpu(), v.cpu().float()), (tag, what, k, osd[k], v)
+                    continue
+                assert osd[k].dtype == v.dtype and osd[k].shape == v.shape and torch.equal(osd[k].cpu(), v.cpu()), (tag, what, k, osd[k], v)
+            with torch.no_grad():
+                got = other(*args)
+            assert torch.equal(got, ref), (tag, what)

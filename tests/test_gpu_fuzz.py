@@ -669,3 +669,54 @@ def test_state_dict_and_copies(dev):
             with torch.no_grad():
                 got = other(*args)
             assert torch.equal(got, ref), (tag, what)
+
+
+def test_fused_sites_vs_eager(dev):
+    """The two fused producer sites against the eager sequences they replace, on random shapes and misaligned buffers:
+    GELU + fake-quant (bit-identical to F.gelu followed by the fake-quant launch) and residual + LayerNorm + shift +
+    fake-quant (the normalisation within 4e-6 of torch's, the quantised output at most one step away and only next to
+    a rounding boundary)."""
+    import torch.nn.functional as F
+    from outlier_suppression_amd import ops
+    rng = np.random.default_rng(1234567)
+    for case in range(max(30, N_CASES // 16)):
+        shape = tuple(int(v) for v in rng.integers(1, 9, size=int(rng.integers(1, 3)))) + (int(rng.choice([1, 3, 4, 64, 100, 768, 3072])),)
+        x_np = (rng.standard_normal(shape) * rng.choice([0.5, 3.0])).astype(np.float32)
+        x, _ = _as_view(rng, x_np, "bth", dev)
+        s = torch.tensor([float(rng.uniform(0.01, 0.3))], device=dev)
+        z = torch.tensor([float(rng.integers(0, 64))], device=dev)
+        mode = int(rng.choice([ops.PARAM_FIXED, ops.PARAM_LSQPLUS]))
+        got = ops.gelu_fake_quant_per_tensor(x, s, z, 0, 63, mode, 1e-3)
+        want = ops.fake_quant_per_tensor(F.gelu(x), s, z, 0, 63, mode, 1e-3)
+        assert torch.equal(got, want), (case, shape, "gelu")
+        H = int(rng.choice([4, 64, 260, 768, 1024]))
+        lshape = tuple(int(v) for v in rng.integers(1, 7, size=int(rng.integers(1, 3)))) + (H,)
+        a = torch.from_numpy((rng.standard_normal(lshape) * 2).astype(np.float32)).to(dev)
+        hid = torch.from_numpy(rng.standard_normal(lshape).astype(np.float32)).to(dev)
+        gamma = torch.from_numpy((rng.random(H) + 0.5).astype(np.float32)).to(dev)
+        w = torch.from_numpy((rng.random(H) + 0.5).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rng.standard_normal(H).astype(np.float32)).to(dev)
+        use_hid, use_gamma, use_w, use_b = (bool(v) for v in rng.integers(0, 2, 4))
+        eps = float(rng.choice([1e-5, 1e-12]))
+        r = a
+        if use_hid:
+            r = (a * gamma if use_gamma else a) + hid
+        n = F.layer_norm(r, (H,), w if use_w else None, None, eps)
+        if use_b:
+            n = n + b
+        quant = (s, z, 0, 63, mode, 1e-3)
+        plain = ops.residual_layernorm_fake_quant(a, hid if use_hid else None, gamma if (use_hid and use_gamma) else None,
+                                                  w if use_w else None, b if use_b else None, eps, None)
+        fused = ops.residual_layernorm_fake_quant(a, hid if use_hid else None, gamma if (use_hid and use_gamma) else None,
+                                                  w if use_w else None, b if use_b else None, eps, quant)
+        tag = (case, lshape, use_hid, use_gamma, use_w, use_b, eps)
+        tol = 4e-6 * max(1.0, float(n.abs().max()))
+        assert float((plain - n).abs().max()) <= tol, (tag, float((plain - n).abs().max()))
+        assert torch.equal(fused, ops.fake_quant_per_tensor(plain, s, z, 0, 63, mode, 1e-3)), (tag, "own normalisation")
+        eager_q = ops.fake_quant_per_tensor(n, s, z, 0, 63, mode, 1e-3)
+        differ = fused != eager_q
+        if bool(differ.any()):
+            step = float(s.item())
+            assert float((fused - eager_q).abs().max()) <= step * 1.0001, tag
+            u = (n / s)[differ]
+            assert float(((u - torch.floor(u)) - 0.5).abs().max()) <= 2 * tol / step + 1e-4, tag   # only next to a rounding boundary

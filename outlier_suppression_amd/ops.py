@@ -147,6 +147,8 @@ def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max
     _check_f32(x, grad_out, scale)
     if not is_dense(x):
         x = x.contiguous()
+    elif x.data_ptr() % 16:
+        x = x.clone()              # the kernel reads 16 bytes per lane: a misaligned saved input (a slice of a larger buffer) is copied once
     g = _like_layout(grad_out, x)
     dx = torch.empty_like(x)
     ds = torch.empty(1, dtype=torch.float32, device=x.device) if need_scale else None

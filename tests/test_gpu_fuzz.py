@@ -135,7 +135,7 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
         if quantizer == "LSQPlusFakeQuantize":
             # frozen parameters, autograd on: dx bit for bit, the two parameter gradients to summation order
             q.disable_observer()
-            xg = x.detach().clone().requires_grad_(True)
+            xg = x.detach().requires_grad_(True)          # the view itself: permuted or 4 bytes off alignment
             gy_np = rng.standard_normal(shape).astype(np.float32)
             s0, z0 = q.scale.detach().cpu().numpy().copy(), q.zero_point.detach().cpu().numpy().copy()
             out = q(xg, None, seq_pos)

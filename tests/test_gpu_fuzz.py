@@ -720,3 +720,43 @@ def test_fused_sites_vs_eager(dev):
             assert float((fused - eager_q).abs().max()) <= step * 1.0001, tag
             u = (n / s)[differ]
             assert float(((u - torch.floor(u)) - 0.5).abs().max()) <= 2 * tol / step + 1e-4, tag   # only next to a rounding boundary
+
+
+def test_quantized_operator_arguments(eq32, dev):
+    """QLinear / QConv2d / QEmbedding keep the wrapped module's arguments (quantized_module.py:23-58: bias or not, stride,
+    padding, dilation, groups, padding_idx): the quantized operator equals the stock functional on the fake-quantised weight."""
+    import torch.nn.functional as F
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(31415)
+    cfg = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
+    for case in range(max(30, N_CASES // 16)):
+        kind = str(rng.choice(["linear", "conv", "embedding"]))
+        torch.manual_seed(int(rng.integers(0, 10 ** 6)))
+        if kind == "linear":
+            mod = torch.nn.Linear(int(rng.integers(1, 40)), int(rng.integers(1, 20)), bias=bool(rng.integers(0, 2)))
+            x = torch.randn(int(rng.integers(1, 5)), int(rng.integers(1, 6)), mod.in_features)
+        elif kind == "conv":
+            groups = int(rng.choice([1, 2]))
+            cin, cout = groups * int(rng.integers(1, 4)), groups * int(rng.integers(1, 5))
+            mod = torch.nn.Conv2d(cin, cout, int(rng.choice([1, 3])), stride=int(rng.choice([1, 2])), padding=int(rng.choice([0, 1])),
+                                  dilation=int(rng.choice([1, 2])), groups=groups, bias=bool(rng.integers(0, 2)))
+            x = torch.randn(int(rng.integers(1, 4)), cin, 9, 11)
+        else:
+            n = int(rng.integers(3, 30))
+            mod = torch.nn.Embedding(n, int(rng.choice([4, 9, 32])), padding_idx=(int(rng.integers(0, n)) if rng.random() < 0.5 else None))
+            x = torch.randint(0, n, (int(rng.integers(1, 5)), int(rng.integers(1, 9))))
+        qm = Quantizer(mod, cfg).to(dev)
+        fq = qm.weight_fake_quant
+        fq.enable_observer(); fq.enable_fake_quant()
+        with torch.no_grad():
+            got = qm(x.to(dev))
+            wq = fq(qm.weight)
+            b = None if getattr(qm, "bias", None) is None else qm.bias
+            if kind == "linear":
+                want = F.linear(x.to(dev), wq, b)
+            elif kind == "conv":
+                want = F.conv2d(x.to(dev), wq, b, mod.stride, mod.padding, mod.dilation, mod.groups)
+            else:
+                want = F.embedding(x.to(dev), wq, mod.padding_idx)
+        assert got.shape == want.shape and torch.equal(got, want), (case, kind, mod)
+        assert torch.equal(qm.weight.cpu(), mod.weight.detach()) and (b is None) == (getattr(mod, "bias", None) is None), (case, kind)

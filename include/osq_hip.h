@@ -405,11 +405,17 @@ int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs,
                                     const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                     void* workspace, osq_stream stream);
 int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
+/* ref_float64 (nullable): int32[2] on the device, zero before the observer's first commit -- whether the REFERENCE's
+ * min_val / max_val hold float64 by now.  Its per-tensor results are float64 except the float32 zeros_like of a one-sided
+ * search (observer.py:491-492) and the float32 extremum that Python's max / min hand back when the nested search's range
+ * reaches beyond the data (observer.py:479-480); while a statistic is float32 its running mean is fp32 arithmetic, while
+ * both are, calculate_qparams is, and observer.py:524 / 549 cast the NEXT batch to min_val's dtype: the caller reads
+ * ref_float64[0] for osq_msefast_tensor_begin's float64_input.  NULL: float64 throughout. */
 int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt,
                               double* min_val, double* max_val,
                               int quant_min, int quant_max, int symmetric,
                               float* scale_out, void* zero_point_out, int zp_type,
-                              int32_t* nfev, osq_stream stream);
+                              int32_t* nfev, int32_t* ref_float64, osq_stream stream);
 
 /* ------------------------------------------------------------------ remaining observers of ObserverDict */
 

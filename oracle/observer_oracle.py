@@ -20,14 +20,16 @@ def quant_range(bit, symmetric):
 
 
 def calculate_qparams(min_val, max_val, quant_min, quant_max, symmetric):
-    """observer.py:101-119.  Works in the dtype of ``min_val`` (fp32, or fp64 inside MSEFast).
+    """observer.py:101-119.  Works in the promoted dtype of the two statistics, as torch's 0-dim / same-shape type promotion
+    does: fp32, or float64 as soon as EITHER is float64 (per-tensor MSEFast: a float32 min_val beside a float64 max_val
+    -- checked against the reference run live).
 
     Returns (scale, zero_point); zero_point is int32 zeros when symmetric
     (observer.py:109) and a float array otherwise (observer.py:117-118).
     """
     min_val = np.asarray(min_val)
     max_val = np.asarray(max_val)
-    dt = min_val.dtype if min_val.dtype.kind == "f" else F32
+    dt = np.dtype(np.float64) if np.float64 in (min_val.dtype, max_val.dtype) else (min_val.dtype if min_val.dtype.kind == "f" else np.dtype(F32))
     zero = dt.type(0)
     min_neg = np.minimum(min_val.astype(dt), zero)
     max_pos = np.maximum(max_val.astype(dt), zero)

@@ -491,26 +491,65 @@ __global__ void msefast_valid_count_kernel(const int64_t* __restrict__ lengths, 
 // commit a finished per-tensor search: running min/max (observer.py:535-536) or running mean
 // (observer.py:559-567) in float64 -- per-tensor results stay float64 in the reference
 // (torch.tensor(np.float64), observer.py:481,494) -- then qparams in float64 (observer.py:101-119).
+// ref_f64 (nullable: both statistics float64 from the start): int[2] = does the REFERENCE's min_val / max_val hold float64 by
+// now.  Its per-tensor results are np.float64 wrapped in tensors -- except where Python hands back a float32 tensor: the
+// zeros_like of a one-sided search (observer.py:491-492) and the extremum itself when the nested search's range reaches
+// beyond the data (`max(tmp_min - shift, x_min)`, observer.py:479-480).  torch.min / `* cnt + cur` / `/ cnt` then stay
+// float32 until a float64 value joins (type promotion of 0-dim tensors), the running mean of such a statistic is fp32
+// arithmetic, and calculate_qparams runs in fp32 while BOTH are float32.  Followed here operation by operation; the flags
+// are sticky and the host reads [0] to know whether the next batch is cast to float64 (observer.py:524 / 549).
+__device__ __forceinline__ double avg_step(double old, bool old_f64, double cur, bool new_f64, int64_t cnt) {
+    const double prod = old_f64 ? old * static_cast<double>(cnt)
+                                : static_cast<double>(static_cast<float>(old) * static_cast<float>(cnt));
+    const double sum = new_f64 ? prod + cur : static_cast<double>(static_cast<float>(prod) + static_cast<float>(cur));
+    return new_f64 ? sum / static_cast<double>(cnt + 1)
+                   : static_cast<double>(static_cast<float>(sum) / static_cast<float>(cnt + 1));
+}
+
 __global__ void msefast_commit_kernel(const TensorSearch* __restrict__ ts, int rule, int64_t cnt,
                                       double* __restrict__ min_val, double* __restrict__ max_val, int quant_min,
                                       int quant_max, int symmetric, float* __restrict__ scale_out,
-                                      void* __restrict__ zp_out, int zp_type, int* __restrict__ nfev_out) {
+                                      void* __restrict__ zp_out, int zp_type, int* __restrict__ nfev_out,
+                                      int* __restrict__ ref_f64) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double bmin = ts->S.best_min, bmax = ts->S.best_max;
+    const Search& S = ts->S;
+    const double bmin = S.best_min, bmax = S.best_max;
+    bool cur_min_f64 = true, cur_max_f64 = true, old_min_f64 = true, old_max_f64 = true;
+    if (ref_f64) {
+        old_min_f64 = ref_f64[0] != 0;
+        old_max_f64 = ref_f64[1] != 0;
+        if (!S.two_d) {
+            cur_min_f64 = S.side != SIDE_POS;
+            cur_max_f64 = S.side != SIDE_NEG;
+        } else if (!S.f64) {
+            cur_min_f64 = !(bmin == S.x_min);          // the float32 extremum itself came back
+            cur_max_f64 = !(bmax == S.x_max);
+        }
+    }
+    const bool new_min_f64 = old_min_f64 || cur_min_f64, new_max_f64 = old_max_f64 || cur_max_f64;
     double mn = min_val[0], mx = max_val[0];
     if (rule == OSQ_UPDATE_AVERAGE) {
         if (__builtin_isinf(mx)) { mn = bmin; mx = bmax; }
-        else { mn = mn * static_cast<double>(cnt) + bmin; mx = mx * static_cast<double>(cnt) + bmax; }
-        mn /= static_cast<double>(cnt + 1);
-        mx /= static_cast<double>(cnt + 1);
+        else {
+            mn = avg_step(mn, old_min_f64, bmin, new_min_f64, cnt);
+            mx = avg_step(mx, old_max_f64, bmax, new_max_f64, cnt);
+        }
     } else {
         mn = bmin < mn ? bmin : mn;
         mx = bmax > mx ? bmax : mx;
     }
     min_val[0] = mn;
     max_val[0] = mx;
-    if (nfev_out) nfev_out[0] = ts->S.nfev;
+    if (ref_f64) { ref_f64[0] = new_min_f64 ? 1 : 0; ref_f64[1] = new_max_f64 ? 1 : 0; }
+    if (nfev_out) nfev_out[0] = S.nfev;
     if (scale_out) {
+        if (!new_min_f64 && !new_max_f64) {           // both statistics float32 in the reference: observer.py:101-119 in fp32
+            float s, z;
+            qparams_from_range(static_cast<float>(mn), static_cast<float>(mx), quant_min, quant_max, symmetric, &s, &z);
+            scale_out[0] = s;
+            if (zp_out) store_zp(zp_out, zp_type, 0, z);
+            return;
+        }
         const double min_neg = mn < 0.0 ? mn : 0.0, max_pos = mx > 0.0 ? mx : 0.0;
         const double eps = static_cast<double>(1e-8f);
         double scale, zp = 0.0;
@@ -1297,11 +1336,11 @@ extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq
 extern "C" int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt, double* min_val,
                                          double* max_val, int quant_min, int quant_max, int symmetric,
                                          float* scale_out, void* zero_point_out, int zp_type, int32_t* nfev,
-                                         osq_stream stream) {
+                                         int32_t* ref_float64, osq_stream stream) {
     OSQ_REQUIRE(state && min_val && max_val, "msefast_tensor_commit: null pointer");
     OSQ_REQUIRE(update_rule == OSQ_UPDATE_RUNNING || update_rule == OSQ_UPDATE_AVERAGE, "msefast_tensor_commit: bad rule");
     hipLaunchKernelGGL(msefast_commit_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const TensorSearch*>(state), update_rule, cnt, min_val, max_val, quant_min, quant_max,
-                       symmetric, scale_out, zero_point_out, zp_type, nfev);
+                       symmetric, scale_out, zero_point_out, zp_type, nfev, ref_float64);
     return check_launch("msefast_tensor_commit");
 }

@@ -530,7 +530,7 @@ def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
 
 class MseSearch:
     """One per-tensor MSEFast search between its begin and its commit (state on the device, what the launches need)."""
-    __slots__ = ("state", "x", "view", "lengths", "args", "elems", "cur", "fp32_2d")
+    __slots__ = ("state", "x", "view", "lengths", "args", "elems")
 
 
 def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
@@ -613,7 +613,8 @@ def msefast_resident_slots(elems):
     return int(_hip.load().osq_msefast_resident_slots(int(elems)))
 
 
-def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None):
+def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None, ref_float64=None):
+    """ref_float64: int32[2] on the device (the reference's dtype of min_val / max_val so far, see osq_hip.h) or None."""
     lib = _hip.load()
     dev = r.x.device
     quant_min, quant_max, symmetric = r.args
@@ -621,7 +622,7 @@ def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None):
     nfev = torch.empty(1, dtype=torch.int32, device=dev)
     _hip.check(lib.osq_msefast_tensor_commit(_hip.ptr(r.state), rule, int(cnt), _hip.ptr(min_val), _hip.ptr(max_val),
                                              quant_min, quant_max, symmetric, s_ptr, z_ptr, z_type,
-                                             _hip.ptr(nfev), _hip.stream_ptr(dev)), "msefast_commit")
+                                             _hip.ptr(nfev), _hip.ptr(ref_float64), _hip.stream_ptr(dev)), "msefast_commit")
     return nfev
 
 

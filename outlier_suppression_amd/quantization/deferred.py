@@ -63,8 +63,8 @@ class DeferredSites:
                     ops.msefast_tensor_run(it[1], None, it[2])
             self.launches += 1
         for obs, search, two_d, sink, cnt, rule in pending:
-            obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink)
-            obs._note_batch_result(search)
+            obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink,
+                                                      obs._ref_flags(obs.min_val.device))
         self.flushed_sites += len(pending)
         return len(pending)
 

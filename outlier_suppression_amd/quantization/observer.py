@@ -233,21 +233,18 @@ class MSEFastObserver(ObserverBase):
             return self.one_side_dist != "pos"
         known = self.__dict__.get("_min_f64_known", False)
         if not known:
-            flag = self.__dict__.get("_min_f64_flag")
-            known = flag is not None and bool(flag.item())        # one 4-byte read per call, only until it is set
+            flags = self.__dict__.get("_ref_f64")
+            known = flags is not None and bool(flags[0].item())        # one 4-byte read per call, only until it is set
             object.__setattr__(self, "_min_f64_known", known)
         return known
 
-    def _note_batch_result(self, search):
-        """After the commit of a 2-D search that ran on fp32 input: was this batch's best minimum the data's own minimum
-        (the reference then keeps a float32 min_val) or a searched number (float64 from here on)?  Device-side, no sync."""
-        if not getattr(search, "fp32_2d", False) or self.__dict__.get("_min_f64_known", False):
-            return
-        best = torch.tensor([float("inf"), float("-inf")], dtype=torch.float64, device=search.cur.device)
-        ops.msefast_tensor_commit(search, UPDATE_RUNNING, 0, best[0:1], best[1:2], None)      # running rule on (+inf, -inf): the batch's own result
-        inside = (best[0] != search.cur[0].to(torch.float64)).to(torch.int32).reshape(1)
-        flag = self.__dict__.get("_min_f64_flag")
-        object.__setattr__(self, "_min_f64_flag", inside if flag is None else torch.maximum(flag, inside))
+    def _ref_flags(self, device):
+        """int32[2] on the device: the reference's dtype of (min_val, max_val) so far; the commit kernel keeps it."""
+        flags = self.__dict__.get("_ref_f64")
+        if flags is None or flags.device != device:
+            flags = torch.zeros(2, dtype=torch.int32, device=device)
+            object.__setattr__(self, "_ref_f64", flags)
+        return flags
 
     def observe_into(self, x, observation_mask=None, seq_pos=-1, sink=None):
         if observation_mask is not None:
@@ -264,8 +261,10 @@ class MSEFastObserver(ObserverBase):
             #   * 1-D otherwise: -torch.tensor(np.float64) -- from the second call on;
             #   * 2-D: `max(tmp_min - shift, x_min)` (observer.py:479) hands back the float32 extremum when the searched
             #     range reaches beyond it, so min_val stays float32 until one batch's best minimum lies INSIDE the data --
-            #     kept as a sticky device flag (`_note_batch_result`), read back once per call while it is still unset.
-            # (This package keeps both statistics float64 on the device; the numbers are the same.)
+            #     a sticky device flag kept by the commit kernel (osq_msefast_tensor_commit, ref_float64), read back once
+            #     per call while it is still unset.  The same flags make the commit average a still-float32 statistic in
+            #     fp32 and derive the parameters in fp32 while both are.
+            # (This package keeps both statistics in float64 storage on the device; the numbers are the reference's.)
             first_call = self.min_val.dtype != torch.float64
             float64_input = (not first_call) and self._reference_min_is_float64(two_d)
             if self.min_val.dtype != torch.float64 or self.min_val.device != x.device:
@@ -276,15 +275,13 @@ class MSEFastObserver(ObserverBase):
                 # (quantization/deferred.py); min_val / max_val / scale move at the flush
                 search = ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
                                                   self.symmetric, self.one_side_dist, two_d, float64_input)
-                search.cur, search.fp32_2d = cur, (two_d and not float64_input)
                 DEFERRED.add_mse(self, search, two_d, sink)
             else:
                 search = ops.msefast_tensor_begin(x, cur, observation_mask, seq_pos, self.quant_min, self.quant_max,
                                                   self.symmetric, self.one_side_dist, two_d, float64_input)
-                search.cur, search.fp32_2d = cur, (two_d and not float64_input)
                 ops.msefast_tensor_run(search, None, two_d)
-                self.last_nfev = ops.msefast_tensor_commit(search, self.update_rule, self._counter(), self.min_val, self.max_val, sink)
-                self._note_batch_result(search)
+                self.last_nfev = ops.msefast_tensor_commit(search, self.update_rule, self._counter(), self.min_val, self.max_val, sink,
+                                                           self._ref_flags(x.device))
         else:
             bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
                                                           self.symmetric, self.one_side_dist, two_d)

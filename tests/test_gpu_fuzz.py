@@ -760,3 +760,39 @@ def test_quantized_operator_arguments(eq32, dev):
                 want = F.embedding(x.to(dev), wq, mod.padding_idx)
         assert got.shape == want.shape and torch.equal(got, want), (case, kind, mod)
         assert torch.equal(qm.weight.cpu(), mod.weight.detach()) and (b is None) == (getattr(mod, "bias", None) is None), (case, kind)
+
+
+def test_msefast_float32_statistics_corner(dev):
+    """Per-tensor AvgMSEFast on data with a populated lower bound (GELU-like: the optimal range keeps the data's own minimum):
+    the reference's min_val is then the float32 extremum, batch after batch -- its running mean is fp32 arithmetic, the next
+    batch is searched on fp32 input, and while max_val is float32 too the parameters are derived in fp32.  Statistics,
+    scale and zero point bit for bit against the oracle for as long as it searches on fp32 input."""
+    from oracle import observer_oracle as OB
+    from outlier_suppression_amd.quantization import Quantizer
+    rng = np.random.default_rng(1)
+    exact_later = 0
+    for trial in range(max(8, N_CASES // 100)):
+        bit = int(rng.choice([6, 8]))
+        q = Quantizer(None, NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=bit, symmetric=False, ch_axis=-1)).to(dev)
+        q.enable_observer(); q.enable_fake_quant()
+        st = OB.ObserverState(bit=bit, symmetric=False)
+        floor, cap = float(rng.choice([-0.5, -0.17, -1.0])), (float(rng.choice([1.5, 2.5])) if rng.random() < 0.4 else None)
+        for it in range(4):
+            x = np.maximum(rng.standard_normal((4, 16, 64)), floor)
+            if cap is not None:
+                x = np.minimum(x, cap)                   # both extrema populated: both statistics can stay float32
+            x = (x * (1 + 0.1 * it)).astype(np.float32)
+            fp32_input = np.asarray(st.min_val).dtype != np.float64
+            if not fp32_input:
+                break
+            with torch.no_grad():
+                q(torch.from_numpy(x).to(dev))
+            OB.observe_msefast(st, x, average=True)
+            scale, zp = st.qparams()
+            tag = (trial, it, bit, floor, cap, np.asarray(st.min_val).dtype, np.asarray(st.max_val).dtype)
+            assert float(q.observer.min_val) == float(st.min_val) and float(q.observer.max_val) == float(st.max_val), \
+                (tag, float(q.observer.min_val), float(st.min_val), float(q.observer.max_val), float(st.max_val))
+            assert np.float32(q.scale.item()) == np.float32(np.asarray(scale).reshape(-1)[0]) and \
+                float(q.zero_point.item()) == float(np.asarray(zp).reshape(-1)[0]), (tag, q.scale.item(), scale, q.zero_point.item(), zp)
+            exact_later += it > 0
+    assert exact_later >= 3          # the walk did reach later batches on fp32 input

@@ -196,3 +196,20 @@ def test_shipped_quant_sections_equal_the_reference_yaml():
         assert plain(ptq.namespace(quant)) == quant
         seen.add(kind)
     assert seen == set(ptq.SHIPPED_QUANT_SECTIONS)
+
+
+def test_qparams_of_mixed_dtype_statistics(ref):
+    """calculate_qparams on the statistics per-tensor MSEFast leaves behind: a float32 min_val beside a float64 max_val (and
+    the other three combinations) -- torch promotes to float64 as soon as either is; values and dtype equal the reference's."""
+    O, _ = ref
+    from oracle import observer_oracle as OB
+    rng = np.random.default_rng(0)
+    for sym in (False, True):
+        ob = O.AvgMSEFastObserver(bit=8, symmetric=sym, ch_axis=-1)
+        for k in range(2000):
+            dts = [(np.float32, np.float64), (np.float64, np.float32), (np.float32, np.float32), (np.float64, np.float64)][k % 4]
+            mn, mx = dts[0](-rng.random() * 2), dts[1](rng.random() * 3)
+            s, z = ob.calculate_qparams(torch.tensor(mn), torch.tensor(mx))
+            so, zo = OB.calculate_qparams(np.asarray(mn), np.asarray(mx), ob.quant_min, ob.quant_max, sym)
+            assert s.item() == float(so) and float(z) == float(zo), (sym, k, dts)
+            assert str(s.dtype).replace("torch.", "") == str(np.asarray(so).dtype), (sym, k, dts)

@@ -405,6 +405,11 @@ int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs,
                                     const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                     void* workspace, osq_stream stream);
 int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
+/* ObserverBase.calculate_qparams (observer.py:101-119) on float64 statistics -- what a per-tensor MSEFast observer holds:
+ * torch computes in the statistics' (promoted) dtype; scale / zero_point are rounded to their fp32 / int32 storage once. */
+int osq_calculate_qparams_f64(const double* min_val, const double* max_val, int64_t n, int quant_min, int quant_max,
+                              int symmetric, float* scale_out, void* zero_point_out, int zp_type, osq_stream stream);
+
 /* ref_float64 (nullable): int32[2] on the device, zero before the observer's first commit -- whether the REFERENCE's
  * min_val / max_val hold float64 by now.  Its per-tensor results are float64 except the float32 zeros_like of a one-sided
  * search (observer.py:491-492) and the float32 extremum that Python's max / min hand back when the nested search's range

@@ -92,6 +92,7 @@ SIGNATURES = {
     "osq_msefast_tensor_search_multi": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L), ctypes.POINTER(TokenView),
                                              ctypes.POINTER(_P), _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
+    "osq_calculate_qparams_f64": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P]),
     "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_observe_quantile": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _D, _P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),

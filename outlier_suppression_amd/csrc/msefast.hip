@@ -568,6 +568,32 @@ __global__ void msefast_commit_kernel(const TensorSearch* __restrict__ ts, int r
     }
 }
 
+// calculate_qparams on float64 statistics (a caller handing a per-tensor MSEFast observer's min_val / max_val to
+// ObserverBase.calculate_qparams, observer.py:101-119: torch computes in the statistics' dtype and the result is float64)
+__global__ void qparams_f64_kernel(const double* __restrict__ mn_p, const double* __restrict__ mx_p, int64_t n, int quant_min,
+                                   int quant_max, int symmetric, float* __restrict__ scale_out, void* __restrict__ zp_out,
+                                   int zp_type) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mn = mn_p[i], mx = mx_p[i];
+    const double nan = __builtin_nan("");
+    const double min_neg = (mn != mn) ? nan : (mn < 0.0 ? mn : 0.0), max_pos = (mx != mx) ? nan : (mx > 0.0 ? mx : 0.0);
+    const double eps = static_cast<double>(1e-8f);
+    double scale, zp = 0.0;
+    if (symmetric) {
+        const double m = (min_neg != min_neg || max_pos != max_pos) ? nan : (-min_neg > max_pos ? -min_neg : max_pos);
+        scale = m / (static_cast<double>(quant_max - quant_min) / 2.0);
+        scale = (scale != scale) ? nan : (scale > eps ? scale : eps);
+    } else {
+        scale = (max_pos - min_neg) / static_cast<double>(quant_max - quant_min);
+        scale = (scale != scale) ? nan : (scale > eps ? scale : eps);
+        zp = static_cast<double>(quant_min) - rint(min_neg / scale);
+        zp = (zp != zp) ? nan : (zp < quant_min ? quant_min : (zp > quant_max ? quant_max : zp));
+    }
+    scale_out[i] = static_cast<float>(scale);
+    if (zp_out) store_zp(zp_out, zp_type, i, static_cast<float>(zp));
+}
+
 __global__ void msefast_done_kernel(const TensorSearch* __restrict__ ts, int* __restrict__ done_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) done_out[0] = ts->S.done;
 }
@@ -1331,6 +1357,16 @@ extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq
     hipLaunchKernelGGL(msefast_done_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const TensorSearch*>(state), done_out);
     return check_launch("msefast_tensor_done");
+}
+
+extern "C" int osq_calculate_qparams_f64(const double* min_val, const double* max_val, int64_t n, int quant_min, int quant_max,
+                                         int symmetric, float* scale_out, void* zero_point_out, int zp_type, osq_stream stream) {
+    OSQ_REQUIRE(n >= 0 && min_val && max_val && scale_out, "calculate_qparams_f64: null pointer or n < 0");
+    OSQ_REQUIRE(quant_max > quant_min, "calculate_qparams_f64: quant_max must exceed quant_min");
+    if (n == 0) return OSQ_OK;
+    hipLaunchKernelGGL(qparams_f64_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       min_val, max_val, n, quant_min, quant_max, symmetric, scale_out, zero_point_out, zp_type);
+    return check_launch("calculate_qparams_f64");
 }
 
 extern "C" int osq_msefast_tensor_commit(const void* state, int update_rule, int64_t cnt, double* min_val,

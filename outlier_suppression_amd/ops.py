@@ -240,14 +240,16 @@ def calculate_qparams(min_val, max_val, quant_min, quant_max, symmetric, scale_o
     symmetric and fp32 otherwise unless ``zp_dtype`` / ``zero_point_out`` says differently."""
     lib = _hip.load()
     _hip.require_device(min_val, max_val)
-    mn = min_val.detach().to(torch.float32).contiguous()
-    mx = max_val.detach().to(torch.float32).contiguous()
+    f64 = torch.float64 in (min_val.dtype, max_val.dtype)          # torch's promotion: float64 as soon as either statistic is
+    mn = min_val.detach().to(torch.float64 if f64 else torch.float32).contiguous()
+    mx = max_val.detach().to(torch.float64 if f64 else torch.float32).contiguous()
     if scale_out is None:
         scale_out = torch.empty(mn.shape, dtype=torch.float32, device=mn.device)
     if zero_point_out is None:
         dt = zp_dtype if zp_dtype is not None else (torch.int32 if symmetric else torch.float32)
         zero_point_out = torch.empty(mn.shape, dtype=dt, device=mn.device)
-    _hip.check(lib.osq_calculate_qparams(_hip.ptr(mn), _hip.ptr(mx), mn.numel(), int(quant_min), int(quant_max),
+    fn = lib.osq_calculate_qparams_f64 if f64 else lib.osq_calculate_qparams
+    _hip.check(fn(_hip.ptr(mn), _hip.ptr(mx), mn.numel(), int(quant_min), int(quant_max),
                                          int(bool(symmetric)), _hip.ptr(scale_out), _hip.ptr(zero_point_out),
                                          _zp_type(zero_point_out), _hip.stream_ptr(mn.device)), "calculate_qparams")
     return scale_out, zero_point_out

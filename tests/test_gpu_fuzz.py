@@ -2,7 +2,7 @@
 hand-written case lists -- odd shapes (T < 4, 1..7 features), permuted and offset (16-byte-misaligned) views, empty and
 full samples, one-sided and constant tensors, heavy duplicates (quantised values), 4 / 6 / 8 bit, both symmetries, the
 three running-statistic observers, Fixed and LSQ+ quantizers, forward and LSQ+ backward.  Seeded: the cases are the same
-in every run; OSQ_FUZZ_CASES=<n> lengthens the walk (default 800 cases, a few seconds)."""
+in every run; OSQ_FUZZ_CASES=<n> lengthens the walk, OSQ_FUZZ_SEED=<n> takes another one (default 800 cases, a few seconds)."""
 import os
 from types import SimpleNamespace as NS
 
@@ -13,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 N_CASES = int(os.environ.get("OSQ_FUZZ_CASES", "800"))
+SEED = int(os.environ.get("OSQ_FUZZ_SEED", "0"))          # another walk: OSQ_FUZZ_SEED=<n> shifts every family's seed
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +86,7 @@ def _as_view(rng, x_np, kind, dev):
 def test_quantizer_calls_vs_oracle(eq32, dev):
     from oracle import observer_oracle as OB, fake_quant_oracle as FQ
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(20260930)
+    rng = np.random.default_rng(20260930 + SEED)
     observers = {"AvgPruneMinMaxObserver": OB.observe_avg_prune_minmax, "AvgMinMaxObserver": OB.observe_avg_minmax,
                  "MinMaxObserver": OB.observe_minmax}
     seen = set()
@@ -161,7 +162,7 @@ def test_weight_operators_vs_oracle(eq32, dev):
     from oracle import observer_oracle as OB, fake_quant_oracle as FQ
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + SEED)
     for case in range(max(40, N_CASES // 4)):
         bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
         kind = str(rng.choice(["linear", "conv", "embedding"]))
@@ -209,7 +210,7 @@ def test_msefast_rows_vs_oracle(dev):
     iterate for iterate -- the same (min, max) bit for bit -- over random row lengths, one-sided and mixed rows, 4 / 6 / 8 bit."""
     from oracle import observer_oracle as OB
     from outlier_suppression_amd.quantization.observer import MSEFastObserver
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + SEED)
     for case in range(max(6, N_CASES // 40)):
         bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
         rows, cols = int(rng.integers(1, 12)), int(rng.choice([4, 12, 64, 100, 768]))
@@ -231,7 +232,7 @@ def test_token_selection_vs_oracle(eq32, dev):
     distinct values, all equal, all-negative per-token maxima, heavy ties round the percentile, extreme percentiles."""
     from oracle import observer_oracle as OB
     from outlier_suppression_amd.quantization.observer import AvgPruneMinMaxObserver
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + SEED)
     for case in range(max(30, N_CASES // 8)):
         big = rng.random() < 0.25
         B = int(rng.integers(1, 65 if big else 9))
@@ -275,7 +276,7 @@ def test_fused_step_vs_three_launches_random(dev):
     multiple of 256), lengths with empty samples, random percentiles, occasionally a NaN among the valid tokens."""
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(31337 + SEED)
     try:
         for case in range(max(12, N_CASES // 40)):
             B, T = int(rng.integers(1, 97)), int(rng.integers(4, 200))
@@ -311,7 +312,7 @@ def test_other_observers_vs_oracle(eq32, dev):
     MSEFastObserver / AvgMSEFastObserver per tensor (bounded Brent, float64 statistics from the second batch on)."""
     from oracle import observer_oracle as OB
     from outlier_suppression_amd.quantization.quantized_module import ObserverDict
-    rng = np.random.default_rng(2718)
+    rng = np.random.default_rng(2718 + SEED)
     for case in range(max(24, N_CASES // 16)):
         cls = str(rng.choice(["AvgQuantileObserver", "MSEObserver", "AvgMSEObserver", "MSEFastObserver", "AvgMSEFastObserver"]))
         bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
@@ -384,7 +385,7 @@ def test_deferred_forwards_vs_oracle(eq32, dev):
     from oracle import observer_oracle as OB
     from outlier_suppression_amd.quantization import Quantizer
     from outlier_suppression_amd.quantization.deferred import deferred_observation
-    rng = np.random.default_rng(60606)
+    rng = np.random.default_rng(60606 + SEED)
     fns = {"AvgPruneMinMaxObserver": OB.observe_avg_prune_minmax, "AvgMinMaxObserver": OB.observe_avg_minmax,
            "MinMaxObserver": OB.observe_minmax}
     for case in range(max(20, N_CASES // 16)):
@@ -450,7 +451,7 @@ def test_gamma_ops_vs_oracle(eq32, dev):
     buffers: weight fold in place, beta / gamma, input * gamma + hidden."""
     from oracle import gamma_oracle as GO
     from outlier_suppression_amd import ops
-    rng = np.random.default_rng(5150)
+    rng = np.random.default_rng(5150 + SEED)
     for case in range(max(40, N_CASES // 8)):
         rows, cols = int(rng.integers(1, 70)), int(rng.choice([1, 2, 3, 4, 7, 8, 33, 64, 100, 768]))
         w_np = rng.standard_normal((rows, cols)).astype(np.float32)
@@ -477,7 +478,7 @@ def test_per_channel_learnable_vs_oracle(eq32, dev):
     (fake_quant.py:195-206: 1 / sqrt(numel / C * quant_max))."""
     from oracle import fake_quant_oracle as FQ
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(8086)
+    rng = np.random.default_rng(8086 + SEED)
     for case in range(max(20, N_CASES // 16)):
         C, inner = int(rng.integers(1, 20)), int(rng.choice([1, 3, 4, 8, 33, 64, 200]))
         bit, sym = int(rng.choice([4, 6, 8])), bool(rng.integers(0, 2))
@@ -525,7 +526,7 @@ def test_cached_search_equals_literal_random_models(dev):
     from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
     from outlier_suppression_amd.quantization.state import set_observer_name
     from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
-    rng = np.random.default_rng(1999)
+    rng = np.random.default_rng(1999 + SEED)
     a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
 
@@ -618,7 +619,7 @@ def test_state_dict_and_copies(dev):
     zero_point to the stored shape) and copy.deepcopy: same keys, dtypes, shapes, values, and the same quantised output."""
     import copy
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(4711)
+    rng = np.random.default_rng(4711 + SEED)
     for case in range(max(30, N_CASES // 16)):
         weight = rng.random() < 0.4
         quantizer = str(rng.choice(["FixedFakeQuantize", "LSQFakeQuantize", "LSQPlusFakeQuantize"]))
@@ -683,7 +684,7 @@ def test_fused_sites_vs_eager(dev):
     a rounding boundary)."""
     import torch.nn.functional as F
     from outlier_suppression_amd import ops
-    rng = np.random.default_rng(1234567)
+    rng = np.random.default_rng(1234567 + SEED)
     for case in range(max(30, N_CASES // 16)):
         shape = tuple(int(v) for v in rng.integers(1, 9, size=int(rng.integers(1, 3)))) + (int(rng.choice([1, 3, 4, 64, 100, 768, 3072])),)
         x_np = (rng.standard_normal(shape) * rng.choice([0.5, 3.0])).astype(np.float32)
@@ -732,7 +733,7 @@ def test_quantized_operator_arguments(eq32, dev):
     padding, dilation, groups, padding_idx): the quantized operator equals the stock functional on the fake-quantised weight."""
     import torch.nn.functional as F
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(31415)
+    rng = np.random.default_rng(31415 + SEED)
     cfg = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
     for case in range(max(30, N_CASES // 16)):
         kind = str(rng.choice(["linear", "conv", "embedding"]))
@@ -774,7 +775,7 @@ def test_msefast_float32_statistics_corner(dev):
     scale and zero point bit for bit against the oracle for as long as it searches on fp32 input."""
     from oracle import observer_oracle as OB
     from outlier_suppression_amd.quantization import Quantizer
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(1 + SEED)
     exact_later = 0
     for trial in range(max(8, N_CASES // 100)):
         bit = int(rng.choice([6, 8]))

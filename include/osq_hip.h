@@ -90,7 +90,9 @@ size_t      osq_workspace_bytes(void);
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
  *   threshold pass; "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
- *   of the one-launch resident form (the last three exist so that tests can drive every implementation). */
+ *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
+ *   "fused_spin_limit" / "mse_spin_limit" n: bound of the cross-workgroup waits of the two persistent launch families
+ *   (0 = the default, ~2 s; n > 0 = n - 1 polls, so 1 makes every wait give up at once: tests force the time-out path). */
 int osq_set_tuning(const char* key, int value);
 
 /* Measurement aid (bench.py).  The events given to osq_time_next_launch ride on the dispatch packet of the
@@ -291,6 +293,17 @@ int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, co
 
 int osq_fused_step_status(void* workspace, int* status_out, osq_stream stream);
 
+/* Sticky time-out flags of BOTH persistent launch families on this workspace -- the one-launch observe + fake-quant step
+ * (bit 0: a selector, bit 1: a streaming workgroup waited in vain) and the resident MSEFast searches (bit 0) -- read and
+ * cleared after everything enqueued on `stream` has finished (this call synchronises the stream).  Non-zero means some
+ * launch since the last call wrote NaN into its outputs because its workgroups were not resident together (another
+ * process, or another stream's long kernel, held CUs): the caller must treat every result since the last call as
+ * invalid.  reset_on_error != 0 additionally returns both state blocks to their all-zero start, so that the next launch
+ * begins clean.  The host binding (outlier_suppression_amd.ops.check_persistent) calls this at its synchronisation
+ * points and raises. */
+int osq_persistent_status(void* workspace, int* fused_status_out, int* resident_status_out, int reset_on_error,
+                          osq_stream stream);
+
 int osq_set_wide_min_slots(int64_t slots);
 
 /* Grid-search form of the same step (token_wise_clipping.py:50-66 calls the observer pass once per
@@ -389,18 +402,22 @@ int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token
  * the valid part of the tensor is loaded once into the registers of a one-workgroup-per-CU grid, every loss
  * evaluation is one exchange of per-workgroup partial sums through the workspace.  view == NULL: x is flat, n
  * elements; otherwise a token view with valid lengths (n ignored).  OSQ_ERR_UNSUPPORTED (nothing launched): more
- * than 16 float4 per lane of the grid (67 MB on 256 CUs), batch > 1024, a misaligned flat tensor, or
- * osq_set_tuning("mse_resident", 0) -- the caller then runs the _evals_* loop. */
+ * than 32 float4 per lane of the grid (512-thread workgroups: 67 MB on 256 CUs), batch > 512, a misaligned flat tensor,
+ * or osq_set_tuning("mse_resident", 0) -- the caller then runs the _evals_* loop.  A workgroup that waits in vain for
+ * another one's partial sum (the grid was not resident together: another process or stream held CUs) poisons the search
+ * with NaN and raises the sticky flag osq_persistent_status reports. */
 int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
                               const int64_t* lengths, void* workspace, osq_stream stream);
 /* Several searches in ONE persistent launch (the observers of a forward are independent while fake-quant is off):
  * osq_msefast_resident_slots(elems) = float4 slots per lane of the resident grid a search over `elems` elements takes
- * (1..16; 0 = cannot be resident); a group fits when it has at most 16 searches whose slots add up to at most 16.
+ * (1..max_slots; 0 = cannot be resident); a group fits when it has at most max_sites searches whose slots add up to at
+ * most max_slots (osq_msefast_resident_limits: 32 and 16).
  * Every round of the launch evaluates the pending candidate of every unfinished search; the exchange of the partial
  * sums and the serial Brent steps of the searches overlap.  Arrays are HOST arrays of n_sites entries; views[i].batch
  * == 0 marks a flat tensor of ns[i] elements.  Each search sits between its own _begin and _commit.
  * OSQ_ERR_UNSUPPORTED: the group does not fit, nothing was launched. */
 int osq_msefast_resident_slots(int64_t elems);
+int osq_msefast_resident_limits(int* max_slots, int* max_sites);
 int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs, const int64_t* ns,
                                     const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                     void* workspace, osq_stream stream);

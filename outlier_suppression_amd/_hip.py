@@ -78,6 +78,7 @@ SIGNATURES = {
     "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I,
                                            _P, _L, _I, _F, _P, _P, _P]),
     "osq_fused_step_status": (_I, [_P, ctypes.POINTER(_I), _P]),
+    "osq_persistent_status": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _P]),
     "osq_set_wide_min_slots": (_I, [_L]),
     "osq_token_range_finalize_batched": (_I, [_P, _P, _L, _I, _I, _L, _L, _P, _I, _P, _D, _P, _P, _P]),
     "osq_observer_update": (_I, [_P, _P, _L, _I, _L, _P, _P, _P]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
     "osq_msefast_tensor_search": (_I, [_P, _P, _L, ctypes.POINTER(TokenView), _P, _P, _P]),
     "osq_msefast_resident_slots": (_I, [_L]),
+    "osq_msefast_resident_limits": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "osq_msefast_tensor_search_multi": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L), ctypes.POINTER(TokenView),
                                              ctypes.POINTER(_P), _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),

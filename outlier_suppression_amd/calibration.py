@@ -1,4 +1,6 @@
-"""Sharded calibration: batches split over ranks, ONE small exchange of per-batch statistics.
+"""Sharded calibration: batches split over ranks, ONE small exchange of per-batch statistics -- and, for observers whose
+batches cannot be separated (MSEFast and friends), SITES split over ranks with one exchange of their final state
+(``calibrate_owned_sites``, at the end of this file).
 
 The reference calibrates on one GPU (no collectives anywhere).  In every observer pass the
 fake-quantizers are off (state.py:18-19, token_wise_clipping.py:18-19), so batch b's
@@ -56,13 +58,14 @@ def act_quantizers(model, select=lambda name: "act" in name):
 def _require_capture_support(quantizers, what):
     """Sharded / cached calibration records each batch's (min, max) and replays the observers' update rules later.
     Observers that keep their own state (MSEFast / MSE searches with float64 statistics, AvgQuantile, LSQPlusObserver)
-    neither fill the capture slot nor fit the fp32 replay: refuse instead of folding zeros into their statistics."""
+    neither fill the capture slot nor fit the fp32 replay: they are sharded by SITE instead (calibrate_owned_sites)."""
     for name, q in quantizers:
         obs = q.observer
         if not getattr(obs, "supports_capture", False) or obs.min_val.dtype != torch.float32 or obs.ch_axis != -1:
             raise NotImplementedError(
                 f"{what}: {type(obs).__name__} at '{name}' cannot be recorded per batch and replayed "
-                "(per-tensor MinMax / AvgMinMax / AvgPruneMinMax observers only); calibrate it with the plain loop")
+                "(per-tensor MinMax / AvgMinMax / AvgPruneMinMax observers only); use calibration.calibrate_owned_sites, "
+                "which deals the sites -- not the batches -- over the ranks")
 
 
 class CaptureTable:
@@ -186,4 +189,198 @@ def calibrate_sharded(model, batches, forward, n_batches=None, group=None, selec
         cap.disarm()
     ordered = gather_batch_table(cap.table, n_batches, group)
     replay(ordered, qs)
+    ops.check_persistent("calibrate_sharded")
     return ordered
+
+
+# ---------------------------------------------------------------------------------------------
+# Observers that cannot be recorded per batch: shard the SITES instead of the batches
+# ---------------------------------------------------------------------------------------------
+#
+# MSEFast / AvgMSEFast (observer.py:412-567), MSE / AvgMSE, AvgQuantile and LSQPlusObserver keep state that the next
+# batch's arithmetic depends on -- a per-tensor MSEFast observer searches its SECOND batch on a float64 copy of x if and
+# only if its first search left a float64 min_val behind (observer.py:481,494,524), which for the nested 2-D search
+# depends on where the first batch's optimum fell.  Dealing the batches of ONE such observer to different ranks would
+# need that decision before the batch that makes it has been searched.  What is independent is the SITE: with
+# fake-quant off (state.py:18-19) no observer reads another one's result.  So every rank runs every forward (7 ms of a
+# 270 ms observer pass of RoBERTa-base: the searches are the work), but only the observers it OWNS observe; each owned
+# observer sees all batches in order, exactly as in one process -- bit-identical by construction -- and one all-gather
+# of the final (min_val, max_val, scale, zero_point, counters, dtype flags) hands every rank every site's result.
+# Per-channel weight observers (MSEFast: one bounded-Brent search per row, observer.py:496-517) are sites like any
+# other: their [C] statistics travel in the same table.
+
+_SIDE_CODE = {None: -1.0, "no": 0.0, "pos": 1.0, "neg": 2.0}
+_SIDE_NAME = {v: k for k, v in _SIDE_CODE.items()}
+_META = 8          # per site: cnt, one_side code, ref-float64 flags (2), statistics dtype (0 fp32 / 1 float64), nfev, 2 spare
+
+
+def _site_cost(name, q, numel, channels):
+    """Relative cost of observing one site once (only the balance of the deal depends on it, never a result)."""
+    kind = type(q.observer).__name__
+    if "MSEFast" in kind:
+        if channels > 1:
+            return numel * 15.0                                        # ~15 loss evaluations per row (SURVEY 8a, A16)
+        nested = not q.observer.symmetric and "attention_probs" not in name     # softmax outputs are one-sided: 1-D search
+        return numel * (350.0 if nested else 20.0)
+    if "MSE" in kind:
+        return numel * (200.0 if not q.observer.symmetric else 4.0)
+    return float(numel)
+
+
+def probe_sites(model, batch, forward, quantizers):
+    """One forward with every selected observer off: (numel, channels) of the tensor each quantizer is called with
+    (0, 1 for quantizers the forward does not reach).  Weight quantizers are called with their operator's weight."""
+    seen = {}
+    handles, saved = [], []
+    for i, (_, q) in enumerate(quantizers):
+        def hook(mod, args, kwargs, i=i):
+            x = args[0] if args else kwargs.get("X")
+            if x is not None and i not in seen:
+                seen[i] = (x.numel(), 1 if mod.ch_axis == -1 else x.shape[mod.ch_axis])
+        handles.append(q.register_forward_pre_hook(hook, with_kwargs=True))
+        saved.append((q.observer_enabled, q.fake_quant_enabled))
+        q.observer_enabled, q.fake_quant_enabled = 0, 0
+    try:
+        with torch.no_grad():
+            forward(model, batch)
+    finally:
+        for h in handles:
+            h.remove()
+        for (_, q), (o, f) in zip(quantizers, saved):
+            q.observer_enabled, q.fake_quant_enabled = o, f
+    return [seen.get(i, (0, 1)) for i in range(len(quantizers))]
+
+
+def deal_sites(costs, world):
+    """Owner rank of every site: longest-processing-time-first onto the least loaded rank (ties: lowest rank, lowest
+    index) -- the same deal on every rank."""
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def _pack_site(q, channels, out):
+    """Final state of an owned quantizer as float64 numbers (fp32 / int32 / float64 values all convert exactly)."""
+    obs = q.observer
+    c = channels
+    flags = obs.__dict__.get("_ref_f64")
+    nfev = getattr(obs, "last_nfev", None)
+    meta = torch.zeros(_META, dtype=torch.float64, device=out.device)
+    meta[0] = float(getattr(obs, "cnt", 0))
+    meta[1] = _SIDE_CODE[getattr(obs, "one_side_dist", None)]
+    if flags is not None:
+        meta[2:4] = flags.to(torch.float64)
+    meta[4] = 1.0 if obs.min_val.dtype == torch.float64 else 0.0
+    if nfev is not None:
+        meta[5] = nfev.to(torch.float64).sum()
+    out[:_META] = meta
+    body = out[_META:]
+    for k, t in enumerate((obs.min_val, obs.max_val, q.scale.detach(), q.zero_point.detach())):
+        flat = t.reshape(-1).to(device=out.device, dtype=torch.float64)
+        if flat.numel() == c:
+            body[k * c:(k + 1) * c] = flat
+        elif flat.numel() == 1:                    # never observed (a site no forward reached): the start values
+            body[k * c:(k + 1) * c] = flat
+        else:
+            raise RuntimeError(f"site state has {flat.numel()} entries, expected {c}")
+
+
+def _unpack_site(q, channels, row, device):
+    """Install an owner's final state in this rank's copy of the quantizer (same dtypes and shapes as the owner's)."""
+    obs = q.observer
+    c = channels
+    meta = row[:_META].cpu()
+    body = row[_META:]
+    stat_dtype = torch.float64 if meta[4].item() == 1.0 else torch.float32
+    shape = (c,) if (obs.ch_axis != -1 or obs.min_val.dim()) else ()
+    obs.min_val = body[0:c].to(stat_dtype).reshape(shape).clone()
+    obs.max_val = body[c:2 * c].to(stat_dtype).reshape(shape).clone()
+    scale, zero_point = q._qparam_storage(device, c)
+    q._touch_qparams()
+    scale.copy_(body[2 * c:3 * c].to(scale.dtype))
+    zero_point.copy_(body[3 * c:4 * c].to(zero_point.dtype))
+    if hasattr(obs, "cnt"):
+        object.__setattr__(obs, "cnt", int(meta[0].item()))
+    if hasattr(obs, "one_side_dist"):
+        obs.one_side_dist = _SIDE_NAME[meta[1].item()]
+    if hasattr(obs, "_ref_flags"):
+        obs._ref_flags(device).copy_(meta[2:4].to(torch.int32))
+        object.__setattr__(obs, "_min_f64_known", bool(meta[2].item()))
+
+
+@torch.no_grad()
+def exchange_site_states(quantizers, channels, owner, rank, world, device, group=None):
+    """The one exchange of a site-sharded pass: every quantizer's final state travels from its owner to everybody
+    (one all_gather_into_tensor of a float64 table: 8 meta numbers + 4 x channels values per site; RCCL gathers the
+    device tensor, a gloo group is served through the host).  Returns the seconds spent."""
+    import time
+    sizes = [_META + 4 * ch for ch in channels]
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + sz)
+    table = torch.zeros(offs[-1], dtype=torch.float64, device=device)
+    for i, ((_, q), r) in enumerate(zip(quantizers, owner)):
+        if r == rank:
+            _pack_site(q, channels[i], table[offs[i]:offs[i + 1]])
+    if table.is_cuda:
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    staged = table.is_cuda and dist.get_backend(group) == "gloo"
+    src = table.cpu() if staged else table
+    gathered = torch.empty(world * offs[-1], dtype=torch.float64, device=src.device)
+    dist.all_gather_into_tensor(gathered, src, group=group)
+    gathered = gathered.to(device).view(world, offs[-1])
+    if table.is_cuda:
+        torch.cuda.synchronize(device)
+    seconds = time.perf_counter() - t0
+    for i, ((_, q), r) in enumerate(zip(quantizers, owner)):
+        if r != rank:
+            _unpack_site(q, channels[i], gathered[r, offs[i]:offs[i + 1]], device)
+    return seconds
+
+
+@torch.no_grad()
+def calibrate_owned_sites(model, batches, forward, group=None, select=lambda name: "act" in name, defer=True):
+    """Observer pass with the SITES dealt over the ranks of ``group`` (see the block comment above): for observers whose
+    batches cannot be separated -- MSEFast / AvgMSEFast / MSE / AvgMSE / AvgQuantile / LSQPlusObserver, per-tensor or
+    per-channel.  ``batches``: ALL calibration batches, the same on every rank, in order; ``forward(model, batch)`` runs
+    the model.  Observers of the selected quantizers are expected on, fake-quant off.  Ends with every rank holding every
+    selected quantizer's final statistics, scale and zero_point, bit-identical to a one-process pass.
+
+    Returns {"owner": [...], "collective_s": seconds spent in the exchange}."""
+    import contextlib
+    import time
+    from .quantization.deferred import deferred_observation
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    qs = [(n, q) for n, q in act_quantizers(model, select) if q.observer_enabled == 1]
+    if not batches or not qs:
+        return {"owner": [], "collective_s": 0.0}
+    dev = next(model.parameters()).device
+    if world == 1:
+        owner = [0] * len(qs)
+        geo = None
+    else:
+        geo = probe_sites(model, batches[0], forward, qs)
+        owner = deal_sites([_site_cost(n, q, numel, ch) for (n, q), (numel, ch) in zip(qs, geo)], world)
+    for (_, q), r in zip(qs, owner):
+        if r != rank:
+            q.observer_enabled = 0
+    try:
+        with (deferred_observation() if defer else contextlib.nullcontext()) as sites:
+            for batch in batches:
+                forward(model, batch)
+                if sites is not None:
+                    sites.flush()
+    finally:
+        for _, q in qs:
+            q.observer_enabled = 1
+    ops.check_persistent("calibrate_owned_sites")
+    if world == 1:
+        return {"owner": owner, "collective_s": 0.0}
+    collective_s = exchange_site_states(qs, [ch for _, ch in geo], owner, rank, world, dev, group)
+    return {"owner": owner, "collective_s": collective_s}

@@ -40,8 +40,13 @@ constexpr int kFusedMaxBatch = 1024;      // prefix sums of the lengths live in 
 constexpr int kFusedShards = 8;           // arrival counters, one per XCD (workgroup b runs on XCD b % 8)
 constexpr unsigned int kFusedSpinLimit = 1u << 21;
 
-struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch
-    unsigned int arrive[kFusedShards][16];    // one 64-byte line per counter; zero between launches
+struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch (or after a reset)
+    // Arrival counters, one 64-byte line each, in TWO sets: launch number e (the epoch word) counts in set e & 1 and
+    // zeroes set (e + 1) & 1 at its end.  Nobody of launch e touches the other set, and every workgroup of launch
+    // e - 1 has left by the kernel boundary -- also the ones that arrived after a time-out -- so a late arrival can
+    // never be added to a counter a later launch compares with `==` (round 2 zeroed the set in use, which a workgroup
+    // arriving after its selectors' time-out would then have left at 1 for every launch after it).
+    unsigned int arrive[2][kFusedShards][16];
     unsigned int epoch, pad0[15];             // launches completed on this workspace
     unsigned long long side[16];              // side[0], side[1]: one granule per selector (tag30 << 34 | empty << 33 | bad << 32 | value bits), adjacent: one 16-byte poll reads both
     unsigned int status, pad3[15];            // sticky: 1 = a selector timed out, 2 = a streaming workgroup timed out
@@ -66,6 +71,7 @@ struct FusedArgs {
     int gate;                     // 1: padded tokens are loaded only after every workgroup has arrived
     int deal;                     // how a slot's tokens are dealt to the waves (see the kernel): 0 = 16 consecutive tokens per workgroup,
                                   // 2 = round the workgroups token by token, 1 = only the slot with the last valid tokens
+    unsigned int spin_limit;      // bound of every cross-workgroup wait (kFusedSpinLimit; osq_set_tuning("fused_spin_limit") for tests)
 };
 
 __device__ __forceinline__ unsigned long long peek64(const unsigned long long* p) {
@@ -177,8 +183,8 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             const unsigned int s = lane < kFusedShards ? lane : 0;
             const unsigned int want = fused_members(gridDim.x, s);
             bool ok = false;
-            for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
-                ok = peek32(&st->arrive[s][0]) == want;
+            for (unsigned int spins = 0; spins < a.spin_limit; ++spins) {
+                ok = peek32(&st->arrive[(tag - 1u) & 1u][s][0]) == want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     OSQ_FSTAMP(2);
     __syncthreads();
     if (tid == 0)
-        __hip_atomic_fetch_add(&st->arrive[blockIdx.x % kFusedShards][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&st->arrive[(tag - 1u) & 1u][blockIdx.x % kFusedShards][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     OSQ_FSTAMP(3);
 
     // ---- phase A2: this wave's padded tokens -> registers / LDS, while the selectors work.  Not before every workgroup
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     }
     if (a.gate) {
         if (tid == 0) {
-            for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
+            for (unsigned int spins = 0; spins < a.spin_limit; ++spins) {
                 if (peek32(&st->go[0][0]) == tag && peek32(&st->go[1][0]) == tag) break;
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         bool ok = false;
         const unsigned long long want = static_cast<unsigned long long>(tag & 0x3fffffffu);
         const auto srs = __builtin_amdgcn_make_buffer_rsrc(st->side, 0, 16, 0x00020000);
-        for (unsigned int spins = 0; spins < kFusedSpinLimit; ++spins) {
+        for (unsigned int spins = 0; spins < a.spin_limit; ++spins) {
             const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(srs, 0, 0, 16);      // sc1: both granules, one request
             g0 = (static_cast<unsigned long long>(w.y) << 32) | w.x;
             g1 = (static_cast<unsigned long long>(w.w) << 32) | w.z;
@@ -449,9 +455,9 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             }
             if (fin.zp_type != OSQ_ZP_FLOAT32) z = static_cast<float>(static_cast<int32_t>(z));   // what a reader of the int32 buffer sees
         }
-        if (blockIdx.x == 2u) {                            // ... and closes the launch's bookkeeping: every workgroup has
-            for (int k = 0; k < kFusedShards; ++k)         // arrived (the selectors saw it), so nobody adds or reads the epoch any more
-                __hip_atomic_store(&st->arrive[k][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 2u) {                            // ... and closes the launch's bookkeeping: the NEXT launch's counter set
+            for (int k = 0; k < kFusedShards; ++k)         // (untouched by this launch) is zeroed, the epoch moves on -- every workgroup
+                __hip_atomic_store(&st->arrive[tag & 1u][k][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read it at its start
             __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_word[2] = __float_as_uint(s);

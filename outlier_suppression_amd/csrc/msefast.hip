@@ -534,9 +534,9 @@ __global__ void msefast_commit_kernel(const TensorSearch* __restrict__ ts, int r
             mn = avg_step(mn, old_min_f64, bmin, new_min_f64, cnt);
             mx = avg_step(mx, old_max_f64, bmax, new_max_f64, cnt);
         }
-    } else {
-        mn = bmin < mn ? bmin : mn;
-        mx = bmax > mx ? bmax : mx;
+    } else {                                   // torch.min / torch.max propagate NaN (a poisoned or NaN-fed search must not vanish)
+        mn = (bmin != bmin || mn != mn) ? __builtin_nan("") : (bmin < mn ? bmin : mn);
+        mx = (bmax != bmax || mx != mx) ? __builtin_nan("") : (bmax > mx ? bmax : mx);
     }
     min_val[0] = mn;
     max_val[0] = mx;
@@ -550,18 +550,20 @@ __global__ void msefast_commit_kernel(const TensorSearch* __restrict__ ts, int r
             if (zp_out) store_zp(zp_out, zp_type, 0, z);
             return;
         }
-        const double min_neg = mn < 0.0 ? mn : 0.0, max_pos = mx > 0.0 ? mx : 0.0;
+        // the same NaN-propagating min / max / clamp as qparams_f64_kernel below (torch.min, torch.max, torch.clamp)
+        const double nan = __builtin_nan("");
+        const double min_neg = (mn != mn) ? nan : (mn < 0.0 ? mn : 0.0), max_pos = (mx != mx) ? nan : (mx > 0.0 ? mx : 0.0);
         const double eps = static_cast<double>(1e-8f);
         double scale, zp = 0.0;
         if (symmetric) {
-            const double m = -min_neg > max_pos ? -min_neg : max_pos;
+            const double m = (min_neg != min_neg || max_pos != max_pos) ? nan : (-min_neg > max_pos ? -min_neg : max_pos);
             scale = m / (static_cast<double>(quant_max - quant_min) / 2.0);
-            scale = scale > eps ? scale : eps;
+            scale = (scale != scale) ? nan : (scale > eps ? scale : eps);
         } else {
             scale = (max_pos - min_neg) / static_cast<double>(quant_max - quant_min);
-            scale = scale > eps ? scale : eps;
+            scale = (scale != scale) ? nan : (scale > eps ? scale : eps);
             zp = static_cast<double>(quant_min) - rint(min_neg / scale);
-            zp = zp < quant_min ? quant_min : (zp > quant_max ? quant_max : zp);
+            zp = (zp != zp) ? nan : (zp < quant_min ? quant_min : (zp > quant_max ? quant_max : zp));
         }
         scale_out[0] = static_cast<float>(scale);
         if (zp_out) store_zp(zp_out, zp_type, 0, static_cast<float>(zp));
@@ -603,8 +605,8 @@ __global__ void msefast_done_kernel(const TensorSearch* __restrict__ ts, int* __
 // The launch-per-evaluation form above costs ~12 us per evaluation on a BERT-base site whatever the tensor's size (a
 // kernel boundary, the parameters' round trip through memory, the ticket of the last workgroup, and a 6-27 MB tensor
 // streamed again from L2 / HBM), and an asymmetric per-tensor search is 300-600 evaluations.  Here the VALID part of
-// the tensor is loaded ONCE into the registers of a persistent grid (one 1024-thread workgroup per CU; 16 float4 per
-// lane = 67 MB on 256 CUs), and one evaluation is: every thread's squared errors -> one double per workgroup,
+// the tensor is loaded ONCE into the registers of a persistent grid (one 512-thread workgroup per CU; up to 32 float4
+// per lane = 67 MB on 256 CUs), and one evaluation is: every thread's squared errors -> one double per workgroup,
 // published as two tagged 8-byte granules -> EVERY workgroup collects all partials, adds them in the same order and
 // advances its own copy of the state machine (identical arithmetic on identical numbers: no master, no second
 // exchange).  One hop through memory per evaluation instead of a kernel boundary.  Padded slots hold 0.0f, whose
@@ -612,9 +614,18 @@ __global__ void msefast_done_kernel(const TensorSearch* __restrict__ ts, int* __
 // Tags: epoch + 1 + evaluation; the epoch word lives in the workspace (read by every workgroup at its start, advanced by
 // workgroup 0 at its end -- every workgroup has taken part in the last evaluation by then).  Two buffers of granules:
 // a workgroup can be at most one evaluation ahead of the slowest reader of its previous partial.
-constexpr int kResThreads = 1024;
+//
+// Workgroup shape (round 3): 512 threads = 8 waves = two per SIMD, so a wave may use 256 VGPRs.  Round 2 ran 1024
+// threads (128 VGPRs per wave) with 16 float4 per lane: the float64 error chain, the poll and the Brent step did not
+// fit beside 64 registers of data and the compiler spilled 102-486 VGPRs to scratch in the instantiations that hold
+// 8-16 float4 -- the ones the BERT-base sites use.  Same capacity per CU (512 x 32 float4), same VALU work per SIMD,
+// no scratch (tests/test_abi_and_host.py reads vgpr_spill_count of every msefast_resident* kernel from the library).
+constexpr int kResThreads = 512;
 constexpr int kResWaves = kResThreads / OSQ_WAVE;
+constexpr int kResMaxSlots = 32;                     // float4 per lane
+constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
+static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
     unsigned int epoch, pad0[15];                        // tags handed out so far
@@ -622,6 +633,7 @@ struct ResidentState {                                   // workspace slice, all
     unsigned long long part[2][kResidentMaxSites][kResidentMaxBlocks][2];   // [evaluation parity][site][workgroup]{tag << 32 | low word, tag << 32 | high word}
 };
 static_assert(sizeof(ResidentState) == kWsResidentBytes, "ResidentState must fill its slice of the workspace");
+static_assert(offsetof(ResidentState, status) == 64, "osq_persistent_status (observer.hip) reads the status word at byte 64");
 
 struct ResidentArgs {
     const float* x;
@@ -631,18 +643,182 @@ struct ResidentArgs {
     int vec;
     TensorSearch* ts;
     ResidentState* rs;
+    unsigned int spin_limit;
 };
+
+__device__ __forceinline__ unsigned int uniform(unsigned int v) {
+    return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    const unsigned long long u = (static_cast<unsigned long long>(uniform(static_cast<unsigned int>(b >> 32))) << 32) | uniform(static_cast<unsigned int>(b));
+    return __longlong_as_double(static_cast<long long>(u));
+}
+// the true-division form of the float64 chain, out of line: it runs only for a scale whose significand is all ones (or
+// non-finite extrema), and inlined once per slot it would cost the loop its registers
+__device__ __attribute__((noinline)) double sq_err4_f64_outofline(float4 a, double s, double z, double qmin, double qmax) {
+    return sq_err4_f64(a, s, z, qmin, qmax);
+}
+
+// prefix sums of the clamped lengths of a masked site into pre[0..B] (B <= kResMaxBatch); all threads call
+__device__ __forceinline__ void resident_prefix(const int64_t* lengths, unsigned int Bu, int64_t T, unsigned int* pre, unsigned int* s_wtot) {
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    unsigned int len = 0u;
+    if (static_cast<unsigned int>(tid) < Bu) {
+        int64_t l = lengths ? lengths[tid] : T;
+        l = l < 0 ? 0 : (l > T ? T : l);
+        len = static_cast<unsigned int>(l);
+    }
+    const unsigned int incl = wave_inclusive_scan_u32(len);
+    if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl;
+    __syncthreads();
+    unsigned int base = 0u;
+#pragma unroll
+    for (int k = 0; k < kResWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
+    if (tid == 0) pre[0] = 0u;
+    if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
+    __syncthreads();
+}
+
+// float4 group g of the valid-element stream of a masked site (its tokens listed sample by sample), zero beyond the end
+__device__ __forceinline__ float4 resident_load_masked(const float* x, const osq_token_view& v, int vec, const unsigned int* pre,
+                                                       unsigned int Bu, unsigned int V, uint64_t g) {
+    const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
+    const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
+    auto token_base = [&](unsigned int j) -> const float* {       // valid token j -> its first element
+        unsigned int lo = 0u, hi = Bu;                             // invariant pre[lo] <= j < pre[hi]
+        while (lo + 1u < hi) {
+            const unsigned int mid = (lo + hi) >> 1;
+            if (pre[mid] <= j) lo = mid; else hi = mid;
+        }
+        return x + static_cast<int64_t>(lo) * v.stride_batch + static_cast<int64_t>(j - pre[lo]) * v.stride_token;
+    };
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {                                                     // feat_inner contiguous, 16-byte aligned segments
+        const unsigned int inner4 = fi / 4u, F4 = F / 4u;
+        if (g < static_cast<uint64_t>(V) * F4) {
+            const unsigned int j = static_cast<unsigned int>(g / F4), i = static_cast<unsigned int>(g - static_cast<uint64_t>(j) * F4);
+            const unsigned int o = i / inner4, ii = i - o * inner4;
+            h = reinterpret_cast<const float4*>(token_base(j) + static_cast<int64_t>(o) * v.stride_outer)[ii];
+        }
+    } else {
+        const uint64_t E = static_cast<uint64_t>(V) * F;
+        float e4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t q = g * 4u + c;
+            if (q < E) {
+                const unsigned int j = static_cast<unsigned int>(q / F), f = static_cast<unsigned int>(q - static_cast<uint64_t>(j) * F);
+                const unsigned int o = f / fi, i = f - o * fi;
+                e4[c] = token_base(j)[static_cast<int64_t>(o) * v.stride_outer + static_cast<int64_t>(i) * v.stride_inner];
+            }
+        }
+        h = make_float4(e4[0], e4[1], e4[2], e4[3]);
+    }
+    return h;
+}
+__device__ __forceinline__ float4 resident_load_flat(const float* x, int64_t n, int64_t g) {
+    const int64_t n4 = n / 4;
+    const int tail = static_cast<int>(n - n4 * 4);
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < n4) {
+        h = reinterpret_cast<const float4*>(x)[g];
+    } else if (g == n4 && tail) {
+        const float* t = x + n4 * 4;
+        h.x = t[0];
+        if (tail > 1) h.y = t[1];
+        if (tail > 2) h.z = t[2];
+    }
+    return h;
+}
+
+// Loading goes through a small LDS stage: the addressing of a masked / strided site (a bisection of the prefix sums per
+// token, 64-bit strides) is sizeable code, and a lane's data registers can only be named statically -- unrolled once per
+// slot it was 120-200 KB per instantiation (and beyond the unroller's budget at 32 slots: the array then lived in
+// scratch).  A rolled loop loads kResStage slots into the thread's own LDS cells, a small unrolled loop moves them to the
+// registers.  No barrier: every thread reads back its own cells.
+// Slots KR .. K-1 of a lane (the multi-site kernel at 32 slots: 24 in registers were the most the compiler kept without
+// scratch beside the site tables) stay in LDS cells of their own (`keep`), read back by ds_read_b128 in every evaluation.
+constexpr int kResStage = 8;
+template <int K, int KR, typename Load>
+__device__ __forceinline__ void resident_fill(float4 (&hold)[KR], float4* keep, int slot0, int slots, float4* stage, Load load) {
+    float4* const mine = stage + threadIdx.x;
+    for (int c0 = 0; c0 < slots; c0 += kResStage) {
+#pragma unroll 2
+        for (int kk = 0; kk < kResStage; ++kk)
+            if (c0 + kk < slots) mine[kk * kResThreads] = load(c0 + kk);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int kk = k - slot0 - c0;                             // uniform
+            if (kk >= 0 && kk < kResStage && kk + c0 < slots) {
+                if (k < KR) hold[k < KR ? k : 0] = mine[kk * kResThreads];
+                else keep[(k - KR) * kResThreads + threadIdx.x] = mine[kk * kResThreads];
+            }
+        }
+    }
+}
+
+// One wave: publish this workgroup's partial `p` of one search under `tag`, collect every workgroup's partial of the same
+// tag and return their sum, added in the same order by every workgroup (wave-uniform).  *failed: a partial did not
+// arrive within spin_limit polls.  Lane l takes workgroups l, l + 64, ...: one 16-byte sc1 load per partial (each half
+// carries its own tag), all of a lane's loads in flight together; halves still stale are read again.
+__device__ __forceinline__ double resident_exchange(unsigned long long (*part)[2], double p, unsigned int tag, unsigned int spin_limit, bool* failed) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    if (lane == 0) {
+        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
+        unsigned long long* slot = part[blockIdx.x];
+        __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
+    const auto prs = __builtin_amdgcn_make_buffer_rsrc(&part[0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
+    double got[kSlots];
+    unsigned int pending = 0u;
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+        got[i] = 0.0;
+        if (static_cast<unsigned int>(lane + i * OSQ_WAVE) < gridDim.x) pending |= 1u << i;
+    }
+    unsigned int spins = 0u;
+    while (__any(pending != 0u)) {
+        if (++spins > spin_limit) break;
+        v4u32_t w[kSlots];
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i)
+            if (pending & (1u << i)) w[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, static_cast<unsigned int>(lane + i * OSQ_WAVE) * 16u, 0, 16);
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            if ((pending & (1u << i)) && w[i].y == tag && w[i].w == tag) {
+                got[i] = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(w[i].z) << 32) | w[i].x));
+                pending &= ~(1u << i);
+            }
+        }
+        if (pending) __builtin_amdgcn_s_sleep(1);
+    }
+    *failed = __any(pending != 0u);
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) mine += got[i];               // the same order in every workgroup
+    return wave_sum(mine);
+}
+
+// the squared errors of one held float4 under the pending candidate; every parameter wave-uniform (SGPRs)
+__device__ __forceinline__ double resident_sq_err4(const float4& h, int f64, int fast, float sc, float zp, double sd, double rcp, float qmin, float qmax) {
+    if (!f64) return sq_err4(h, sc, zp, qmin, qmax);
+    if (fast) return sq_err4_f64_rcp(h, sd, rcp, zp, qmin, qmax);
+    return sq_err4_f64_outofline(h, sd, zp, qmin, qmax);
+}
 
 template <int K>
 __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentArgs a) {
-    __shared__ unsigned int pre[1025];
+    __shared__ unsigned int pre[kResMaxBatch + 1];
     __shared__ unsigned int s_wtot[kResWaves];
     __shared__ double s_part[kResWaves];
     __shared__ Search S;
     __shared__ float s_scale, s_zp;
     __shared__ double s_scale_d, s_count;
     __shared__ double s_rcp;
-    __shared__ unsigned int s_epoch, s_done, s_fast, s_kv;
+    __shared__ unsigned int s_epoch, s_done, s_fast, s_kv, s_failed;
 
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
     const unsigned int NT = gridDim.x * kResThreads, gt = blockIdx.x * kResThreads + tid;
@@ -656,102 +832,37 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
         s_done = a.ts->S.done ? 1u : 0u;
         s_rcp = 1.0 / a.ts->scale_d;
         s_fast = rcp_division_exact(a.ts->scale_d, a.ts->S.x_min, a.ts->S.x_max) ? 1u : 0u;
+        s_failed = 0u;
     }
     // ---- load this thread's share of the valid elements: float4 group g = gt + k * NT of the valid-element stream
+    __shared__ float4 stage[kResStage * kResThreads];
     float4 hold[K];
-    if (a.v.batch == 0) {
-        const int64_t n4 = a.n / 4;
-        const int tail = static_cast<int>(a.n - n4 * 4);
-        const float4* x4 = reinterpret_cast<const float4*>(a.x);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int64_t g = static_cast<int64_t>(gt) + static_cast<int64_t>(k) * NT;
-            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < n4) {
-                h = x4[g];
-            } else if (g == n4 && tail) {
-                const float* t = a.x + n4 * 4;
-                h.x = t[0];
-                if (tail > 1) h.y = t[1];
-                if (tail > 2) h.z = t[2];
-            }
-            hold[k] = h;
-        }
+    for (int k = 0; k < K; ++k) hold[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.v.batch == 0) {
+        resident_fill<K, K>(hold, nullptr, 0, K, stage, [&](int k) { return resident_load_flat(a.x, a.n, static_cast<int64_t>(gt) + static_cast<int64_t>(k) * NT); });
         if (tid == 0) { s_count = static_cast<double>(a.n); s_kv = static_cast<unsigned int>(((a.n + 3) / 4 + NT - 1) / NT); }
     } else {
         const osq_token_view v = a.v;
         const unsigned int Bu = static_cast<unsigned int>(v.batch);
-        {
-            unsigned int len = 0u;
-            if (static_cast<unsigned int>(tid) < Bu) {
-                int64_t l = a.lengths ? a.lengths[tid] : v.tokens;
-                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
-                len = static_cast<unsigned int>(l);
-            }
-            const unsigned int incl = wave_inclusive_scan_u32(len);
-            if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl;
-            __syncthreads();
-            unsigned int base = 0u;
-#pragma unroll
-            for (int k = 0; k < kResWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
-            if (tid == 0) pre[0] = 0u;
-            if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
-            __syncthreads();
-        }
+        resident_prefix(a.lengths, Bu, v.tokens, pre, s_wtot);
         const unsigned int V = pre[Bu];                                // valid tokens
         const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
-        const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
         if (tid == 0) {
             s_count = static_cast<double>(V) * static_cast<double>(F);   // observer.py:72-84: what remove_padding keeps
             const uint64_t groups = (static_cast<uint64_t>(V) * F + 3u) / 4u;
             s_kv = static_cast<unsigned int>((groups + NT - 1) / NT);
         }
-        auto token_base = [&](unsigned int j) -> const float* {       // valid token j -> its first element
-            unsigned int lo = 0u, hi = Bu;                             // invariant pre[lo] <= j < pre[hi]
-            while (lo + 1u < hi) {
-                const unsigned int mid = (lo + hi) >> 1;
-                if (pre[mid] <= j) lo = mid; else hi = mid;
-            }
-            return a.x + static_cast<int64_t>(lo) * v.stride_batch + static_cast<int64_t>(j - pre[lo]) * v.stride_token;
-        };
-        if (a.vec) {                                                   // feat_inner contiguous, 16-byte aligned segments
-            const unsigned int inner4 = fi / 4u, F4 = F / 4u;
-            const uint64_t G = static_cast<uint64_t>(V) * F4;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint64_t g = static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT;
-                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g < G) {
-                    const unsigned int j = static_cast<unsigned int>(g / F4), i = static_cast<unsigned int>(g - static_cast<uint64_t>(j) * F4);
-                    const unsigned int o = i / inner4, ii = i - o * inner4;
-                    h = reinterpret_cast<const float4*>(token_base(j) + static_cast<int64_t>(o) * v.stride_outer)[ii];
-                }
-                hold[k] = h;
-            }
-        } else {
-            const uint64_t E = static_cast<uint64_t>(V) * F;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float e4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint64_t q = (static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT) * 4u + c;
-                    if (q < E) {
-                        const unsigned int j = static_cast<unsigned int>(q / F), f = static_cast<unsigned int>(q - static_cast<uint64_t>(j) * F);
-                        const unsigned int o = f / fi, i = f - o * fi;
-                        e4[c] = token_base(j)[static_cast<int64_t>(o) * v.stride_outer + static_cast<int64_t>(i) * v.stride_inner];
-                    }
-                }
-                hold[k] = make_float4(e4[0], e4[1], e4[2], e4[3]);
-            }
-        }
+        const int vec = a.vec;
+        resident_fill<K, K>(hold, nullptr, 0, K, stage, [&](int k) { return resident_load_masked(a.x, v, vec, pre, Bu, V, static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT); });
     }
     __syncthreads();
     const unsigned int base_tag = s_epoch + 1u;
     const double count = s_count;
-    const float qmin = static_cast<float>(S.quant_min), qmax = static_cast<float>(S.quant_max);
-    const bool f64 = S.f64 != 0;
-    const int kv = static_cast<int>(s_kv);                 // float4 slots of every lane that can hold valid data (the rest is padding)
+    const float qmin = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S.quant_min))));
+    const float qmax = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S.quant_max))));
+    const int f64 = static_cast<int>(uniform(static_cast<unsigned int>(S.f64)));
+    const int kv = static_cast<int>(uniform(s_kv));       // float4 slots of every lane that can hold valid data (the rest is padding)
     unsigned int e = 0u;
 #ifdef OSQ_FINAL_TIMING
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -762,17 +873,14 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
 #endif
     // ---- one trip per loss evaluation
     while (!s_done) {                                                  // LDS, uniform: written by thread 0 before the closing barrier
-        const float s = s_scale, z = s_zp;
-        const double sd = s_scale_d, rcp = s_rcp;
-        const bool fast = s_fast != 0u;
+        const float sc = __uint_as_float(uniform(__float_as_uint(s_scale))), zp = __uint_as_float(uniform(__float_as_uint(s_zp)));
+        const double sd = uniform_f64(s_scale_d), rcp = uniform_f64(s_rcp);
+        const int fast = static_cast<int>(uniform(s_fast));
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k < kv) {
-                if (!f64) acc += sq_err4(hold[k], s, z, qmin, qmax);
-                else if (fast) acc += sq_err4_f64_rcp(hold[k], sd, rcp, z, qmin, qmax);
-                else acc += sq_err4_f64(hold[k], sd, z, qmin, qmax);
-            }
+            if (k < kv) acc += resident_sq_err4(hold[k], f64, fast, sc, zp, sd, rcp, qmin, qmax);
+            __builtin_amdgcn_sched_barrier(0);                         // one slot's temporaries at a time
         }
         acc = wave_sum(acc);
         if (lane == 0) s_part[wv] = acc;
@@ -780,64 +888,27 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
         OSQ_RSTAMP(0);
         if (wv == 0) {
             // ---- wave 0: publish this workgroup's partial, collect everybody's, advance the state machine
-            const unsigned int tag = base_tag + e;
             double p = 0.0;
 #pragma unroll
             for (int k = 0; k < kResWaves; ++k) p += s_part[k];
-            if (lane == 0) {
-                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
-                unsigned long long* slot = rs->part[e & 1u][0][blockIdx.x];
-                __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            OSQ_RSTAMP(1);
-            // lane l takes workgroups l, l + 64, ...: one 16-byte sc1 load per partial (each half carries its own tag), all
-            // of a lane's loads in flight together; halves still stale are read again
-            constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
-            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][0][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
-            double got[kSlots];
-            unsigned int pending = 0u;
-#pragma unroll
-            for (int i = 0; i < kSlots; ++i) {
-                got[i] = 0.0;
-                if (static_cast<unsigned int>(lane + i * OSQ_WAVE) < gridDim.x) pending |= 1u << i;
-            }
-            unsigned int spins = 0u;
-            while (__any(pending != 0u)) {
-                if (++spins > kResSpinLimit) break;
-                v4u32_t w[kSlots];
-#pragma unroll
-                for (int i = 0; i < kSlots; ++i)
-                    if (pending & (1u << i)) w[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, static_cast<unsigned int>(lane + i * OSQ_WAVE) * 16u, 0, 16);
-#pragma unroll
-                for (int i = 0; i < kSlots; ++i) {
-                    if ((pending & (1u << i)) && w[i].y == tag && w[i].w == tag) {
-                        got[i] = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(w[i].z) << 32) | w[i].x));
-                        pending &= ~(1u << i);
-                    }
-                }
-                if (pending) __builtin_amdgcn_s_sleep(1);
-            }
-            const bool failed = __any(pending != 0u);
-            double mine = 0.0;
-#pragma unroll
-            for (int i = 0; i < kSlots; ++i) mine += got[i];           // the same order in every workgroup
-            const double tot = wave_sum(mine);
+            bool failed = false;
+            const double tot = resident_exchange(rs->part[e & 1u][0], p, base_tag + e, a.spin_limit, &failed);
             OSQ_RSTAMP(2);
             if (lane == 0) {
                 if (failed) {                                          // poison the search instead of hanging
                     S.best_min = S.best_max = __builtin_nan("");
                     S.done = 1;
                     s_done = 1u;
+                    s_failed = 1u;
                     __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     const double mean = tot / count;
                     S.tell(f64 ? mean : static_cast<double>(static_cast<float>(mean)));
                     if (!S.done) {
-                        float sc, zp;
+                        float scn, zpn;
                         double scd;
-                        loss_qparams(S.cand_min, S.cand_max, S.quant_min, S.quant_max, S.symmetric, &sc, &zp, &scd);
-                        s_scale = sc; s_zp = zp; s_scale_d = scd;
+                        loss_qparams(S.cand_min, S.cand_max, S.quant_min, S.quant_max, S.symmetric, &scn, &zpn, &scd);
+                        s_scale = scn; s_zp = zpn; s_scale_d = scd;
                         s_rcp = 1.0 / scd;
                         s_fast = rcp_division_exact(scd, S.x_min, S.x_max) ? 1u : 0u;
                     }
@@ -852,13 +923,15 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
     }
 #ifdef OSQ_FINAL_TIMING
     if (blockIdx.x == 0 && tid == 0 && e > 0)
-        printf("resident K=%d kv=%d evals=%u: compute+reduce %.2f publish %.2f poll+sum %.2f (unused %.2f) tell %.2f barrier %.2f us per evaluation\n",
+        printf("resident K=%d kv=%d evals=%u: compute+reduce %.2f (unused %.2f) publish+poll+sum %.2f (unused %.2f) tell %.2f barrier %.2f us per evaluation\n",
                K, kv, e, tacc[0] / 100.0 / e, tacc[1] / 100.0 / e, tacc[2] / 100.0 / e, tacc[3] / 100.0 / e, tacc[4] / 100.0 / e, tacc[5] / 100.0 / e);
 #endif
 #undef OSQ_RSTAMP
     if (blockIdx.x == 0 && tid == 0) {
         a.ts->S = S;
-        __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // after a time-out the workgroups may have stopped one evaluation apart: leave a gap so that no granule of this
+        // launch can carry a tag of the next one
+        __hip_atomic_store(&rs->epoch, base_tag + e + (s_failed ? 8u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -868,7 +941,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_kernel(ResidentA
 // serial Brent step leave the VALUs idle.  The observers of one forward are independent (observer passes run with
 // fake-quant off), so up to 16 of them share a launch: a lane's float4 slots are dealt out to the sites (slot_site),
 // every round evaluates every unfinished site's loss, wave w of every workgroup publishes / collects the partials of
-// site w and advances site w's state machine -- the exchange and the Brent steps of all sites overlap.
+// sites w, w + 8 and advances their state machines -- the exchange and the Brent steps of the sites overlap.
 struct ResidentSite {
     const float* x;
     int64_t n;                    // flat tensor (v.batch == 0)
@@ -880,32 +953,19 @@ struct ResidentSite {
 struct ResidentMultiArgs {
     ResidentSite site[kResidentMaxSites];
     int n_sites;
+    unsigned int spin_limit;
     ResidentState* rs;
 };
 
-__device__ __forceinline__ unsigned int uniform(unsigned int v) {
-    return static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
-}
-// the true-division form of the float64 chain, out of line: it runs only for a scale whose significand is all ones (or
-// non-finite extrema), and inlined sixteen times it costs the multi-site loop its registers
-__device__ __attribute__((noinline)) double sq_err4_f64_outofline(float4 a, double s, double z, double qmin, double qmax) {
-    return sq_err4_f64(a, s, z, qmin, qmax);
-}
-__device__ __forceinline__ double uniform_f64(double v) {
-    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
-    const unsigned long long u = (static_cast<unsigned long long>(uniform(static_cast<unsigned int>(b >> 32))) << 32) | uniform(static_cast<unsigned int>(b));
-    return __longlong_as_double(static_cast<long long>(u));
-}
-
 template <int KT>
 __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(ResidentMultiArgs a) {
-    __shared__ unsigned int pre[1025];
+    __shared__ unsigned int pre[kResMaxBatch + 1];
     __shared__ unsigned int s_wtot[kResWaves];
     __shared__ double s_part[kResidentMaxSites][kResWaves];
     __shared__ Search S[kResidentMaxSites];
     __shared__ float s_scale[kResidentMaxSites], s_zp[kResidentMaxSites];
     __shared__ double s_scale_d[kResidentMaxSites], s_rcp[kResidentMaxSites], s_count[kResidentMaxSites];
-    __shared__ unsigned int s_done[kResidentMaxSites], s_fast[kResidentMaxSites], s_kv[kResidentMaxSites], s_epoch, s_active;
+    __shared__ unsigned int s_done[kResidentMaxSites], s_fast[kResidentMaxSites], s_kv[kResidentMaxSites], s_epoch, s_active, s_failed;
     __shared__ ResidentSite s_site[kResidentMaxSites];     // a by-value kernel argument indexed dynamically would be copied to scratch
     __shared__ int s_slot_site[KT];                        // slot -> site (or -1)
 
@@ -936,101 +996,38 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
         s_fast[tid] = rcp_division_exact(ts->scale_d, ts->S.x_min, ts->S.x_max) ? 1u : 0u;
         s_done[tid] = ts->S.done ? 1u : 0u;
     }
-    if (tid == 0) s_epoch = __hip_atomic_load(&rs->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) { s_epoch = __hip_atomic_load(&rs->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_failed = 0u; }
     // ---- load: site after site (the prefix sums of a masked site's lengths take their turn in `pre`)
-    float4 hold[KT];
+    constexpr int KR = KT > 24 ? 24 : KT, KL = KT - KR;      // register slots, LDS slots
+    __shared__ float4 stage[kResStage * kResThreads];
+    __shared__ float4 keep[(KL > 0 ? KL : 1) * (KL > 0 ? kResThreads : 1)];
+    float4 hold[KR];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) hold[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < KR; ++k) hold[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KL; ++k) keep[k * kResThreads + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int si = 0; si < ns; ++si) {
-        const ResidentSite st = s_site[si];
         __syncthreads();                                               // `pre` of the previous site is no longer read
-        if (st.v.batch == 0) {
-            const int64_t n4 = st.n / 4;
-            const int tail = static_cast<int>(st.n - n4 * 4);
-            const float4* x4 = reinterpret_cast<const float4*>(st.x);
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const int kk = k - st.slot0;
-                if (kk < 0 || kk >= st.slots) continue;                // uniform
-                const int64_t g = static_cast<int64_t>(gt) + static_cast<int64_t>(kk) * NT;
-                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g < n4) {
-                    h = x4[g];
-                } else if (g == n4 && tail) {
-                    const float* t = st.x + n4 * 4;
-                    h.x = t[0];
-                    if (tail > 1) h.y = t[1];
-                    if (tail > 2) h.z = t[2];
-                }
-                hold[k] = h;
-            }
-            if (tid == 0) { s_count[si] = static_cast<double>(st.n); s_kv[si] = static_cast<unsigned int>(((st.n + 3) / 4 + NT - 1) / NT); }
+        const int slot0 = s_site[si].slot0, slots = s_site[si].slots;
+        const float* x = s_site[si].x;
+        if (s_site[si].v.batch == 0) {
+            const int64_t n = s_site[si].n;
+            resident_fill<KT, KR>(hold, keep, slot0, slots, stage, [&](int k) { return resident_load_flat(x, n, static_cast<int64_t>(gt) + static_cast<int64_t>(k) * NT); });
+            if (tid == 0) { s_count[si] = static_cast<double>(n); s_kv[si] = static_cast<unsigned int>(((n + 3) / 4 + NT - 1) / NT); }
             continue;
         }
-        const osq_token_view v = st.v;
+        const osq_token_view v = s_site[si].v;
         const unsigned int Bu = static_cast<unsigned int>(v.batch);
-        {
-            unsigned int len = 0u;
-            if (static_cast<unsigned int>(tid) < Bu) {
-                int64_t l = st.lengths ? st.lengths[tid] : v.tokens;
-                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
-                len = static_cast<unsigned int>(l);
-            }
-            const unsigned int incl = wave_inclusive_scan_u32(len);
-            if (lane == OSQ_WAVE - 1) s_wtot[wv] = incl;
-            __syncthreads();
-            unsigned int base = 0u;
-#pragma unroll
-            for (int k = 0; k < kResWaves; ++k) base += (k < wv) ? s_wtot[k] : 0u;
-            if (tid == 0) pre[0] = 0u;
-            if (static_cast<unsigned int>(tid) < Bu) pre[tid + 1] = base + incl;
-            __syncthreads();
-        }
+        resident_prefix(s_site[si].lengths, Bu, v.tokens, pre, s_wtot);
         const unsigned int V = pre[Bu];
         const unsigned int F = static_cast<unsigned int>(v.feat_outer * v.feat_inner);
-        const unsigned int fi = static_cast<unsigned int>(v.feat_inner);
         if (tid == 0) {
             s_count[si] = static_cast<double>(V) * static_cast<double>(F);
             const uint64_t groups = (static_cast<uint64_t>(V) * F + 3u) / 4u;
             s_kv[si] = static_cast<unsigned int>((groups + NT - 1) / NT);
         }
-        auto token_base = [&](unsigned int j) -> const float* {
-            unsigned int lo = 0u, hi = Bu;
-            while (lo + 1u < hi) {
-                const unsigned int mid = (lo + hi) >> 1;
-                if (pre[mid] <= j) lo = mid; else hi = mid;
-            }
-            return st.x + static_cast<int64_t>(lo) * v.stride_batch + static_cast<int64_t>(j - pre[lo]) * v.stride_token;
-        };
-        const unsigned int inner4 = fi / 4u, F4 = F / 4u;
-        const uint64_t G = static_cast<uint64_t>(V) * F4, E = static_cast<uint64_t>(V) * F;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const int kk = k - st.slot0;
-            if (kk < 0 || kk >= st.slots) continue;                    // uniform
-            const uint64_t g = static_cast<uint64_t>(gt) + static_cast<uint64_t>(kk) * NT;
-            float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (st.vec) {
-                if (g < G) {
-                    const unsigned int j = static_cast<unsigned int>(g / F4), i = static_cast<unsigned int>(g - static_cast<uint64_t>(j) * F4);
-                    const unsigned int o = i / inner4, ii = i - o * inner4;
-                    h = reinterpret_cast<const float4*>(token_base(j) + static_cast<int64_t>(o) * v.stride_outer)[ii];
-                }
-            } else {
-                float e4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint64_t q = g * 4u + c;
-                    if (q < E) {
-                        const unsigned int j = static_cast<unsigned int>(q / F), f = static_cast<unsigned int>(q - static_cast<uint64_t>(j) * F);
-                        const unsigned int o = f / fi, i = f - o * fi;
-                        e4[c] = token_base(j)[static_cast<int64_t>(o) * v.stride_outer + static_cast<int64_t>(i) * v.stride_inner];
-                    }
-                }
-                h = make_float4(e4[0], e4[1], e4[2], e4[3]);
-            }
-            hold[k] = h;
-        }
+        const int vec = s_site[si].vec;
+        resident_fill<KT, KR>(hold, keep, slot0, slots, stage, [&](int k) { return resident_load_masked(x, v, vec, pre, Bu, V, static_cast<uint64_t>(gt) + static_cast<uint64_t>(k) * NT); });
     }
     __syncthreads();
     if (tid == 0) {
@@ -1048,7 +1045,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             // slots of a site are contiguous: a change of site closes the previous site's sum (uniform control flow)
-            const int site_k = s_slot_site[k];
+            const int site_k = static_cast<int>(uniform(static_cast<unsigned int>(s_slot_site[k])));
             if (site_k != si) {
                 if (si >= 0 && !s_done[si]) {
                     acc = wave_sum(acc);
@@ -1059,17 +1056,16 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
             }
             if (si < 0 || s_done[si] || static_cast<unsigned int>(k - s_site[si].slot0) >= s_kv[si]) continue;
             // the site's parameters go to SGPRs: as vector registers, hoisted above the arithmetic, the parameters of all
-            // slots would be alive together (11 VGPRs per slot, spilled)
+            // slots would be alive together
             const float qmin = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S[si].quant_min))));
             const float qmax = static_cast<float>(static_cast<int>(uniform(static_cast<unsigned int>(S[si].quant_max))));
             const float zp = __uint_as_float(uniform(__float_as_uint(s_zp[si])));
-            if (!uniform(static_cast<unsigned int>(S[si].f64))) {
-                acc += sq_err4(hold[k], __uint_as_float(uniform(__float_as_uint(s_scale[si]))), zp, qmin, qmax);
-            } else {
-                const double sd = uniform_f64(s_scale_d[si]);
-                if (uniform(s_fast[si])) acc += sq_err4_f64_rcp(hold[k], sd, uniform_f64(s_rcp[si]), zp, qmin, qmax);
-                else acc += sq_err4_f64_outofline(hold[k], sd, zp, qmin, qmax);
-            }
+            const float sc = __uint_as_float(uniform(__float_as_uint(s_scale[si])));
+            const int f64 = static_cast<int>(uniform(static_cast<unsigned int>(S[si].f64)));
+            const int fast = static_cast<int>(uniform(s_fast[si]));
+            const double sd = uniform_f64(s_scale_d[si]), rcp = uniform_f64(s_rcp[si]);
+            const float4 h = k < KR ? hold[k < KR ? k : 0] : keep[(k - KR) * kResThreads + tid];
+            acc += resident_sq_err4(h, f64, fast, sc, zp, sd, rcp, qmin, qmax);
             __builtin_amdgcn_sched_barrier(0);                         // one slot's temporaries at a time
         }
         if (si >= 0 && !s_done[si]) {
@@ -1077,53 +1073,19 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
             if (lane == 0) s_part[si][wv] = acc;
         }
         __syncthreads();
-        if (wv < ns && !s_done[wv]) {
-            // ---- wave w: site w's partial out, everybody's in, site w's state machine one step on
-            const int w = wv;
-            const unsigned int tag = base_tag + e;
+        for (int w = wv; w < ns; w += kResWaves) {
+            if (s_done[w]) continue;
+            // ---- this wave: site w's partial out, everybody's in, site w's state machine one step on
             double p = 0.0;
 #pragma unroll
             for (int k = 0; k < kResWaves; ++k) p += s_part[w][k];
-            if (lane == 0) {
-                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(p));
-                unsigned long long* slot = rs->part[e & 1u][w][blockIdx.x];
-                __hip_atomic_store(&slot[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slot[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            constexpr int kSlots = kResidentMaxBlocks / OSQ_WAVE;
-            const auto prs = __builtin_amdgcn_make_buffer_rsrc(&rs->part[e & 1u][w][0][0], 0, static_cast<int>(gridDim.x * 16u), 0x00020000);
-            double got[kSlots];
-            unsigned int pending = 0u;
-#pragma unroll
-            for (int i = 0; i < kSlots; ++i) {
-                got[i] = 0.0;
-                if (static_cast<unsigned int>(lane + i * OSQ_WAVE) < gridDim.x) pending |= 1u << i;
-            }
-            unsigned int spins = 0u;
-            while (__any(pending != 0u)) {
-                if (++spins > kResSpinLimit) break;
-                v4u32_t wd[kSlots];
-#pragma unroll
-                for (int i = 0; i < kSlots; ++i)
-                    if (pending & (1u << i)) wd[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, static_cast<unsigned int>(lane + i * OSQ_WAVE) * 16u, 0, 16);
-#pragma unroll
-                for (int i = 0; i < kSlots; ++i) {
-                    if ((pending & (1u << i)) && wd[i].y == tag && wd[i].w == tag) {
-                        got[i] = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(wd[i].z) << 32) | wd[i].x));
-                        pending &= ~(1u << i);
-                    }
-                }
-                if (pending) __builtin_amdgcn_s_sleep(1);
-            }
-            const bool failed = __any(pending != 0u);
-            double mine = 0.0;
-#pragma unroll
-            for (int i = 0; i < kSlots; ++i) mine += got[i];
-            const double tot = wave_sum(mine);
+            bool failed = false;
+            const double tot = resident_exchange(rs->part[e & 1u][w], p, base_tag + e, a.spin_limit, &failed);
             if (lane == 0) {
                 if (failed) {
                     S[w].best_min = S[w].best_max = __builtin_nan("");
                     S[w].done = 1;
+                    s_failed = 1u;
                     __hip_atomic_fetch_or(&rs->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     const double mean = tot / s_count[w];
@@ -1148,7 +1110,7 @@ __global__ __launch_bounds__(kResThreads) void msefast_resident_multi_kernel(Res
     }
     if (blockIdx.x == 0) {
         if (tid < ns) s_site[tid].ts->S = S[tid];
-        if (tid == 0) __hip_atomic_store(&rs->epoch, base_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&rs->epoch, base_tag + e + (s_failed ? 8u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1234,6 +1196,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
 static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
+    if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }
 
@@ -1252,7 +1215,7 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
     if (view) {
         const osq_token_view v = *view;
         OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_search: empty view");
-        if (v.batch > 1024) return OSQ_ERR_UNSUPPORTED;
+        if (v.batch > kResMaxBatch) return OSQ_ERR_UNSUPPORTED;
         elems = v.batch * v.tokens * v.feat_outer * v.feat_inner;
         a.v = v;
         a.lengths = lengths;
@@ -1264,12 +1227,13 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
         elems = n;
         a.n = n;
     }
+    a.spin_limit = g_res_spin_limit ? g_res_spin_limit - 1u : kResSpinLimit;
     static int grid = -1;       // per process; devices of one node are identical
-    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_kernel<16>), kResThreads);
-    if (grid < 1 || grid > kResidentMaxBlocks || grid > kResThreads) return OSQ_ERR_UNSUPPORTED;
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_kernel<kResMaxSlots>), kResThreads);
+    if (grid < 1 || grid > kResidentMaxBlocks) return OSQ_ERR_UNSUPPORTED;
     const int64_t per_k = static_cast<int64_t>(grid) * kResThreads * 4;      // elements one float4 per lane holds
     const int64_t need = (elems + per_k - 1) / per_k;
-    if (need > 16) return OSQ_ERR_UNSUPPORTED;
+    if (need > kResMaxSlots) return OSQ_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!persistent_serialize(st)) return OSQ_ERR_UNSUPPORTED;
 #define OSQ_RESIDENT(KK) hipLaunchKernelGGL(msefast_resident_kernel<KK>, dim3(grid), dim3(kResThreads), 0, st, a)
@@ -1277,27 +1241,35 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
     else if (need <= 2) OSQ_RESIDENT(2);
     else if (need <= 4) OSQ_RESIDENT(4);
     else if (need <= 8) OSQ_RESIDENT(8);
-    else if (need <= 12) OSQ_RESIDENT(12);
-    else OSQ_RESIDENT(16);
+    else if (need <= 16) OSQ_RESIDENT(16);
+    else if (need <= 24) OSQ_RESIDENT(24);
+    else OSQ_RESIDENT(32);
 #undef OSQ_RESIDENT
     return check_launch("msefast_tensor_search");
 }
 
-/* Float4 slots per lane of the resident grid that a per-tensor search over `elems` elements occupies (1..16), or 0 when
+/* Float4 slots per lane of the resident grid that a per-tensor search over `elems` elements occupies (1..32), or 0 when
  * it cannot be resident (too large, no persistent grid on this device, osq_set_tuning("mse_resident", 0)).  A group of
- * searches fits one osq_msefast_tensor_search_multi launch when there are at most 16 of them and their slots add up to
- * at most 16. */
+ * searches fits one osq_msefast_tensor_search_multi launch when there are at most osq_msefast_resident_limits' max_sites
+ * of them and their slots add up to at most its max_slots. */
 extern "C" int osq_msefast_resident_slots(int64_t elems) {
     if (!g_mse_resident || elems <= 0) return 0;
     static int grid = -1;
-    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<16>), kResThreads);
-    if (grid < 1 || grid > kResidentMaxBlocks || grid > kResThreads) return 0;
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<kResMaxSlots>), kResThreads);
+    if (grid < 1 || grid > kResidentMaxBlocks) return 0;
     const int64_t per_k = static_cast<int64_t>(grid) * kResThreads * 4;
     const int64_t need = (elems + per_k - 1) / per_k;
-    return need > 16 ? 0 : static_cast<int>(need);
+    return need > kResMaxSlots ? 0 : static_cast<int>(need);
 }
 
-/* Up to 16 per-tensor searches (each between its own osq_msefast_tensor_begin and _commit) in ONE persistent launch:
+extern "C" int osq_msefast_resident_limits(int* max_slots, int* max_sites) {
+    OSQ_REQUIRE(max_slots && max_sites, "msefast_resident_limits: null pointer");
+    *max_slots = kResMaxSlots;
+    *max_sites = kResidentMaxSites;
+    return OSQ_OK;
+}
+
+/* Up to 16 per-tensor searches whose slots add up to at most 32 (each between its own osq_msefast_tensor_begin and _commit) in ONE persistent launch:
  * every round evaluates the pending candidate of every unfinished search.  states[i] / xs[i] / ns[i] / views[i] /
  * lengths[i] as in osq_msefast_tensor_search (views[i].batch == 0: flat, ns[i] elements).  The caller groups with
  * osq_msefast_resident_slots; a group that does not fit returns OSQ_ERR_UNSUPPORTED and launches nothing. */
@@ -1308,6 +1280,7 @@ extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float*
     if (!g_mse_resident || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
     ResidentMultiArgs a{};
     a.n_sites = n_sites;
+    a.spin_limit = g_res_spin_limit ? g_res_spin_limit - 1u : kResSpinLimit;
     a.rs = static_cast<ResidentState*>(Workspace(workspace).resident());
     int slot = 0;
     for (int i = 0; i < n_sites; ++i) {
@@ -1319,7 +1292,7 @@ extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float*
         if (views[i].batch > 0) {
             const osq_token_view v = views[i];
             OSQ_REQUIRE(v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_search_multi: empty view");
-            if (v.batch > 1024) return OSQ_ERR_UNSUPPORTED;
+            if (v.batch > kResMaxBatch) return OSQ_ERR_UNSUPPORTED;
             elems = v.batch * v.tokens * v.feat_outer * v.feat_inner;
             s.v = v;
             s.lengths = lengths[i];
@@ -1337,17 +1310,17 @@ extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float*
         s.slots = k;
         slot += k;
     }
-    if (slot > 16) return OSQ_ERR_UNSUPPORTED;
+    if (slot > kResMaxSlots) return OSQ_ERR_UNSUPPORTED;
     static int grid = -1;
-    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<16>), kResThreads);
+    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<kResMaxSlots>), kResThreads);
     if (grid < 1) return OSQ_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!persistent_serialize(st)) return OSQ_ERR_UNSUPPORTED;
 #define OSQ_RESIDENT_MULTI(KK) hipLaunchKernelGGL(msefast_resident_multi_kernel<KK>, dim3(grid), dim3(kResThreads), 0, st, a)
-    if (slot <= 4) OSQ_RESIDENT_MULTI(4);
-    else if (slot <= 8) OSQ_RESIDENT_MULTI(8);
-    else if (slot <= 12) OSQ_RESIDENT_MULTI(12);
-    else OSQ_RESIDENT_MULTI(16);
+    if (slot <= 8) OSQ_RESIDENT_MULTI(8);
+    else if (slot <= 16) OSQ_RESIDENT_MULTI(16);
+    else if (slot <= 24) OSQ_RESIDENT_MULTI(24);
+    else OSQ_RESIDENT_MULTI(32);
 #undef OSQ_RESIDENT_MULTI
     return check_launch("msefast_tensor_search_multi");
 }

@@ -897,6 +897,7 @@ static int g_fused_gate = 2;          // osq_set_tuning("fused_gate", 0|1|2): wh
 #ifndef OSQ_FUSED_DEAL_DEFAULT
 #define OSQ_FUSED_DEAL_DEFAULT 2
 #endif
+static unsigned int g_fused_spin_limit = 0;     // osq_set_tuning("fused_spin_limit", n): 0 = kFusedSpinLimit, n > 0 = n - 1 polls (1: every wait gives up at once -- tests force the time-out path with it)
 static int g_fused_deal = OSQ_FUSED_DEAL_DEFAULT;   // osq_set_tuning("fused_deal", 0|1|2): how a slot's tokens are dealt to the waves (fused_step.h)
 static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
@@ -1308,6 +1309,7 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "fused_gate") { if (value < 0 || value > 2) return false; g_fused_gate = value; return true; }
     if (k == "fused_deal") { if (value < 0 || value > 2) return false; g_fused_deal = value; return true; }
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
+    if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
@@ -1598,6 +1600,8 @@ bool persistent_serialize(hipStream_t st) {
     return true;
 }
 
+static_assert(sizeof(FusedState) <= kWsFusedBytes, "FusedState must fit its slice of the workspace");
+
 template <int NV>
 static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) {
     static int grid = -1;       // per process; devices of one node are identical
@@ -1635,7 +1639,8 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
         const Finish fin{update_rule, cnt, min_val, max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
         const FusedArgs a{x, y, v.batch, v.tokens, lengths, token_min, token_max, prune, static_cast<float>(percentile),
                           g_select_shortcut, static_cast<FusedState*>(Workspace(workspace).fused()), scale, zero_point,
-                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_fused_deal};
+                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_fused_deal,
+                          g_fused_spin_limit ? g_fused_spin_limit - 1u : kFusedSpinLimit};
         hipStream_t st = static_cast<hipStream_t>(stream);
         bool launched = false;
         switch (nv) {
@@ -1665,6 +1670,41 @@ extern "C" int osq_fused_step_status(void* workspace, int* status_out, osq_strea
         return OSQ_ERR_HIP;
     }
     *status_out = static_cast<int>(v);
+    return OSQ_OK;
+}
+
+/* Sticky time-out flags of BOTH persistent launch families on this workspace (the fused observe + fake-quant step and
+ * the resident MSEFast searches), read and cleared after everything enqueued on `stream` has finished.  With
+ * reset_on_error != 0 a non-zero flag also puts the two state blocks back to their all-zero start (nothing is in
+ * flight on this workspace after the synchronisation): the next launch starts clean. */
+extern "C" int osq_persistent_status(void* workspace, int* fused_status_out, int* resident_status_out, int reset_on_error,
+                                     osq_stream stream) {
+    OSQ_REQUIRE(workspace && fused_status_out && resident_status_out, "persistent_status: null pointer");
+    const Workspace ws(workspace);
+    FusedState* fs = static_cast<FusedState*>(ws.fused());
+    unsigned int* rs_status = reinterpret_cast<unsigned int*>(static_cast<char*>(ws.resident()) + 64);   // ResidentState::status (msefast.hip)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned int f = 0u, r = 0u;
+    if (hipMemcpyAsync(&f, &fs->status, sizeof(f), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&r, rs_status, sizeof(r), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        set_error("persistent_status: copy failed");
+        return OSQ_ERR_HIP;
+    }
+    if (f || r) {
+        hipError_t e = hipSuccess;
+        if (reset_on_error) e = hipMemsetAsync(ws.fused(), 0, kWsFusedBytes + kWsResidentBytes, st);
+        else {
+            e = hipMemsetAsync(&fs->status, 0, sizeof(f), st);
+            if (e == hipSuccess) e = hipMemsetAsync(rs_status, 0, sizeof(r), st);
+        }
+        if (e != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            set_error("persistent_status: reset failed");
+            return OSQ_ERR_HIP;
+        }
+    }
+    *fused_status_out = static_cast<int>(f);
+    *resident_status_out = static_cast<int>(r);
     return OSQ_OK;
 }
 

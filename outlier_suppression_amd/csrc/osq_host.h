@@ -19,7 +19,7 @@ constexpr size_t kWsScratchPerFamily = 64 * 1024;             // 2048 partials o
 constexpr size_t kWsScratchBytes = kWsFamilies * kWsScratchPerFamily;
 constexpr size_t kWsWideBytes = 2 * 2048 * 4 + 64;   // WideState of the multi-workgroup token finaliser
 constexpr size_t kWsMeetBytes = 64 * 1024;           // rendezvous words of token_select_kernel (8 B per problem)
-constexpr size_t kWsFusedBytes = 1024;               // FusedState of the one-launch observe + fake-quant (fused_step.h)
+constexpr size_t kWsFusedBytes = 2048;               // FusedState of the one-launch observe + fake-quant (fused_step.h)
 constexpr int kResidentMaxBlocks = 512;              // workgroups of the resident MSEFast search (msefast.hip)
 constexpr int kResidentMaxSites = 16;                // searches one multi-site launch can hold (one polling wave each)
 constexpr size_t kWsResidentBytes = 128 + 2 * static_cast<size_t>(kResidentMaxSites) * kResidentMaxBlocks * 2 * 8;   // its epoch / status words + two buffers of partial-sum granules per site
@@ -64,7 +64,7 @@ static inline int check_launch(const char* what) {
 }
 
 // Caller-owned scratch: [8 x 4 KiB of ticket counters][8 x 64 KiB of partials][16 KiB + 64 B wide-finaliser state]
-// [64 KiB rendezvous words][1 KiB state of the fused observe + fake-quant launch][256.1 KiB state of the resident MSEFast search].  Counters are zero between
+// [64 KiB rendezvous words][2 KiB state of the fused observe + fake-quant launch][256.1 KiB state of the resident MSEFast search].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;

@@ -351,6 +351,54 @@ def set_wide_min_slots(slots):
 
 
 
+# ---------------------------------------------------------------------------------------
+# persistent launches: time-outs must not stay silent
+# ---------------------------------------------------------------------------------------
+# The one-launch observe + fake-quant step and the resident MSEFast searches are grids whose workgroups wait for each
+# other; when they are not resident together (another process on the GPU, another stream's long kernel on the CUs) a
+# bounded wait expires, the launch writes NaN and raises a sticky flag in its workspace.  Every such launch marks its
+# (device, stream) workspace here; check_persistent() -- called at the host's synchronisation points: the state
+# togglers, state_dict(), the end of calibrate / find_ratio / learn_scale / calibrate_sharded / ptq.run, the flush of a
+# deferred observer pass that ran searches -- reads the flags of the marked workspaces (one stream synchronisation
+# each, nothing when nothing persistent ran), resets the state blocks and raises.
+_persistent_dirty = set()
+
+
+class PersistentLaunchTimeout(RuntimeError):
+    pass
+
+
+def _mark_persistent(device):
+    _persistent_dirty.add((_hip._device_index(device), _hip.raw_stream(device)))
+
+
+def check_persistent(where=""):
+    """Raise PersistentLaunchTimeout if a persistent launch since the last check timed out.  Synchronises the streams
+    that ran persistent launches since then; free when there were none."""
+    if not _persistent_dirty:
+        return
+    lib = _hip.load()
+    failed = []
+    for key in sorted(_persistent_dirty):
+        ws = _hip._workspaces.get(key)
+        if ws is None:
+            continue
+        f, r = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(key[0]):
+            _hip.check(lib.osq_persistent_status(ws.data_ptr(), ctypes.byref(f), ctypes.byref(r), 1, key[1]), "persistent_status")
+        if f.value or r.value:
+            failed.append((key[0], f.value, r.value))
+    _persistent_dirty.clear()
+    if failed:
+        what = "; ".join(f"device {d}: fused observe+fake-quant step status {f}, resident MSEFast search status {r}" for d, f, r in failed)
+        raise PersistentLaunchTimeout(
+            f"outlier_suppression_amd{' (' + where + ')' if where else ''}: a persistent launch timed out waiting for its own "
+            f"workgroups ({what}).  Its outputs and the statistics / scale / zero_point it wrote are NaN-poisoned: everything "
+            "computed since the previous check is invalid.  Cause: the grid was not resident together -- another process is "
+            "using this GPU, or another stream of this process kept CUs busy.  Set OSQ_FUSED_STEP=0 (launch-per-stage "
+            "kernels, no cross-workgroup waits) when the GPU is shared.  The launch state has been reset.")
+
+
 def _scratch(device, n):
     """(token_min, token_max, list_scratch): per (device, stream) scratch, grown on demand.  The three
     views are cached per slot count: building tensor views costs microseconds on a path that runs per site."""
@@ -451,6 +499,7 @@ def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt,
                                            lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))
     if rc != 0:
         _hip.check(rc, "observe_tokens_fake_quant")
+    _persistent_dirty.add((dev.index, _hip.raw_stream(dev)))
     return y, view.batch, view.tokens, lengths
 
 
@@ -574,6 +623,8 @@ def msefast_tensor_run(r, chunk=None, two_d=True):
                                        _hip.ptr(r.lengths), _hip.ptr(ws), st)
     if rc not in (0, _hip.ERR_UNSUPPORTED):
         _hip.check(rc, "msefast_tensor_search")
+    if rc == 0:
+        _mark_persistent(dev)
     done = torch.zeros(1, dtype=torch.int32, device=dev)
     chunk = chunk or (64 if two_d else 32)
     launched = 0
@@ -608,11 +659,25 @@ def msefast_tensor_run_group(group):
     if rc == _hip.ERR_UNSUPPORTED:
         return False
     _hip.check(rc, "msefast_tensor_search_multi")
+    _mark_persistent(dev)
     return True
 
 
 def msefast_resident_slots(elems):
     return int(_hip.load().osq_msefast_resident_slots(int(elems)))
+
+
+_resident_limits = None
+
+
+def msefast_resident_limits():
+    """(float4 slots per lane, searches) one osq_msefast_tensor_search_multi launch can hold."""
+    global _resident_limits
+    if _resident_limits is None:
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _hip.check(_hip.load().osq_msefast_resident_limits(ctypes.byref(a), ctypes.byref(b)), "msefast_resident_limits")
+        _resident_limits = (a.value, b.value)
+    return _resident_limits
 
 
 def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None, ref_float64=None):

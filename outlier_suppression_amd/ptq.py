@@ -81,11 +81,16 @@ def run(model, fp_input, fp_output, config_quant, config_model, per_device_eval_
         disable_all(model)
         set_observer_name(model)
         TWC.model_type, TWC.task_type = config_model.model_type, config_model.task_type
+        # token_wise_clipping.py:140-146: step / iters from cac_step_iters, EACH overridden on its own by the section
         if hasattr(config_quant, "iters") and hasattr(config_quant, "step"):
-            grid = {"iters": config_quant.iters, "step": config_quant.step}
+            step, iters = config_quant.step, config_quant.iters          # nothing left to derive: config_data not needed
         else:
-            step, iters = TWC.cac_step_iters(config_quant.a_qconfig.bit, per_device_eval_batch_size, config_data)
-            grid = {"iters": iters, "step": step}
+            if config_data is None:
+                raise ValueError("ptq.run: the quant section gives no `iters` + `step`, so the grid comes from "
+                                 "cac_step_iters(a_bit, batch size, config.data) (token_wise_clipping.py:118-129): pass "
+                                 "config_data with max_seq_length (GLUE / SQuAD) or max_source_length (summarisation)")
+            step, iters = TWC.cac_step_iters(config_quant.a_qconfig.bit, per_device_eval_batch_size, namespace(config_data))
+        grid = {"iters": getattr(config_quant, "iters", iters), "step": getattr(config_quant, "step", step)}
         trainer = NS(model=model)
         (TWC.find_ratio_cached if search == "cached" else TWC.find_ratio)(trainer, fp_input, fp_output, grid)
         if "LSQ" in config_quant.a_qconfig.quantizer:
@@ -98,4 +103,6 @@ def run(model, fp_input, fp_output, config_quant, config_model, per_device_eval_
         calibrate(model, fp_input)
     if full_quantization:
         enable_quantization(model)         # ptq_glue_quant.py:249-251
+    from . import ops
+    ops.check_persistent("ptq.run")
     return model

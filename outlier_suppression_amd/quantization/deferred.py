@@ -35,7 +35,7 @@ class DeferredSites:
 
     def add_mse(self, obs, search, two_d, sink):
         """A per-tensor MSEFast search that has begun (ops.msefast_tensor_begin): its loss evaluations run at the flush,
-        together with the other searches of the forward (up to 16 per persistent launch); its batch counter is the one
+        together with the other searches of the forward (up to 16 per persistent launch, 32 float4 slots per lane); its batch counter is the one
         of the call."""
         self.mse.append((obs, search, two_d, sink, obs._counter(), obs.update_rule))
 
@@ -43,14 +43,16 @@ class DeferredSites:
         pending, self.mse = self.mse, []
         if not pending:
             return 0
-        # greedy groups: at most 16 searches and 16 float4 slots per lane in a launch; what cannot be resident runs alone
+        # greedy groups: at most max_sites searches and max_slots float4 slots per lane in a launch (16 and 32); what cannot
+        # be resident runs alone
+        max_slots, max_sites = ops.msefast_resident_limits()
         groups, cur, used = [], [], 0
         for item in pending:
             k = ops.msefast_resident_slots(item[1].elems)
             if k == 0:
                 groups.append([item])
                 continue
-            if cur and (used + k > 16 or len(cur) == 16):
+            if cur and (used + k > max_slots or len(cur) == max_sites):
                 groups.append(cur)
                 cur, used = [], 0
             cur.append(item)
@@ -66,6 +68,7 @@ class DeferredSites:
             obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink,
                                                       obs._ref_flags(obs.min_val.device))
         self.flushed_sites += len(pending)
+        ops.check_persistent("deferred MSEFast searches")     # one synchronisation per flushed forward: the searches took milliseconds
         return len(pending)
 
     def add(self, obs, x, lengths, seq_pos, prune, sink):

@@ -32,6 +32,7 @@ class QuantizeBase(nn.Module):
 
     @torch.jit.export
     def calculate_qparams(self):
+        ops.check_persistent("calculate_qparams")
         return self.observer.calculate_qparams(self.observer.min_val, self.observer.max_val)
 
     @torch.jit.export
@@ -137,6 +138,7 @@ class QuantizeBase(nn.Module):
 
     # ---- state dict: scale / zero_point change size on the first observation ----------
     def _save_to_state_dict(self, destination, prefix, keep_vars):
+        ops.check_persistent("state_dict")        # what is about to be saved must not come from a timed-out launch
         super()._save_to_state_dict(destination, prefix, keep_vars)
         destination[prefix + "scale"] = self.scale
         destination[prefix + "zero_point"] = self.zero_point

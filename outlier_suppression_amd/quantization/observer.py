@@ -282,6 +282,7 @@ class MSEFastObserver(ObserverBase):
                 ops.msefast_tensor_run(search, None, two_d)
                 self.last_nfev = ops.msefast_tensor_commit(search, self.update_rule, self._counter(), self.min_val, self.max_val, sink,
                                                            self._ref_flags(x.device))
+                ops.check_persistent("MSEFast search")     # one synchronisation behind a search of milliseconds
         else:
             bmin, bmax, self.last_nfev = ops.msefast_rows(x, self.ch_axis, self.quant_min, self.quant_max,
                                                           self.symmetric, self.one_side_dist, two_d)

@@ -6,6 +6,7 @@ same logger name.
 """
 import logging
 
+from .. import ops
 from .fake_quant import LSQFakeQuantize, LSQPlusFakeQuantize, QuantizeBase
 from .observer import ObserverBase
 
@@ -16,8 +17,19 @@ def _quantizers(model):
     return ((n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase))
 
 
+def _transition(model):
+    """Every state change is a synchronisation point of the calibration flow: surface a time-out of the persistent
+    launches issued in the state that ends here (ops.check_persistent: free when none ran), and drop the kept
+    fake-quantised weights -- callers edit weights between states through paths the cache key cannot see (`.data`
+    arithmetic as in the reference's gamma_migration.py:70-71, foreign kernels)."""
+    ops.check_persistent("quantizer state change")
+    from . import weight_cache
+    weight_cache.invalidate(model)
+
+
 def _switch(model, quantizer_type, except_quantizer, observe, quantize, learnable_observe=None):
     """Apply (observer on/off, fake-quant on/off) to selected quantizers; everything else off."""
+    _transition(model)
     for name, q in _quantizers(model):
         selected = quantizer_type in name and not (except_quantizer is not None and name in except_quantizer)
         want_obs, want_fq = (observe, quantize) if selected else (False, False)
@@ -50,6 +62,7 @@ def enable_quantization(model, quantizer_type="fake_quant", except_quantizer=Non
 def disable_all(model):
     """state.py:56-62."""
     logger.info("Disable observer and disable quantize.")
+    _transition(model)
     for _, q in _quantizers(model):
         q.disable_observer()
         q.disable_fake_quant()

@@ -71,6 +71,8 @@ def calibrate(model, fp_input, fp_output=None):
                 sites.flush()
             if fp_output is not None:
                 loss += batch_loss(outputs, batch, fp_output[i])
+    from . import ops
+    ops.check_persistent("calibrate")       # free unless a persistent launch ran in this pass (both flags on, or searches)
     return loss
 
 
@@ -137,6 +139,8 @@ def learn_scale(trainer, fp_input, fp_output, config_quant_learn):
                 loss.backward()
                 opt.step()
                 sched.step()
+    from . import ops
+    ops.check_persistent("learn_scale")
 
 
 def learn_scale_sharded(trainer, fp_input, fp_output, config_quant_learn, group=None):
@@ -432,4 +436,5 @@ def find_ratio_cached(trainer, fp_input, fp_output, param, n_batches=None, group
     for _, q in qs:                 # state find_ratio leaves behind: observers on, fake-quant off
         q.disable_fake_quant()
         q.enable_observer()
+    ops.check_persistent("find_ratio_cached")
     return ratio

@@ -226,3 +226,24 @@ def test_quantize_model_takes_the_reference_config_form():
     assert get_model_task_type("bartforconditionalgeneration", NS(dataset_name="xsum")) == ("summ", "bart")
     with pytest.raises(NotImplementedError):
         get_model_task_type("bertforsequenceclassification", NS(dataset_name="imdb"))
+
+
+def test_resident_kernels_do_not_spill():
+    """The resident MSEFast kernels exist to keep a tensor in registers across hundreds of loss evaluations: a spilled
+    VGPR is a scratch round trip in every evaluation.  Round 2 shipped them with 102-486 spilled VGPRs; this reads the
+    code-object metadata of the built library (no GPU needed) and fails on the first spilled or scratch-backed one.
+    The fused observe + fake-quant kernel is held to the same bar (its noinline selection call may use stack)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+    rows = kernel_resources.kernel_resources()
+    assert len(rows) > 50, "could not read the code-object notes of libosq_hip.so"
+    resident = [r for r in rows if "msefast_resident" in r["name"]]
+    assert len(resident) >= 11
+    for r in resident:
+        assert r.get("vgpr_spill_count", 0) == 0 and r.get("private_segment_fixed_size", 0) == 0, r
+        assert r.get("max_flat_workgroup_size") == 512, r
+    for r in rows:
+        if "observe_fq_fused_kernel" in r["name"] or "msefast_rows_kernel" in r["name"]:
+            assert r.get("vgpr_spill_count", 0) == 0, r

@@ -81,3 +81,100 @@ def test_single_process_passthrough():
     from outlier_suppression_amd.calibration import gather_batch_table
     t = torch.arange(24.0).reshape(4, 3, 2)
     assert torch.equal(gather_batch_table(t, 3), t[:3])
+
+
+# ---- site-sharded passes (calibration.calibrate_owned_sites): the deal and the exchange of final states
+
+def _site_quantizers():
+    """Quantizers as a site-sharded pass leaves them on their OWNER: a per-tensor AvgMSEFast activation quantizer
+    (float64 statistics, dtype flags, counter, sidedness), a per-channel MSEFast weight quantizer ([C] fp32 statistics,
+    int32 zero-points) and a learnable per-tensor one (fp32 Parameters)."""
+    from types import SimpleNamespace as NS
+    from outlier_suppression_amd.quantization import Quantizer
+    torch.manual_seed(5)
+    a = Quantizer(None, NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1))
+    w = Quantizer(None, NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0))
+    l = Quantizer(None, NS(quantizer="LSQPlusFakeQuantize", observer="AvgQuantileObserver", bit=6, symmetric=False, ch_axis=-1))
+    return [("layer.act_fake_quant_a", a), ("layer.weight_fake_quant", w), ("layer.act_fake_quant_l", l)]
+
+
+def _fill_owned(q, i):
+    obs = q.observer
+    if i == 0:
+        obs.min_val = torch.tensor(-1.2345678901234567, dtype=torch.float64)
+        obs.max_val = torch.tensor(float("nan"), dtype=torch.float64)           # NaN travels as NaN
+        obs.cnt, obs.one_side_dist = 8, "no"
+        obs._ref_flags(torch.device("cpu")).copy_(torch.tensor([1, 0], dtype=torch.int32))
+        q.scale.copy_(torch.tensor([0.0371]))
+        q.zero_point.copy_(torch.tensor([31], dtype=torch.int32))
+    elif i == 1:
+        obs.min_val = -torch.rand(5) - 0.1
+        obs.max_val = torch.rand(5) + 0.1
+        obs.one_side_dist = "no"
+        q.scale = torch.rand(5) + 0.01
+        q.zero_point = torch.zeros(5, dtype=torch.int32)
+        obs.last_nfev = torch.tensor([15, 14, 16, 15, 17], dtype=torch.int32)
+    else:
+        obs.min_val = torch.tensor(-0.5)
+        obs.max_val = torch.tensor(7.25)
+        obs.cnt = 3
+        q.scale.data = torch.tensor([0.123])
+        q.zero_point.data = torch.tensor([4.0])
+
+
+def _site_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from outlier_suppression_amd import calibration
+    qs = _site_quantizers()
+    channels = [1, 5, 1]
+    owner = [0, 1, 0]
+    for i, (_, q) in enumerate(qs):
+        if owner[i] == rank:
+            _fill_owned(q, i)
+    calibration.exchange_site_states(qs, channels, owner, rank, world, torch.device("cpu"))
+    out = {}
+    for i, (_, q) in enumerate(qs):
+        obs = q.observer
+        out[f"mn{i}"], out[f"mx{i}"] = obs.min_val.numpy(), obs.max_val.numpy()
+        out[f"s{i}"], out[f"z{i}"] = q.scale.detach().numpy(), q.zero_point.detach().numpy()
+        out[f"cnt{i}"] = np.array(getattr(obs, "cnt", -1))
+        out[f"side{i}"] = np.array(str(getattr(obs, "one_side_dist", None)))
+    out["flags0"] = qs[0][1].observer._ref_flags(torch.device("cpu")).numpy()
+    np.savez(os.path.join(out_dir, f"sites_{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_site_states_reach_every_rank_world2(tmp_path):
+    """calibration.exchange_site_states: after the one all-gather every rank holds every site's final statistics, scale,
+    zero_point, counters and dtype flags exactly as its owner computed them -- values, dtypes and shapes."""
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_site_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = _site_quantizers()
+    for i, (_, q) in enumerate(want):
+        _fill_owned(q, i)
+    r0, r1 = np.load(tmp_path / "sites_0.npz"), np.load(tmp_path / "sites_1.npz")
+    for got in (r0, r1):
+        for i, (_, q) in enumerate(want):
+            obs = q.observer
+            for key, ref in ((f"mn{i}", obs.min_val), (f"mx{i}", obs.max_val), (f"s{i}", q.scale.detach()), (f"z{i}", q.zero_point.detach())):
+                a, b = got[key], ref.numpy()
+                assert a.dtype == b.dtype and a.shape == b.shape, (key, a.dtype, b.dtype, a.shape, b.shape)
+                assert np.array_equal(a, b, equal_nan=True), key
+            assert int(got[f"cnt{i}"]) == getattr(obs, "cnt", -1)
+            assert str(got[f"side{i}"]) == str(getattr(obs, "one_side_dist", None))
+        assert list(got["flags0"]) == [1, 0]
+
+
+def test_deal_sites_is_balanced_and_deterministic():
+    from outlier_suppression_amd.calibration import deal_sites
+    # a BERT-base layer's sites (elements x search weight): 7 hidden-sized, attention probabilities (1-D), GELU output
+    layer = [3.1e6 * 350] * 7 + [6.3e6 * 20] + [12.6e6 * 350]
+    costs = layer * 12 + [24.6e3 * 350] * 2
+    for world in (2, 4, 8):
+        owner = deal_sites(costs, world)
+        assert owner == deal_sites(list(costs), world)
+        load = [sum(c for c, r in zip(costs, owner) if r == k) for k in range(world)]
+        assert max(load) <= 1.08 * (sum(costs) / world), (world, load)
+    assert deal_sites([], 4) == [] and deal_sites([5.0, 1.0], 1) == [0, 0]

@@ -77,6 +77,113 @@ def test_fused_step_vs_oracle(shape, eq32, dev):
     assert fused_status(dev) == 0
 
 
+@pytest.mark.parametrize("shape,lengths", [((256, 128, 768), "bench"), ((256, 128, 768), "full"), ((256, 128, 768), "zeros"),
+                                           ((256, 128, 1024), "bench")])
+def test_fused_step_vs_oracle_at_the_headline_shape(shape, lengths, eq32, dev):
+    """The bench kernel at the bench shape, DIRECTLY against the oracle: BERT-base [256,128,768]
+    with the bench's length distribution, with every token valid, and with a lengths vector that holds zeros and full
+    rows; plus [256,128,1024], whose 32768 tokens of 1024 floats exceed what the waves keep (streamed tail).  Three
+    batches each, so the running mean is exercised; min_val / max_val / scale / zero_point and every element of y
+    bit-equal to observer.py:50-70,206-237 + util_quant.py:48-55 as restated in oracle/."""
+    from oracle import observer_oracle as OB, fake_quant_oracle as FQ
+    B, T, H = shape
+    gen = torch.Generator().manual_seed(1234)
+    outliers = torch.randperm(H, generator=gen)[:6]
+    q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False, percentile=0.95)
+    st = OB.ObserverState(bit=6, symmetric=False, name=q.observer.name)
+    st.percentile = 0.95
+    for it in range(3):
+        if lengths == "bench":
+            L = torch.randint(8, T + 1, (B,), generator=gen)
+        elif lengths == "full":
+            L = torch.full((B,), T)
+        else:
+            L = torch.randint(0, T + 1, (B,), generator=gen)
+            L[::7] = 0
+            L[3::11] = T
+        x = torch.randn(*shape, generator=gen) * (1.0 + 0.5 * it)
+        x[..., outliers] *= 20.0
+        with torch.no_grad():
+            y = q(x.to(dev), L.to(dev), 1)
+        OB.observe_avg_prune_minmax(st, x.numpy(), L.numpy(), 1)
+        scale, zp = st.qparams()
+        assert eq32(q.observer.min_val.cpu().numpy(), st.min_val) and eq32(q.observer.max_val.cpu().numpy(), st.max_val), it
+        assert np.float32(q.scale.item()) == np.float32(scale) and np.float32(q.zero_point.item()) == np.float32(zp), it
+        _, ref = FQ.fake_quantize_learnableplus_per_tensor(x.numpy(), scale, zp, 0, 63, FQ.lsqplus_grad_factor(x.numel(), 63))
+        assert eq32(y.cpu().numpy(), ref), (shape, lengths, it)
+        del y, ref
+    assert fused_status(dev) == 0
+
+
+def test_fused_step_time_out_is_loud_and_recoverable(eq32, dev):
+    """A persistent launch whose workgroups do not meet (here: the test knob shortens every cross-workgroup wait to one
+    poll, so the selectors give up before the streaming workgroups arrive) must not go unnoticed: y and the statistics
+    are NaN, the sticky flag is up, ops.check_persistent raises at the next synchronisation point (here: state_dict())
+    and resets the launch state -- the next launch is correct again, also after the late arrivals of the failed one."""
+    from outlier_suppression_amd import ops
+    x = torch.randn(64, 128, 768)
+    L = torch.randint(8, 129, (64,))
+    ops.check_persistent()
+    ref_q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+    with torch.no_grad():
+        ref = ref_q(x.to(dev), L.to(dev), 1).cpu()
+    ops.check_persistent()
+    ops.set_tuning("fused_spin_limit", 1)
+    try:
+        q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+        with torch.no_grad():
+            y = q(x.to(dev), L.to(dev), 1)
+            y2 = q(x.to(dev), L.to(dev), 1)           # a second launch on the poisoned state, before anybody looked
+        torch.cuda.synchronize()
+        assert torch.isnan(y).all() and torch.isnan(y2).all()
+        with pytest.raises(ops.PersistentLaunchTimeout):
+            q.state_dict()
+    finally:
+        ops.set_tuning("fused_spin_limit", 0)
+    ops.check_persistent()                             # the flag was consumed and the state reset: nothing left to report
+    q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+    with torch.no_grad():
+        for _ in range(3):
+            y = q(x.to(dev), L.to(dev), 1)
+    q2 = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+    with torch.no_grad():
+        y2 = q2(x.to(dev), L.to(dev), 1)
+    assert eq32(y2.cpu().numpy(), ref.numpy())
+    q.state_dict()
+    assert fused_status(dev) == 0
+
+
+def test_fused_step_time_out_without_reset_heals(eq32, dev):
+    """The launch state itself survives a time-out (round 2 zeroed the arrival counters in use, which a workgroup arriving
+    after the time-out then left at 1 for every later launch): WITHOUT the host's reset -- only the flag is read through
+    the C ABI -- the launches after a timed-out one are correct."""
+    from outlier_suppression_amd import ops
+    x = torch.randn(64, 128, 768)
+    L = torch.randint(8, 129, (64,))
+    ops.check_persistent()
+    ref_q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+    with torch.no_grad():
+        ref = ref_q(x.to(dev), L.to(dev), 1).cpu()
+    ops.set_tuning("fused_spin_limit", 1)
+    try:
+        q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+        with torch.no_grad():
+            for _ in range(3):
+                q(x.to(dev), L.to(dev), 1)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("fused_spin_limit", 0)
+    assert fused_status(dev) != 0                      # reads and clears the flag only (no reset of counters / epoch)
+    ops._persistent_dirty.clear()
+    for _ in range(4):
+        q = make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False)
+        with torch.no_grad():
+            y = q(x.to(dev), L.to(dev), 1)
+        assert eq32(y.cpu().numpy(), ref.numpy())
+    assert fused_status(dev) == 0
+    ops.check_persistent()
+
+
 def test_fused_step_special_values(eq32, dev):
     """NaN among the valid tokens poisons the statistics (torch.max / quantile propagate it) and therefore y; NaN and inf
     in PADDED tokens do not touch the statistics and quantise like everywhere else (inf -> NaN, util_quant.py:8)."""

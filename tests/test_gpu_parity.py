@@ -816,6 +816,48 @@ def test_msefast_resident_search_equals_launch_per_evaluation(dev):
                     np.testing.assert_allclose(a[:2], b[:2], rtol=2e-3 if sym else 3e-2, atol=1e-9, err_msg=f"{name} {cls.__name__} {sym}")
 
 
+def test_resident_search_time_out_is_loud_and_recoverable(dev):
+    """A resident MSEFast search whose workgroups do not meet (the test knob makes every collection of partial sums give up
+    at once) poisons its range with NaN, the commit PROPAGATES the NaN into min_val / max_val / scale (round 2's commit
+    dropped it: `bmin < mn ? bmin : mn`), and the host raises at the call's own synchronisation point; the next search on
+    the same workspace is correct."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(16, 64, 96, generator=gen) * 3).to(dev)
+    L = torch.randint(1, 65, (16,), generator=gen).to(dev)
+    ops.check_persistent()
+    good = MSEFastObserver(bit=6, symmetric=False).to(dev)
+    good(x, L, 1)
+    want = (good.min_val.item(), good.max_val.item())
+    ops.set_tuning("mse_spin_limit", 1)
+    try:
+        ob = MSEFastObserver(bit=6, symmetric=False).to(dev)
+        with pytest.raises(ops.PersistentLaunchTimeout):
+            ob(x, L, 1)
+        assert torch.isnan(ob.min_val).all() and torch.isnan(ob.max_val).all()
+        # several searches in one launch (an observer pass): the flush raises
+        from types import SimpleNamespace as NS
+        from outlier_suppression_amd.quantization import Quantizer
+        qs = [Quantizer(None, NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)).to(dev)
+              for _ in range(3)]
+        for q in qs:
+            q.enable_observer()
+        with pytest.raises(ops.PersistentLaunchTimeout):
+            with deferred_observation() as sites:
+                for q in qs:
+                    q(x, L, 1)
+                sites.flush()
+        assert all(torch.isnan(q.scale).all() for q in qs)
+    finally:
+        ops.set_tuning("mse_spin_limit", 0)
+    ops.check_persistent()
+    again = MSEFastObserver(bit=6, symmetric=False).to(dev)
+    again(x, L, 1)
+    assert (again.min_val.item(), again.max_val.item()) == want
+
+
 def test_msefast_searches_of_a_forward_share_a_launch(dev):
     """Inside deferred_observation() the per-tensor MSEFast searches of a forward are recorded and run together, up to 16
     per persistent launch (every round evaluates every unfinished search).  Each search does the arithmetic it does

@@ -252,3 +252,108 @@ def test_masked_learn_scale_two_ranks_equal_one(tmp_path, task, port):
         # Adam normalises every gradient by its own running magnitude: a parameter whose gradient is rounding noise moves by
         # a fraction of lr either way, so the bound is in steps (6 steps of lr = 1e-3), not relative to the value
         assert np.abs(rs[0]["zp"] - one["zp"]).max() <= 0.05 * 6 * 1e-3, (world, np.abs(rs[0]["zp"] - one["zp"]).max())
+
+
+# ---- site-sharded passes: the observers that cannot be recorded per batch (MSEFast and friends)
+
+def _run_sites(rank, world, port, out_dir):
+    """RoBERTa-like W4A6 flow of BASELINE configs[3] on the tiny golden BERT: per-channel MSEFast weight observers (one
+    search per row), per-tensor AvgMSEFast activation observers over four batches (float32 search on the first batch,
+    float64 from the second on, where the reference's dtype accident says so), sites dealt over the ranks."""
+    import torch.distributed as dist
+    os.environ["OSQ_FUSED_STEP"] = "0"        # several processes share the test GPU: no persistent grids (same path in the 1-rank run)
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformers import BertConfig, BertForSequenceClassification
+    from outlier_suppression_amd import calibration
+    from outlier_suppression_amd.quant_model import quantize_model
+    from outlier_suppression_amd.quantization import enable_calibration_woquantization
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bert_tiny_pipeline.npz"))
+    cfg = BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                     max_position_embeddings=40, num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                     type_vocab_size=2)
+    fp = BertForSequenceClassification(cfg).eval()
+    fp.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}, strict=False)
+    dev = torch.device("cuda:0")
+    fp = fp.to(dev)
+    batches = [{"input_ids": torch.from_numpy(g["input_ids"][b]).to(dev),
+                "attention_mask": torch.from_numpy(g["attention_mask"][b]).to(dev),
+                "token_type_ids": torch.zeros_like(torch.from_numpy(g["input_ids"][b])).to(dev)} for b in range(4)]
+    w_q = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
+    a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)
+    model = quantize_model(fp, w_q, a_q).to(dev)
+    fwd = lambda m, b: m(**b)
+    enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
+    info_w = calibration.calibrate_owned_sites(model, batches[:1], fwd, select=lambda n: "weight_fake_quant" in n)
+    enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
+    info_a = calibration.calibrate_owned_sites(model, batches, fwd)
+    if world > 1:
+        assert len(set(info_w["owner"])) == world and len(set(info_a["owner"])) == world     # every rank had work
+    out = {}
+    for i, (n, q) in enumerate((n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase)):
+        obs = q.observer
+        out[f"{i}:mn"], out[f"{i}:mx"] = obs.min_val.cpu().numpy(), obs.max_val.cpu().numpy()
+        out[f"{i}:s"], out[f"{i}:z"] = q.scale.detach().cpu().numpy(), q.zero_point.detach().cpu().numpy()
+        out[f"{i}:cnt"] = np.array(getattr(obs, "cnt", -1))
+        out[f"{i}:side"] = np.array(str(getattr(obs, "one_side_dist", None)))
+        if "_ref_f64" in obs.__dict__:
+            out[f"{i}:flags"] = obs._ref_f64.cpu().numpy()
+    # the model every rank ends with quantises identically: logits of the fully quantised model
+    from outlier_suppression_amd.quantization import enable_quantization
+    enable_quantization(model)
+    with torch.no_grad():
+        out["logits"] = model(**batches[1])[0].cpu().numpy()
+    np.savez(os.path.join(out_dir, f"sites_w{world}_r{rank}.npz"), **out)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_site_sharded_msefast_equals_one_process(tmp_path):
+    """calibration.calibrate_owned_sites with 2 and 4 ranks: every statistic (value, dtype, shape), scale, zero_point,
+    counter, sidedness and reference-dtype flag of every weight and activation quantizer, and the quantised model's
+    logits, equal the one-process pass bit for bit -- on every rank."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    mp.spawn(_run_sites, args=(1, 0, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_run_sites, args=(2, 29761, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_run_sites, args=(4, 29763, str(tmp_path)), nprocs=4, join=True)
+    one = np.load(tmp_path / "sites_w1_r0.npz")
+    assert len(one.files) > 100
+    for world, r in ((2, 0), (2, 1), (4, 0), (4, 2), (4, 3)):
+        got = np.load(tmp_path / f"sites_w{world}_r{r}.npz")
+        assert sorted(got.files) == sorted(one.files)
+        for k in one.files:
+            a, b = got[k], one[k]
+            assert a.dtype == b.dtype and a.shape == b.shape, (world, r, k, a.dtype, b.dtype, a.shape, b.shape)
+            assert np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), (world, r, k)
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the form the driver used for N = 1) re-launches itself
+    under torch.distributed.run and prints ONE JSON line.  On this one-GPU box the two ranks share the device through the
+    OSQ_BENCH_SHARE_GPU=1 test hook (gloo, three-launch path); with N visible devices the same command runs on RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    env = dict(os.environ, OSQ_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--settle", "0.1",
+                        "--no-calib", "--no-kernel-table", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert out["collective"]["ranks_seen"] == 2 and out["collective"]["world_size"] == 2
+    # without the hook and without a second device the command must refuse, loudly, instead of measuring something else
+    if torch.cuda.device_count() < 2:
+        env.pop("OSQ_BENCH_SHARE_GPU")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "visible HIP devices" in r.stderr

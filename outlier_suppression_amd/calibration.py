@@ -211,7 +211,7 @@ def calibrate_sharded(model, batches, forward, n_batches=None, group=None, selec
 
 _SIDE_CODE = {None: -1.0, "no": 0.0, "pos": 1.0, "neg": 2.0}
 _SIDE_NAME = {v: k for k, v in _SIDE_CODE.items()}
-_META = 8          # per site: cnt, one_side code, ref-float64 flags (2), statistics dtype (0 fp32 / 1 float64), nfev, 2 spare
+_META = 8          # per site: cnt, one_side code, ref-float64 flags (2), statistics dtype (0 fp32 / 1 float64), nfev, has-flags, 1 spare
 
 
 def _site_cost(name, q, numel, channels):
@@ -274,6 +274,7 @@ def _pack_site(q, channels, out):
     meta[1] = _SIDE_CODE[getattr(obs, "one_side_dist", None)]
     if flags is not None:
         meta[2:4] = flags.to(torch.float64)
+        meta[6] = 1.0
     meta[4] = 1.0 if obs.min_val.dtype == torch.float64 else 0.0
     if nfev is not None:
         meta[5] = nfev.to(torch.float64).sum()
@@ -307,7 +308,7 @@ def _unpack_site(q, channels, row, device):
         object.__setattr__(obs, "cnt", int(meta[0].item()))
     if hasattr(obs, "one_side_dist"):
         obs.one_side_dist = _SIDE_NAME[meta[1].item()]
-    if hasattr(obs, "_ref_flags"):
+    if hasattr(obs, "_ref_flags") and meta[6].item() == 1.0:
         obs._ref_flags(device).copy_(meta[2:4].to(torch.int32))
         object.__setattr__(obs, "_min_f64_known", bool(meta[2].item()))
 

@@ -283,13 +283,76 @@ __device__ __forceinline__ double sq_err4(const float4& a, float s, float z, flo
            (static_cast<double>(sq_err(a.z, s, z, qmin, qmax)) + static_cast<double>(sq_err(a.w, s, z, qmin, qmax)));
 }
 
+// ---------------------------------------------------------------- the reference machine's summation order (test mode)
+//
+// The reference's loss is torch's CPU `mean` of n fp32 squared errors: sum_out(...).div_(n), and the sum adds in the
+// order of ATen's cascade_sum / vectorized_inner_sum (aten/src/ATen/native/cpu/SumKernel.cpp; restated and pinned in
+// oracle/aten_sum.py): W = 8 SIMD lanes (the sum kernel is dispatched at AVX2 width also on AVX-512 machines), lane l
+// owning elements l, l + 8, ...; per lane four interleaved accumulators, each a 4-level cascade; then the n % 8
+// trailing scalars and the 8 lanes, in order, onto a scalar.  osq_set_tuning("mse_sum_order", 8) makes the per-row
+// kernel add in exactly that order (fp32 additions, lanes 0..7 of the wave playing the SIMD lanes, squared errors staged
+// in LDS): the searches are then the reference's own, iterate for iterate, and the ranges equal the reference-generated
+// fixtures BIT FOR BIT (tests/test_gpu_parity.py::test_msefast_rows_equal_reference_in_its_summation_order).  The default
+// stays the exact (float64) sum: it is the correctly rounded loss, and it does not depend on a vector width.
+__device__ __forceinline__ int ceil_log2_i(int x) { return x <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned int>(x - 1)); }
+
+// lane < W: that SIMD lane's partial sum over vectors 0 .. n_vec-1 of sq (vector i = sq[i*W .. i*W + W-1])
+__device__ __forceinline__ float aten_lane_partial(const float* sq, int n_vec, int W, int lane) {
+    constexpr int kLevels = 4, kIlp = 4;
+    const int size = n_vec / kIlp;
+    int level_power = ceil_log2_i(size) / kLevels;
+    level_power = level_power < 4 ? 4 : level_power;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[kLevels][kIlp];
+#pragma unroll
+    for (int j = 0; j < kLevels; ++j)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[j][k] = 0.0f;
+    int i = 0;
+    while (i + level_step <= size) {
+        for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+            for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
+#pragma unroll
+        for (int j = 1; j < kLevels; ++j) {
+#pragma unroll
+            for (int k = 0; k < kIlp; ++k) { acc[j][k] = acc[j][k] + acc[j - 1][k]; acc[j - 1][k] = 0.0f; }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < size; ++i)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
+#pragma unroll
+    for (int j = 1; j < kLevels; ++j)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + acc[j][k];
+    for (int v = size * kIlp; v < n_vec; ++v) acc[0][0] = acc[0][0] + sq[v * W + lane];
+#pragma unroll
+    for (int k = 1; k < kIlp; ++k) acc[0][0] = acc[0][0] + acc[0][k];
+    return acc[0][0];
+}
+
+// the whole wave calls; returns torch's fp32 mean of sq[0..n-1] (n >= W) in every lane
+__device__ __forceinline__ float aten_mean_wave(const float* sq, int n, int W) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int n_vec = n / W;
+    const float part = lane < W ? aten_lane_partial(sq, n_vec, W, lane) : 0.0f;
+    float fin = 0.0f;
+    for (int k = n_vec * W; k < n; ++k) fin = fin + sq[k];
+    for (int l = 0; l < W; ++l) fin = fin + __shfl(part, l, OSQ_WAVE);
+    return fin / static_cast<float>(n);
+}
+
 // ---------------------------------------------------------------- per-channel: one wave per row
 
-template <int MAXV>   // cached floats per lane (row length <= 64*MAXV); MAXV == 0: re-read the row
+template <int MAXV, bool ATEN = false>   // cached floats per lane (row length <= 64*MAXV); MAXV == 0: re-read the row
 __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __restrict__ w, int64_t rows, int cols,
                                                                 int quant_min, int quant_max, int symmetric, int side,
                                                                 int two_d, float* __restrict__ best_min,
-                                                                float* __restrict__ best_max, int* __restrict__ nfev_out) {
+                                                                float* __restrict__ best_max, int* __restrict__ nfev_out,
+                                                                int sum_width = 0) {
+    extern __shared__ float sq_stage[];          // ATEN: cols floats per wave
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     const int64_t row = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
     if (row >= rows) return;
@@ -318,6 +381,20 @@ __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __r
         // every squared error (an fp32 value) is added in float64 from the first addition on: the total is then the
         // exact sum to ~1e-16 whatever the order, and its fp32-rounded mean is THE correctly rounded loss -- the same
         // number oracle/observer_oracle.py::mse_loss computes, so the search is iterate-for-iterate the oracle's
+        if (ATEN && MAXV > 0) {
+            float* sq = sq_stage + (threadIdx.x / OSQ_WAVE) * cols;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int j = lane + k * OSQ_WAVE;
+                if (j < cols) sq[j] = sq_err(cache[k], s, z, qmin_f, qmax_f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            S.tell(static_cast<double>(aten_mean_wave(sq, cols, sum_width)));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
         double part = 0.0;
         if (MAXV > 0) {
 #pragma unroll
@@ -625,6 +702,7 @@ constexpr int kResWaves = kResThreads / OSQ_WAVE;
 constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
+static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8): 8 = per-row losses summed in ATen's CPU order (test mode)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
@@ -1137,8 +1215,19 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
     const int grid = static_cast<int>((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     const int c = static_cast<int>(cols);
     const TimingHook th = take_timing_hook(OSQ_TIME_MSEFAST_ROWS);
+    if (g_mse_sum_order) {       // test mode: the loss summed in the reference machine's order (see aten_mean_wave)
+        if (cols < g_mse_sum_order || cols > 64 * 48) return OSQ_ERR_UNSUPPORTED;
+        const size_t lds = static_cast<size_t>(kWavesPerBlock) * c * sizeof(float);
+#define OSQ_ROWS_ATEN(M) hipLaunchKernelGGL((msefast_rows_kernel<M, true>), dim3(grid), dim3(kThreads), lds, st, w, rows, c, \
+                                            quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev, g_mse_sum_order)
+        if (cols <= 64 * 4) OSQ_ROWS_ATEN(4);
+        else if (cols <= 64 * 16) OSQ_ROWS_ATEN(16);
+        else OSQ_ROWS_ATEN(48);
+#undef OSQ_ROWS_ATEN
+        return check_launch("msefast_rows(reference summation order)");
+    }
 #define OSQ_ROWS(M) hipExtLaunchKernelGGL(msefast_rows_kernel<M>, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, w, rows, c, \
-                                          quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev)
+                                          quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev, 0)
     if (cols <= 64 * 4) OSQ_ROWS(4);
     else if (cols <= 64 * 16) OSQ_ROWS(16);
     else if (cols <= 64 * 48) OSQ_ROWS(48);
@@ -1196,6 +1285,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
 static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
+    if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }

@@ -941,6 +941,35 @@ def test_msefast_rows_against_reference(golden, name, dev):
     assert abs(int(ob.last_nfev.sum().item()) - ref_nfev) <= 0.02 * ref_nfev
 
 
+@pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
+def test_msefast_rows_equal_reference_in_its_summation_order(golden, name, dev):
+    """osq_set_tuning("mse_sum_order", 8): the per-row kernel adds its squared errors in the order torch's CPU kernel adds
+    them (8 SIMD lanes, 4 interleaved cascades per lane; restated in oracle/aten_sum.py and pinned against torch.sum).
+    Every one of the fixture's 5120 reference-generated rows then comes out BIT-EQUAL -- min_val, max_val, hence every
+    scale and every x_quant entry -- and the evaluation count equals the reference's exactly: the whole distance
+    between the default (exact-sum) kernel and the reference is that summation order."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    from _msefast_rows import msefast_row_weights
+    g = golden("msefast_rows")
+    seed, rows, cols, bit, ref_nfev = (int(v) for v in g[name + "_info"])
+    w = torch.from_numpy(msefast_row_weights(seed, rows, cols)).to(dev)
+    ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
+    ops.set_tuning("mse_sum_order", 8)
+    try:
+        ob(w)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("mse_sum_order", 0)
+    assert np.array_equal(N(ob.max_val), g[name + "_max"]) and np.array_equal(N(ob.min_val), g[name + "_min"])
+    assert int(ob.last_nfev.sum().item()) == ref_nfev
+    s_a, z_a = ob.calculate_qparams(ob.min_val, ob.max_val)
+    s_b, z_b = ob.calculate_qparams(T(g[name + "_min"], dev), T(g[name + "_max"], dev))
+    _, xa = ops.fake_quant_per_channel(w, s_a, z_a, 0, ob.quant_min, ob.quant_max, return_quantized=True)
+    _, xb = ops.fake_quant_per_channel(w, s_b, z_b, 0, ob.quant_min, ob.quant_max, return_quantized=True)
+    assert torch.equal(xa, xb)
+
+
 def test_msefast_through_quantizer(dev):
     from outlier_suppression_amd.quantization import Quantizer
     from oracle import observer_oracle as OB

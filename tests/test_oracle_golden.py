@@ -159,6 +159,26 @@ def test_msefast_rows_vs_reference(golden, name):
     assert xq_mismatch <= b["xquant_mismatch"], xq_mismatch
 
 
+@pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
+def test_msefast_rows_equal_reference_in_its_summation_order(golden, name):
+    """The same rows with the loss summed the way the fixture machine's torch summed it (oracle/aten_sum.py, a numpy
+    restatement -- no torch in the loop): every range equals the reference's BIT FOR BIT.  The summation order is the
+    whole difference between the exact-sum searches above and the reference."""
+    from oracle.aten_sum import aten_mean_f32
+    g = golden("msefast_rows")
+    seed, rows, cols, bit, _ = (int(v) for v in g[name + "_info"])
+    n = 128
+    w = msefast_row_weights(seed, rows, cols)[:n]
+    st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
+    OB.MEAN_LIKE_TORCH = lambda sq: aten_mean_f32(sq, 8)
+    try:
+        OB.observe_msefast(st, w)
+    finally:
+        OB.MEAN_LIKE_TORCH = None
+    assert st.max_val.dtype == g[name + "_max"].dtype
+    assert np.array_equal(st.max_val, g[name + "_max"][:n]) and np.array_equal(st.min_val, g[name + "_min"][:n])
+
+
 def test_module_traces_via_oracle(golden, eq32):
     """FixedFakeQuantize / LSQ(+)FakeQuantize forward as a composition of oracle pieces (fake_quant.py:107-209)."""
     g = golden("modules")

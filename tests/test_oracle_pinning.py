@@ -96,3 +96,25 @@ def test_bounded_brent_ask_tell_and_maxiter():
         n += 1
         x = st.tell((x - 0.77) ** 2)
     assert n == 5 and st.done
+
+
+def test_aten_sum_order():
+    """oracle/aten_sum.py restates the ORDER in which torch's CPU kernel adds a contiguous fp32 vector (cascade_sum,
+    dispatched at AVX2 width: 8 lanes, also on AVX-512 machines) -- the one machine-dependent step of the reference's
+    MSEFast loss (observer.py:420-432).  Pinned against torch.sum / torch.mean themselves, bit for bit, over the row
+    lengths of the BASELINE weights and every awkward size around the vector / ILP / cascade boundaries."""
+    import torch
+    from oracle.aten_sum import aten_mean_f32, aten_sum_f32
+    if torch.backends.cpu.get_cpu_capability() not in ("AVX2", "AVX512"):
+        pytest.skip("torch's sum kernel runs at another vector width on this host")
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256, 257, 511, 512, 513, 768, 769,
+             1000, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 3100, 4095, 4096, 4097, 8191, 8192, 10000, 16384, 20000, 32767]
+    for n in sizes:
+        for rep in range(4):
+            x = (rng.standard_normal(n) ** 2 * rng.choice([1e-6, 1e-3, 1.0, 1e3])).astype(np.float32)
+            t = torch.from_numpy(x)
+            assert np.float32(t.sum().item()) == aten_sum_f32(x, 8), (n, rep)
+            assert np.float32(t.mean().item()) == aten_mean_f32(x, 8), (n, rep)
+    x = (rng.standard_normal((9, 3072)) ** 2).astype(np.float32)           # leading axes are independent rows
+    assert np.array_equal(aten_sum_f32(x, 8), np.array([torch.from_numpy(r).sum().item() for r in x], dtype=np.float32))

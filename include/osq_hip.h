@@ -89,7 +89,8 @@ size_t      osq_workspace_bytes(void);
  *   "obs_blocks" grid cap of osq_observe_flat (768: power-of-two grids put a thread's strided loads on the
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
- *   threshold pass; "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
+ *   threshold pass; "select_hint" 0 = the selectors of the one-launch observe + fake-quant step do not pre-histogram a window around the
+ *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
  *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
  *   "fused_spin_limit" / "mse_spin_limit" n: bound of the cross-workgroup waits of the two persistent launch families
  *   (0 = the default, ~2 s; n > 0 = n - 1 polls, so 1 makes every wait give up at once: tests force the time-out path). */
@@ -279,7 +280,7 @@ int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t
  * dense x[n] into y with those parameters.  No host sync.  A dense row-major [batch, tokens, features] view
  * with features a multiple of 256 (768, 1024, 3072, 4096), batch <= 1024 and 16-byte aligned buffers runs as ONE
  * persistent launch that keeps the tensor in registers between the reduction and the quantisation (x read from
- * HBM once, fused_step.h; token_min / token_max then hold the extrema in valid-token order); anything else, or
+ * HBM once, fused_step.h; token_min / token_max are scratch whose layout is then private to that launch); anything else, or
  * osq_set_tuning("fused_step", 0), is three launches.  osq_fused_step_status reads (and clears) the sticky
  * time-out flags of the one-launch form: 0 = every launch on this workspace completed normally. */
 int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,

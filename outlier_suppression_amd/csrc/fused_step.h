@@ -9,14 +9,15 @@
 // registers: x is read from HBM once, y is written once (8 B/elem of HBM traffic for 12 B/elem of algorithmic
 // work), and there are no kernel boundaries inside the call.
 //
-//   workgroups 0, 1   "selectors": wait until every streaming workgroup has published its per-token extrema, run
-//                     select_side (token_select.h) on one side each, meet, and the second one applies the clip rule,
-//                     the running statistic and calculate_qparams, writes the module's buffers and PUBLISHES
-//                     (scale, zero_point) as two tagged 8-byte granules;
+//   workgroups 0, 1   "selectors", one side each: every wave watches the arrival flags of sixteen streaming workgroups
+//                     and pulls a workgroup's per-token extrema into registers as soon as it has published them --
+//                     counting and histogramming them on the way (token_select.h, HINT) --, so that when the last
+//                     streaming workgroup arrives only its values and the scan are left; then select_from_registers;
+//                     each publishes its result as one tagged 8-byte granule;
 //   workgroups 2..    "streaming": wave w owns tokens j = w, w + W, w + 2W, ... of an enumeration that lists the valid
 //                     tokens first (sample-major) and the padded ones after them.  Phase A1 loads its valid tokens
-//                     and reduces them; the extrema go to the compact arrays (slot j) with write-through stores, the
-//                     workgroup takes an arrival ticket.  Phase A2 loads its padded tokens (they are quantised too:
+//                     and reduces them; the extrema go to the workgroup's chunk of the compact arrays with write-through
+//                     stores, then the workgroup raises its arrival flag.  Phase A2 loads its padded tokens (they are quantised too:
 //                     the reference fake-quantises the whole tensor) while the selectors work.  Phase C: poll the
 //                     granules, quantise the held registers, stream y out.  Tokens beyond the register capacity
 //                     (24 float4 per lane) are streamed instead: reduced in A1 without being kept, re-read in C.
@@ -37,16 +38,13 @@ constexpr int kFusedWaves = kFusedThreads / OSQ_WAVE;
 constexpr int kFusedHoldRegs = 18;        // float4 of activation data a lane keeps in registers across the wait (72 VGPRs)
 constexpr int kFusedHoldLds = 9;          // ... and in LDS (9 x 16 B x 1024 threads = 144 KiB of the CU's 160)
 constexpr int kFusedMaxBatch = 1024;      // prefix sums of the lengths live in LDS, one entry per thread
-constexpr int kFusedShards = 8;           // arrival counters, one per XCD (workgroup b runs on XCD b % 8)
 constexpr unsigned int kFusedSpinLimit = 1u << 21;
 
 struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch (or after a reset)
-    // Arrival counters, one 64-byte line each, in TWO sets: launch number e (the epoch word) counts in set e & 1 and
-    // zeroes set (e + 1) & 1 at its end.  Nobody of launch e touches the other set, and every workgroup of launch
-    // e - 1 has left by the kernel boundary -- also the ones that arrived after a time-out -- so a late arrival can
-    // never be added to a counter a later launch compares with `==` (round 2 zeroed the set in use, which a workgroup
-    // arriving after its selectors' time-out would then have left at 1 for every launch after it).
-    unsigned int arrive[2][kFusedShards][16];
+    // Arrival flags: streaming workgroup g stores this launch's tag into flag[(g % 16) * 16 + g / 16] once its extrema
+    // have left its CU (selector wave w polls the sixteen words of its own 64-byte line).  A tag is never reused, so
+    // nothing has to be reset between launches and a workgroup arriving after a time-out cannot disturb a later launch.
+    unsigned int flag[256];
     unsigned int epoch, pad0[15];             // launches completed on this workspace
     unsigned long long side[16];              // side[0], side[1]: one granule per selector (tag30 << 34 | empty << 33 | bad << 32 | value bits), adjacent: one 16-byte poll reads both
     unsigned int status, pad3[15];            // sticky: 1 = a selector timed out, 2 = a streaming workgroup timed out
@@ -69,8 +67,7 @@ struct FusedArgs {
     int zp_type, mode;
     float g, qmin, qmax;
     int gate;                     // 1: padded tokens are loaded only after every workgroup has arrived
-    int deal;                     // how a slot's tokens are dealt to the waves (see the kernel): 0 = 16 consecutive tokens per workgroup,
-                                  // 2 = round the workgroups token by token, 1 = only the slot with the last valid tokens
+    int hint;                     // 1: the selectors histogram a window around the running statistic while the values arrive (token_select.h, HINT)
     unsigned int spin_limit;      // bound of every cross-workgroup wait (kFusedSpinLimit; osq_set_tuning("fused_spin_limit") for tests)
 };
 
@@ -81,23 +78,220 @@ __device__ __forceinline__ unsigned int peek32(const unsigned int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = uniform(static_cast<unsigned int>(v)), hi = uniform(static_cast<unsigned int>(v >> 32));
+    return reinterpret_cast<T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 __device__ __forceinline__ unsigned long long side_granule(unsigned int tag, const SideResult& r) {
     return (static_cast<unsigned long long>(tag & 0x3fffffffu) << 34) | (r.empty ? (1ull << 33) : 0ull) | (r.bad ? (1ull << 32) : 0ull) |
            __float_as_uint(r.value);
 }
 
-// one selection per call site keeps the code size (and the build time) of the four kernel instantiations down
-template <int R4>
-__device__ __attribute__((noinline)) SideResult select_side_compact(const float* src, int side, int64_t cap, unsigned int n_valid,
-                                                                   int prune, float q, int shortcut, SelShared& S, long long* stamps,
-                                                                   unsigned int* loaded_flag, unsigned int loaded_tag) {
-    return select_side<R4, true>(src, side, 1, cap, nullptr, n_valid, prune, q, shortcut, S, stamps, loaded_flag, loaded_tag);
-}
+// A selector's side of the launch.  The compact arrays hold one CHUNK per streaming workgroup: workgroup g owns the
+// tokens j = local * G + g (G streaming workgroups, local = 16 * slot + wave) and writes token j's extremum to
+// chunk_start(g) + local; its valid tokens are the first nv(g) = ceil((V - g) / G) of them -- every chunk holds cmax or
+// cmax - 1 values.  Selector wave w takes the chunks of workgroups w, w + 16, ...: lane i < 16 polls workgroup
+// (w + 16 i)'s flag, and a published chunk is loaded with one dword per lane and absorbed at once (NaN flag, count below
+// the hinted window, histogram of the window): the LDS atomics of the first histogram level -- what a CU spends most of
+// a selection on -- happen while the streaming workgroups are still arriving.
+// One CU retires an instruction of a 16-wave workgroup in ~8 clocks, so the registers are packed: with CH = ceil(cmax/64),
+// chunk i's first 64 (CH - 1) values fill registers i (CH - 1) .. -- always full --, and the TAILS (cmax - 64 (CH - 1)
+// values or one less) of 64 / tpad chunks share one register (tpad = the tail length rounded up to a power of two):
+// 18 registers per lane instead of 32 at the bench lengths.  noinline: one copy of the selection per CH for the four
+// kernel instantiations; the function publishes the side's granule itself, so that what the call costs at its end
+// (callee-saved registers coming back from scratch) is behind the hand-off, not in front of it.
+template <int CH>
+__device__ __attribute__((noinline)) void fused_select(const float* src_, const int side_, const unsigned int total_, const unsigned int V_,
+                                                      const int prune_, const float q_, const int shortcut_, const float hint,
+                                                      FusedState* st_, const unsigned int tag_, const unsigned int spin_limit_,
+                                                      SelShared& S, long long* stamps) {
+    constexpr int NC = kFusedWaves;            // chunks per selector wave
+    constexpr int NM = NC * (CH - 1);          // registers of full 64-value blocks
+    constexpr int R = NM + NC;                 // ... plus at most sixteen tail registers
+    // arguments of a called function arrive in VGPRs: tell the compiler they are uniform, or every test below is a vector compare
+    const float* const src = uniform_ptr(src_);
+    FusedState* const st = uniform_ptr(st_);
+    const int side = static_cast<int>(uniform(static_cast<unsigned int>(side_))), prune = static_cast<int>(uniform(static_cast<unsigned int>(prune_)));
+    const int shortcut = static_cast<int>(uniform(static_cast<unsigned int>(shortcut_)));
+    const unsigned int total = uniform(total_), V = uniform(V_), tag = uniform(tag_), spin_limit = uniform(spin_limit_);
+    const float q = __uint_as_float(uniform(__float_as_uint(q_)));
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1);
+    const unsigned int wv = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(tid / OSQ_WAVE));
+    const unsigned int nwg = gridDim.x - 2u;
+    const unsigned int qt = total / nwg, rt = total - qt * nwg;      // chunk g starts at g * qt + min(g, rt) ...
+    const unsigned int qv = V / nwg, rv = V - qv * nwg;              // ... and holds qv + (g < rv) valid values
+    const unsigned int flip = side ? 0x80000000u : 0u;               // side 1 works on -token_min
+    const SelWindow win = hint_window(__uint_as_float(uniform(__float_as_uint(hint))), prune);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, static_cast<int>(total * 4u), 0x00020000);
+    OSQ_SSTAMP(0);
 
-// streaming workgroups whose arrival lands on shard s (blockIdx % 8 == s, blockIdx >= 2)
-__device__ __forceinline__ unsigned int fused_members(unsigned int nblocks, unsigned int s) {
-    const unsigned int all = nblocks > s ? (nblocks - 1u - s) / kFusedShards + 1u : 0u;
-    return all - (s < 2u && nblocks > s ? 1u : 0u);
+    // A wave's sixteen chunks form four GROUPS of four (chunks 4 j .. 4 j + 3): a group is loaded and absorbed once its
+    // four workgroups have arrived -- one uniform test per group and round: on a 16-wave workgroup every instruction of
+    // the polling loop costs ~8 clocks, per-chunk tests made a round longer than the arrivals are apart.
+    // Tails: tlen values (or tlen - 1) per chunk behind its full blocks; the tails of a group share ntg registers.
+    constexpr int NG = 4, GC = NC / NG;                              // groups, chunks per group
+    const unsigned int cmax = qv + (rv ? 1u : 0u);                   // V > 0: 64 (CH - 1) < cmax <= 64 CH
+    const unsigned int tlen = cmax - static_cast<unsigned int>(OSQ_WAVE * (CH - 1));
+    const unsigned int lt = tlen <= 1u ? 0u : 32u - static_cast<unsigned int>(__builtin_clz(tlen - 1u));   // tpad = 1 << lt >= tlen
+    const unsigned int cpr = lt <= 4u ? static_cast<unsigned int>(GC) : 1u << (6u - lt);                   // chunks per tail register: 4, 2, 1
+    const unsigned int ntg = static_cast<unsigned int>(GC) / cpr;                                          // tail registers per group: 1, 2, 4
+    // registers: [group j: 4 (CH - 1) full blocks][group j: 4 tail registers, ntg of them in use], j = 0..3
+    constexpr int RG = GC * (CH - 1) + GC;                           // per group
+    // this lane's place in a tail register: chunk ci of the register's cpr, tail position tl
+    const unsigned int ci = static_cast<unsigned int>(lane) >> lt, tl = static_cast<unsigned int>(lane) & ((1u << lt) - 1u);
+    const unsigned int lane4 = static_cast<unsigned int>(lane) * 4u;
+
+    for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
+    if (tid == 0) {
+        S.s_fill = 0u; S.s_next = 0xffffffffu; S.s_found[0] = S.s_found[1] = 0xffffffffu; S.s_sel = 0u; S.s_pos = 0u; S.s_late = 0u;
+    }
+    lds_barrier();
+    OSQ_SSTAMP(1);
+    const unsigned int limit = spin_limit;
+
+    float v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = __builtin_nanf("");
+    unsigned int want = 0u;                                           // chunks that exist and hold valid values
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const unsigned int g = wv + static_cast<unsigned int>(NC * i);
+        if (g < nwg && qv + (g < rv ? 1u : 0u) > 0u) want |= 1u << i;
+    }
+    unsigned int gdone = 0u, below = 0u;                              // groups that are in
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+        if (((want >> (GC * j)) & 0xfu) == 0u) gdone |= 1u << j;      // nothing to wait for
+    bool bad = false;
+    const unsigned int* const flags = &st->flag[wv * NC];
+    // One value: sign, NaN flag, and -- hinted -- below-the-window count and the window's histogram.  The range of the
+    // keys and the plain maximum are left to select_from_registers (only the paths without a usable window need them).
+#define OSQ_ABSORB(reg, okmask)                                                                        \
+    do {                                                                                               \
+        const float xs = __uint_as_float(__float_as_uint(reg) ^ flip);                                 \
+        const bool ok_ = (okmask);                                                                     \
+        bad |= ok_ && (xs != xs);                                                                      \
+        const float x = ok_ ? xs : __builtin_nanf("");                                                 \
+        reg = x;                                                                                       \
+        if (win.on) {              /* a poisoned slot's key 0x7fc00000 is neither below nor inside a finite window */ \
+            const unsigned int key = abs_key(x), d = key - win.lo;                                     \
+            below += key < win.lo ? 1u : 0u;                                                           \
+            if (d < win.wd) atomicAdd(&S.hist[d >> win.sh], 1u);                                       \
+        }                                                                                              \
+    } while (0)
+    // Software-pipelined: the poll of round n + 1 is issued right behind the data loads of round n.
+    unsigned int f = 0u;
+    if (limit && lane < NC) f = peek32(&flags[lane]);
+#ifdef OSQ_FINAL_TIMING
+    long long dbg_rounds = 0, dbg_empty = 0, dbg_first = 0;
+#endif
+    constexpr unsigned int kAllGroups = (1u << NG) - 1u;
+    for (unsigned int spins = 0; gdone != kAllGroups && spins < limit;) {
+        const unsigned int missing = want & ~static_cast<unsigned int>(__ballot(lane < NC && f == tag));   // chunks still awaited
+        unsigned int ready = 0u;
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (((missing >> (GC * j)) & 0xfu) == 0u) ready |= 1u << j;
+        const unsigned int newly = uniform(ready & ~gdone);
+#ifdef OSQ_FINAL_TIMING
+        if (newly) { if (!dbg_rounds) dbg_first = wall_clock64(); ++dbg_rounds; } else ++dbg_empty;
+#endif
+        if (!newly) {
+            ++spins;
+            __builtin_amdgcn_s_sleep(2);
+            if (lane < NC) f = peek32(&flags[lane]);
+            continue;
+        }
+        // every load of the round first, then the values
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            if ((newly >> j) & 1u) {
+#pragma unroll
+                for (int e = 0; e < GC; ++e) {
+                    const unsigned int g = wv + static_cast<unsigned int>(NC * (GC * j + e));
+                    const unsigned int off = g * qt + (g < rt ? g : rt);
+                    // chunk start in the SGPR offset, lane * 4 + c * 256 in the one VGPR / the immediate: no address registers
+                    // per load (a chunk that does not exist reads zeros beyond the buffer or a neighbour: masked below)
+#pragma unroll
+                    for (int c = 0; c < CH - 1; ++c)
+                        v[RG * j + e * (CH - 1) + c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + static_cast<unsigned int>(c * OSQ_WAVE * 4), off * 4u, 16 /* sc1 */));
+                }
+#pragma unroll
+                for (int t = 0; t < GC; ++t) {
+                    if (static_cast<unsigned int>(t) < ntg) {
+                        const unsigned int i = static_cast<unsigned int>(GC * j) + static_cast<unsigned int>(t) * cpr + ci, g = wv + NC * i;   // per lane
+                        const unsigned int off = g * qt + (g < rt ? g : rt) + static_cast<unsigned int>(OSQ_WAVE * (CH - 1)) + tl;
+                        v[RG * j + GC * (CH - 1) + t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off * 4u, 0, 16 /* sc1 */));
+                    }
+                }
+            }
+        }
+        gdone |= newly;
+        if (gdone != kAllGroups && lane < NC) f = peek32(&flags[lane]);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            if ((newly >> j) & 1u) {
+#pragma unroll
+                for (int e = 0; e < GC; ++e) {
+                    const bool exists = (want >> (GC * j + e)) & 1u;                 // uniform
+#pragma unroll
+                    for (int c = 0; c < CH - 1; ++c) OSQ_ABSORB(v[RG * j + e * (CH - 1) + c], exists);
+                }
+#pragma unroll
+                for (int t = 0; t < GC; ++t) {
+                    if (static_cast<unsigned int>(t) < ntg) {
+                        const unsigned int i = static_cast<unsigned int>(GC * j) + static_cast<unsigned int>(t) * cpr + ci, g = wv + NC * i;
+                        const unsigned int nvg = qv + (g < rv ? 1u : 0u);
+                        OSQ_ABSORB(v[RG * j + GC * (CH - 1) + t], ci < cpr && g < nwg && static_cast<unsigned int>(OSQ_WAVE * (CH - 1)) + tl < nvg);
+                    }
+                }
+            }
+        }
+    }
+#undef OSQ_ABSORB
+#ifdef OSQ_FINAL_TIMING
+    if (lane == 0 && g_osq_dbg) {
+        long long* w = g_osq_dbg + 2080 + side * 64 + wv * 4;
+        w[0] = wall_clock64(); w[1] = dbg_rounds; w[2] = dbg_empty; w[3] = dbg_first;
+    }
+#endif
+    if (gdone != kAllGroups && lane == 0) S.s_late = 1u;   // a streaming workgroup never arrived
+    // the NaN flag and the count below the window: per-wave partials -> LDS -> one barrier -> every thread folds them
+    {
+        const bool wbad = wave_any(bad);
+        below = wave_inclusive_scan_u32(below);
+        if (lane == OSQ_WAVE - 1) S.w_below[wv] = below;
+        if (lane == 0) S.w_bad[wv] = wbad ? 1u : 0u;
+    }
+    lds_barrier();
+    SelPass0 p0{V, false, 0u, 0u, 0u, false, win, 0u};
+    {
+        unsigned int nb = 0u, anyb = 0u;
+#pragma unroll
+        for (int k = 0; k < kSelWaves; k += 4) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(&S.w_below[k]), b4 = *reinterpret_cast<const uint4*>(&S.w_bad[k]);
+            nb += a4.x + a4.y + a4.z + a4.w;
+            anyb |= b4.x | b4.y | b4.z | b4.w;
+        }
+        p0.n_below = uniform(nb);
+        p0.any_bad = uniform(anyb) != 0u;
+    }
+    OSQ_SSTAMP(2);
+#ifdef OSQ_FINAL_TIMING
+    if (tid == 0 && stamps) stamps[6] = __builtin_readcyclecounter();
+#endif
+    // the extrema are in registers: the streaming workgroups may use the memory system for their padded tokens
+    if (tid == 0) __hip_atomic_store(&st->go[side][0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SideResult r{__builtin_nanf(""), true, false};
+    if (S.s_late) {                                        // poison the call instead of hanging
+        if (tid == 0) __hip_atomic_fetch_or(&st->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        r = select_from_registers<R, RG, GC * (CH - 1)>(v, p0, prune, q, shortcut, S, stamps, ntg);
+    }
+    if (tid == 0) __hip_atomic_store(&st->side[side], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ float4 as_float4(const v4u32& w) {
@@ -179,47 +373,23 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     if (blockIdx.x < 2u) {
         // =========================================================== selector (one side)
         const int side = blockIdx.x;
-        if (wv == 0) {                                     // lanes 0..7 watch one arrival counter each
-            const unsigned int s = lane < kFusedShards ? lane : 0;
-            const unsigned int want = fused_members(gridDim.x, s);
-            bool ok = false;
-            for (unsigned int spins = 0; spins < a.spin_limit; ++spins) {
-                ok = peek32(&st->arrive[(tag - 1u) & 1u][s][0]) == want;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (lane == 0) s_word[1] = __all(ok) ? 1u : 0u;
-        }
-        __syncthreads();
+        // the observer's running statistic predicts this batch's threshold (token_select.h, HINT)
+        float hint = __builtin_nanf("");
+        if (a.hint && fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val) hint = __builtin_fabsf(side ? fin.min_val[0] : fin.max_val[0]);
         OSQ_FSTAMP(1);
-        const bool arrived = s_word[1] != 0u;
-        SideResult r{__builtin_nanf(""), true, false};     // timed out: poison the call instead of hanging
 #ifdef OSQ_FINAL_TIMING
         long long* sstamps = g_osq_dbg ? g_osq_dbg + 8 * 256 + 16 * side : nullptr;
 #else
         long long* sstamps = nullptr;
 #endif
-        if (arrived) {
-            const float* src = side ? a.tok_min : a.tok_max;
-            const int64_t cap = (static_cast<int64_t>(total) + 3) & ~int64_t(3);
-            const unsigned int g4 = (V + 3u) >> 2;         // 16-byte groups that hold valid slots
-            unsigned int* const go = &st->go[side][0];
-#define OSQ_FUSED_SELECT(R4) r = select_side_compact<R4>(src, side, cap, V, a.prune, a.q, a.shortcut, sel_lds, sstamps, go, tag)
-            if (g4 <= 1u * kSelThreads) OSQ_FUSED_SELECT(1);
-            else if (g4 <= 2u * kSelThreads) OSQ_FUSED_SELECT(2);
-            else if (g4 <= 3u * kSelThreads) OSQ_FUSED_SELECT(3);
-            else if (g4 <= 4u * kSelThreads) OSQ_FUSED_SELECT(4);
-            else if (g4 <= 5u * kSelThreads) OSQ_FUSED_SELECT(5);
-            else if (g4 <= 6u * kSelThreads) OSQ_FUSED_SELECT(6);
-            else OSQ_FUSED_SELECT(8);
+        const float* src = side ? a.tok_min : a.tok_max;
+        const unsigned int nwg = gridDim.x - 2u;
+        const unsigned int cmax = V ? (V - 1u) / nwg + 1u : 0u;        // valid values of the largest chunk (<= 192: the launcher checks)
+#define OSQ_FUSED_SELECT(CH) fused_select<CH>(src, side, total, V, a.prune, a.q, a.shortcut, hint, st, tag, a.spin_limit, sel_lds, sstamps)
+        if (cmax <= 1u * OSQ_WAVE) OSQ_FUSED_SELECT(1);
+        else if (cmax <= 2u * OSQ_WAVE) OSQ_FUSED_SELECT(2);
+        else OSQ_FUSED_SELECT(3);
 #undef OSQ_FUSED_SELECT
-        } else if (tid == 0) {
-            __hip_atomic_fetch_or(&st->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st->go[side][0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        OSQ_FSTAMP(2);
-        if (tid == 0)
-            __hip_atomic_store(&st->side[side], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         OSQ_FSTAMP(3);
         return;
     }
@@ -235,28 +405,26 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         old_z = load_zp(a.zp_p, a.zp_type);
     }
     const unsigned int bp = blockIdx.x - 2u;                                         // this workgroup's number among the streaming ones
-    const unsigned int gw = bp * kFusedWaves + static_cast<unsigned int>(wv);
-    // How the W tokens of a slot are dealt to the waves (a.deal, osq_set_tuning("fused_deal")).
-    //   0: workgroup bp takes 16 consecutive tokens.  The same wave of neighbouring workgroups -- they issue their loads and
-    //      stores at about the same time -- is then 16 rows apart, a multiple of 16 KiB at every feature count the kernel
-    //      takes: simultaneous requests crowd a few memory channels.  And V is rarely a multiple of W: the slot that holds
-    //      the last valid tokens gives the first (V % W) / 16 workgroups one valid token per wave more than the others
-    //      (5 against 4 at the bench lengths), and the selection waits for those.
-    //   2 (default): wave w of workgroup bp takes token w * G + bp (G streaming workgroups): simultaneous requests are one
-    //      row apart, every workgroup has the same share of a slot's valid tokens.  Measured on one box, graph replay of
-    //      the bench step: 44.3 -> 41.5 us ([256,128,768], bench lengths), 55.0 -> 52.8 (all valid), 35.4 -> 33.0
-    //      ([32,128,3072]), 21.7 -> 20.0 ([64,128,1024]), 43.6 -> 41.1 ([32,128,4096]).  Two, four tokens per workgroup or
-    //      the workgroups of one XCD on consecutive tokens measure the same as one; numbering the workgroups in the order
-    //      they start (a ticket: XCDs receive a launch up to 2 us apart) costs the ticket's round trip: +1.5 us.
-    //   1: only the slot that holds the last valid tokens is dealt like 2 (the balance without the channel spreading: -0.3 us).
+    // How the W = 16 G tokens of a slot are dealt to the waves (G streaming workgroups): wave w of workgroup bp takes token
+    // w * G + bp -- the slot's tokens go round the workgroups one by one -- not 16 * bp + w (16 consecutive tokens per
+    // workgroup).  With the latter the same wave of neighbouring workgroups -- they issue their loads and stores at about
+    // the same time -- is 16 rows apart, a multiple of 16 KiB at every feature count the kernel takes, and simultaneous
+    // requests crowd a few memory channels; and V is rarely a multiple of W: the slot that holds the last valid tokens gave
+    // the first (V % W) / 16 workgroups one valid token per wave more than the others (5 against 4 at the bench lengths),
+    // and the selection waited for those.  Measured in round 2 (graph replay of the bench step, one box): 44.3 -> 41.5 us
+    // ([256,128,768], bench lengths), 55.0 -> 52.8 (all valid), 35.4 -> 33.0 ([32,128,3072]), 21.7 -> 20.0 ([64,128,1024]),
+    // 43.6 -> 41.1 ([32,128,4096]); two or four tokens per workgroup, or the workgroups of one XCD on consecutive tokens,
+    // measured the same as one; numbering the workgroups in the order they start (a ticket: XCDs receive a launch up to
+    // 2 us apart) cost the ticket's round trip, +1.5 us.  So workgroup bp's tokens are j = local * G + bp with
+    // local = 16 * slot + wave, and its extrema go to ITS chunk of the compact arrays at position `local`.
     const unsigned int nwg = gridDim.x - 2u;
     const unsigned int gwi = static_cast<unsigned int>(wv) * nwg + bp;
-    const unsigned int kdeal = a.deal >= 2 ? 0xffffffffu : (a.deal == 1 ? V / nwv : 0xfffffffeu);   // slot(s) dealt token by token
+    const unsigned int chunk0 = bp * (total / nwg) + (bp < total % nwg ? bp : total % nwg);       // start of this workgroup's chunk
     // 16 KiB rows (4096 features): workgroup bp starts a token at piece bp % 16, otherwise the workgroups' simultaneous
     // requests are again whole multiples of 16 KiB apart (-1 us of 41 on [32,128,4096]; no effect at 768 / 1024 / 3072)
     const unsigned int prot = NV == 16 ? bp % 16u : 0u;
 #define OSQ_FUSED_PIECE(u) ((((static_cast<unsigned int>(u) + prot) >= static_cast<unsigned int>(NV)) ? static_cast<unsigned int>(u) + prot - NV : static_cast<unsigned int>(u) + prot) * 1024u)
-#define OSQ_FUSED_TOKEN(k) (static_cast<unsigned int>(k) * nwv + ((kdeal == 0xffffffffu || kdeal == static_cast<unsigned int>(k)) ? gwi : gw))
+#define OSQ_FUSED_TOKEN(k) (static_cast<unsigned int>(k) * nwv + gwi)
     // Rows are addressed as buffer base (SGPR descriptor) + wave-uniform row offset (SGPR) + lane * 16 (one VGPR for
     // every access): no 64-bit address pair per token in flight -- the lanes' registers are for data.
     const unsigned int tensor_bytes = total * static_cast<unsigned int>(H4 * 16);      // < 4 GiB, checked by the launcher
@@ -274,7 +442,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
     // (All sixteen waves counting with ballots, 64 entries at a time, took 3 us: the CU's issue slots, not latency.)
     if (tid < kFusedWaves * S) {
         const unsigned int k = static_cast<unsigned int>(tid) / kFusedWaves, w = static_cast<unsigned int>(tid) % kFusedWaves;
-        const unsigned int j = k * nwv + ((kdeal == 0xffffffffu || kdeal == k) ? w * nwg + bp : bp * kFusedWaves + w);
+        const unsigned int j = k * nwv + w * nwg + bp;
         unsigned int r = 0u;
         if (j < total) {
             const bool valid = j < V;
@@ -326,15 +494,15 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
                 acc.wave_reduce();
                 acc.poison();
                 if (lane == 0) {
-                    publish_f32(&a.tok_min[j], acc.mn);
-                    publish_f32(&a.tok_max[j], acc.mx);
+                    publish_f32(&a.tok_min[chunk0 + k * kFusedWaves + wv], acc.mn);
+                    publish_f32(&a.tok_max[chunk0 + k * kFusedWaves + wv], acc.mx);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                // one token's temporaries at a time: the registers hold data
         }
     }
     // valid tokens beyond the capacity: reduced now, read again in phase C
-    for (unsigned int j = gw + static_cast<unsigned int>(S) * nwv; j < V; j += nwv) {
+    for (unsigned int j = gwi + static_cast<unsigned int>(S) * nwv, local = S * kFusedWaves + wv; j < V; j += nwv, local += kFusedWaves) {
         unsigned int b = 0u;
         for (unsigned int c = 0; c < Bu; c += OSQ_WAVE) {
             const unsigned int i = c + static_cast<unsigned int>(lane) + 1u;
@@ -354,15 +522,15 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         acc.wave_reduce();
         acc.poison();
         if (lane == 0) {
-            publish_f32(&a.tok_min[j], acc.mn);
-            publish_f32(&a.tok_max[j], acc.mx);
+            publish_f32(&a.tok_min[chunk0 + local], acc.mn);
+            publish_f32(&a.tok_max[chunk0 + local], acc.mx);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every publishing wave: its extrema have left this CU
     OSQ_FSTAMP(2);
     __syncthreads();
     if (tid == 0)
-        __hip_atomic_fetch_add(&st->arrive[(tag - 1u) & 1u][blockIdx.x % kFusedShards][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->flag[(bp % kFusedWaves) * kFusedWaves + bp / kFusedWaves], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     OSQ_FSTAMP(3);
 
     // ---- phase A2: this wave's padded tokens -> registers / LDS, while the selectors work.  Not before every workgroup
@@ -455,11 +623,8 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             }
             if (fin.zp_type != OSQ_ZP_FLOAT32) z = static_cast<float>(static_cast<int32_t>(z));   // what a reader of the int32 buffer sees
         }
-        if (blockIdx.x == 2u) {                            // ... and closes the launch's bookkeeping: the NEXT launch's counter set
-            for (int k = 0; k < kFusedShards; ++k)         // (untouched by this launch) is zeroed, the epoch moves on -- every workgroup
-                __hip_atomic_store(&st->arrive[tag & 1u][k][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read it at its start
+        if (blockIdx.x == 2u)                              // ... and closes the launch's bookkeeping: the epoch moves on (every workgroup read it at its start)
             __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         s_word[2] = __float_as_uint(s);
         s_word[3] = __float_as_uint(z);
         OSQ_FSTAMP(4);
@@ -485,7 +650,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
         }
     }
     // tokens beyond the capacity: stream
-    for (unsigned int j = gw + static_cast<unsigned int>(S) * nwv; j < total; j += nwv) {
+    for (unsigned int j = gwi + static_cast<unsigned int>(S) * nwv; j < total; j += nwv) {
         unsigned int b = 0u, r;
         if (j < V) {
             for (unsigned int c = 0; c < Bu; c += OSQ_WAVE) {

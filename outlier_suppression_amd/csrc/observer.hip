@@ -894,11 +894,8 @@ static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces 
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
 static int g_fused_step = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_fused_gate = 2;          // osq_set_tuning("fused_gate", 0|1|2): which padded loads wait for the selectors (fused_step.h, phase A2)
-#ifndef OSQ_FUSED_DEAL_DEFAULT
-#define OSQ_FUSED_DEAL_DEFAULT 2
-#endif
+static int g_select_hint = 1;          // osq_set_tuning("select_hint", 0|1): the fused step's selectors histogram a window around the running statistic while the extrema arrive (token_select.h, HINT)
 static unsigned int g_fused_spin_limit = 0;     // osq_set_tuning("fused_spin_limit", n): 0 = kFusedSpinLimit, n > 0 = n - 1 polls (1: every wait gives up at once -- tests force the time-out path with it)
-static int g_fused_deal = OSQ_FUSED_DEAL_DEFAULT;   // osq_set_tuning("fused_deal", 0|1|2): how a slot's tokens are dealt to the waves (fused_step.h)
 static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
@@ -1307,11 +1304,11 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
     if (k == "fused_step") { g_fused_step = value != 0; return true; }
     if (k == "fused_gate") { if (value < 0 || value > 2) return false; g_fused_gate = value; return true; }
-    if (k == "fused_deal") { if (value < 0 || value > 2) return false; g_fused_deal = value; return true; }
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
+    if (k == "select_hint") { g_select_hint = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
     return false;
 }
@@ -1607,6 +1604,9 @@ static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) 
     static int grid = -1;       // per process; devices of one node are identical
     if (grid < 0 || g_fused_grid) grid = fused_grid_for(reinterpret_cast<const void*>(&observe_fq_fused_kernel<NV>));
     if (grid < 3) return false;
+    // a selector wave holds 64 * 3 values of each of its sixteen chunks (fused_select<3>): with fewer workgroups than that
+    // allows (a small "fused_grid", a device with few CUs) the call runs as three launches
+    if ((a.B * a.T + grid - 3) / (grid - 2) > 3 * OSQ_WAVE || grid - 2 > kFusedWaves * kFusedWaves) return false;
     if (!persistent_serialize(st)) return false;
     const TimingHook th = take_timing_hook(OSQ_TIME_FUSED_STEP);
     hipExtLaunchKernelGGL(observe_fq_fused_kernel<NV>, dim3(grid), dim3(kFusedThreads), 0, st, th.start, th.stop, 0, a, fin);
@@ -1639,7 +1639,7 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
         const Finish fin{update_rule, cnt, min_val, max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
         const FusedArgs a{x, y, v.batch, v.tokens, lengths, token_min, token_max, prune, static_cast<float>(percentile),
                           g_select_shortcut, static_cast<FusedState*>(Workspace(workspace).fused()), scale, zero_point,
-                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_fused_deal,
+                          zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_select_hint,
                           g_fused_spin_limit ? g_fused_spin_limit - 1u : kFusedSpinLimit};
         hipStream_t st = static_cast<hipStream_t>(stream);
         bool launched = false;

@@ -48,23 +48,19 @@ struct SelectArgs {
 // instruction per value costs ~0.2 us: the passes below are written to a handful of instructions each
 // (validity as one compare against a per-group count, NaN poisoning as one select, range through
 // float min/max of |v| with source modifiers, the NaN flag as a scalar lane-mask OR).
-// R4 = 16-byte groups per thread; group g = tid + 1024*j covers slots 4g .. 4g+3.
 //
-// select_side: one side's statistic, computed by the calling 1024-thread workgroup (every thread gets the
-// result).  COMPACT = false: slots b*T + t, valid iff t < lengths[b] (plain loads: the arrays were written by an
-// earlier launch).  COMPACT = true: the first `compact_n` slots of the array are the valid ones (the fused
-// observe + fake-quant launch writes per-token extrema in valid-token order) and the loads are sc1 buffer loads,
-// because the producers are other workgroups of the SAME launch (cdna_hip_programming.md G16: write-through
-// stores on the producer side, sc1 loads on the consumer side).
+// Two stages: a GATHERING pass that brings a side's values into registers (select_side below: a token array in
+// memory; fused_step.h: chunk by chunk while the streaming workgroups of the same launch publish them) and
+// select_from_registers, the selection proper.
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
 struct alignas(16) SelShared {            // LDS of one selecting workgroup (the list and the partials are read 16 bytes at a time)
     unsigned int hist[kSelBins];
     unsigned int list[kListCap];
     // per-wave partials of pass 0: plain stores, nothing to initialise, no atomics; every thread folds the sixteen entries
-    unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves];
+    unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves], w_below[kSelWaves];
     SelState sel;
-    unsigned int s_fill, s_next, s_found[2], s_sel, s_pos;
+    unsigned int s_fill, s_next, s_found[2], s_sel, s_pos, s_late;
     unsigned int s_wtot[kSelWaves];
 };
 
@@ -74,34 +70,408 @@ struct SideResult {
     bool empty;       // no valid token at all
 };
 
-template <int R4, bool COMPACT>
+// Barrier for exchanges through LDS only: __syncthreads() is a workgroup-scope fence around s_barrier, and the fence
+// also waits for every global store / load the wave has in flight (vmcnt(0)) -- a polling load, a published flag, a
+// debug stamp: a memory round trip (~1 us while the chip streams) in front of every barrier of the selection.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct SelWindow {        // key range keys lo .. lo + wd - 1 in bins of 2^sh keys; on = false: no window
+    bool on;
+    unsigned int lo, wd, sh;
+};
+
+// HINT (round 3).  An averaging observer already holds a prediction of this batch's threshold: its running mean of
+// the previous batches' clip values (observer.py:194-202), which IS a mean of their order statistics.  A selector that
+// has to wait for its values anyway (fused_step.h: the streaming workgroups publish them while it idles) can build
+// the first histogram level over the window hint * [1/2, 3/2] WHILE the values arrive -- keys below the window
+// are counted, keys inside it histogrammed -- and only the scan is left once the last value is in.  Exactness does not
+// depend on the hint: the window serves as level 0 only if the wanted rank falls inside it; otherwise (first batch,
+// a distribution that moved, another percentile) the full-range level runs as before.
+__device__ __forceinline__ SelWindow hint_window(const float hint, const int prune) {
+    SelWindow w{false, 0u, 0u, 0u};
+    if (prune && hint > 1e-30f && hint < 1e30f) {          // false for NaN, inf, zero and denormal-sized hints
+        w.on = true;
+        w.lo = __float_as_uint(hint * 0.5f);
+        w.wd = __float_as_uint(hint * 1.5f) - w.lo + 1u;     // 1.5 octaves of keys: 1536 bins of 8192 keys
+        w.sh = level_shift(w.wd);
+    }
+    return w;
+}
+
+struct SelPass0 {         // what the gathering pass leaves (all uniform)
+    unsigned int N;           // valid values
+    bool have_range;          // false: kmin / kmax / plain_o are computed from the registers if a path needs them
+    unsigned int kmin, kmax;  // range of their keys
+    unsigned int plain_o;     // ordered bits of their plain maximum
+    bool any_bad;             // a NaN among them
+    SelWindow win;            // win.on: S.hist holds the window's histogram, n_below keys lie below it
+    unsigned int n_below;
+};
+
+// Per-wave partials of the gathering pass -> LDS -> (one barrier) -> every thread folds the sixteen entries.
+__device__ __forceinline__ SelPass0 fold_pass0(SelShared& S, unsigned int n, const bool bad, float amin, float amax, float plain,
+                                               unsigned int below, const SelWindow& win) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    amin = wave_min(amin);
+    amax = wave_max(amax);
+    plain = wave_max(plain);
+    const bool wbad = wave_any(bad);
+    n = wave_inclusive_scan_u32(n);
+    if (lane == OSQ_WAVE - 1) S.w_n[wv] = n;
+    if (win.on) {
+        below = wave_inclusive_scan_u32(below);
+        if (lane == OSQ_WAVE - 1) S.w_below[wv] = below;
+    }
+    if (lane == 0) {
+        S.w_bad[wv] = wbad ? 1u : 0u;
+        S.w_kmin[wv] = __float_as_uint(amin);          // non-negative floats order like their bit patterns
+        S.w_kmax[wv] = __float_as_uint(amax);
+        S.w_plain[wv] = ordered_bits(plain);
+    }
+    lds_barrier();                           // also: the LDS set-up of the caller is complete
+    SelPass0 p{0u, true, 0xffffffffu, 0u, 0u, false, win, 0u};
+    unsigned int any_bad_u = 0u;
+    if (win.on) {
+#pragma unroll
+        for (int k = 0; k < kSelWaves; k += 4) {
+            const uint4 f = *reinterpret_cast<const uint4*>(&S.w_below[k]);
+            p.n_below += f.x + f.y + f.z + f.w;
+        }
+        p.n_below = uniform(p.n_below);
+    }
+#pragma unroll
+    for (int k = 0; k < kSelWaves; k += 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(&S.w_n[k]), b = *reinterpret_cast<const uint4*>(&S.w_bad[k]);
+        const uint4 c = *reinterpret_cast<const uint4*>(&S.w_kmin[k]), d = *reinterpret_cast<const uint4*>(&S.w_kmax[k]);
+        const uint4 e = *reinterpret_cast<const uint4*>(&S.w_plain[k]);
+        p.N += a.x + a.y + a.z + a.w;
+        any_bad_u |= b.x | b.y | b.z | b.w;
+        p.kmin = min(min(p.kmin, min(c.x, c.y)), min(c.z, c.w));
+        p.kmax = max(max(p.kmax, max(d.x, d.y)), max(d.z, d.w));
+        p.plain_o = max(max(p.plain_o, max(e.x, e.y)), max(e.z, e.w));
+    }
+    p.N = uniform(p.N);
+    p.kmin = uniform(p.kmin);
+    p.kmax = uniform(p.kmax);
+    p.plain_o = uniform(p.plain_o);
+    p.any_bad = uniform(any_bad_u) != 0u;
+    return p;
+}
+
+// does register i of a thread hold anything? (compile-time i: a uniform test, or nothing at all)
+template <int PERIOD, int MAINS>
+__device__ __forceinline__ bool sel_used(const int i, const unsigned int n_tail) {
+    if (PERIOD == 0) return true;
+    const int r = i % (PERIOD ? PERIOD : 1);
+    return r < MAINS || static_cast<unsigned int>(r - MAINS) < n_tail;
+}
+
+// Range of the keys and plain maximum of the values in registers (a gathering pass that left them out: only the paths
+// without a usable hinted window need them).  One barrier; S.w_kmin / w_kmax / w_plain must not be in use.
+template <int R, int PERIOD, int MAINS>
+__device__ __forceinline__ void range_from_registers(const float (&v)[R], const unsigned int n_tail, SelShared& S,
+                                                     unsigned int* kmin, unsigned int* kmax, unsigned int* plain_o) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    float amin = __builtin_inff(), amax = 0.0f, plain = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (sel_used<PERIOD, MAINS>(i, n_tail)) {
+            amin = fminf(amin, __builtin_fabsf(v[i]));     // poisoned slots are NaN: fminf / fmaxf ignore them
+            amax = fmaxf(amax, __builtin_fabsf(v[i]));
+            plain = fmaxf(plain, v[i]);
+        }
+    }
+    amin = wave_min(amin);
+    amax = wave_max(amax);
+    plain = wave_max(plain);
+    if (lane == 0) {
+        S.w_kmin[wv] = __float_as_uint(amin);
+        S.w_kmax[wv] = __float_as_uint(amax);
+        S.w_plain[wv] = ordered_bits(plain);
+    }
+    lds_barrier();
+    unsigned int lo = 0xffffffffu, hi = 0u, pl = 0u;
+#pragma unroll
+    for (int k = 0; k < kSelWaves; k += 4) {
+        const uint4 c = *reinterpret_cast<const uint4*>(&S.w_kmin[k]), d = *reinterpret_cast<const uint4*>(&S.w_kmax[k]);
+        const uint4 e = *reinterpret_cast<const uint4*>(&S.w_plain[k]);
+        lo = min(min(lo, min(c.x, c.y)), min(c.z, c.w));
+        hi = max(max(hi, max(d.x, d.y)), max(d.z, d.w));
+        pl = max(max(pl, max(e.x, e.y)), max(e.z, e.w));
+    }
+    *kmin = uniform(lo);
+    *kmax = uniform(hi);
+    *plain_o = uniform(pl);
+}
+
+// The selection proper on R values per thread held in registers (invalid slots poisoned to NaN), after the gathering
+// pass.  S.hist is zero -- or holds the hinted window's histogram (p0.win.on) --, S.s_* are initialised.
+// PERIOD > 0: the registers come in groups of PERIOD, of which the first MAINS and the n_tail (uniform) after them hold
+// something (fused_step.h); PERIOD = 0: all R do.
+template <int R, int PERIOD = 0, int MAINS = 0>
+__device__ __forceinline__ SideResult select_from_registers(const float (&v)[R], const SelPass0& p0, const int prune, const float aq,
+                                                            const int use_shortcut, SelShared& S, long long* stamps,
+                                                            const unsigned int n_tail = 0u) {
+    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    const unsigned int N = p0.N;
+    if (N == 0u) return SideResult{0.0f, false, true};     // both sides agree: nothing observed
+    const bool any_bad = p0.any_bad;
+    unsigned int kmin = p0.kmin, kmax = p0.kmax, plain_o = p0.plain_o;
+    bool have_range = p0.have_range;                       // uniform
+    if (!have_range && !(prune && !any_bad)) {             // the plain maximum is the result
+        range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
+        have_range = true;
+    }
+    float result = have_range ? from_ordered_bits(plain_o) : 0.0f;
+
+    if (prune && !any_bad) {
+        const float rank = aq * static_cast<float>(N - 1u);
+        const float rlo = floorf(rank);
+        const unsigned int k_lo = static_cast<unsigned int>(rlo);
+        const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
+        const float w = rank - rlo;
+        // a window histogrammed during the gathering pass serves as level 0 if the wanted rank lies inside it
+        bool prehist = p0.win.on && p0.n_below <= k_lo;
+        if (!prehist && !have_range) {
+            range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
+            have_range = true;
+        }
+        if (tid == 0) {
+            if (prehist) {
+                S.sel.lo = p0.win.lo;
+                S.sel.width = p0.win.wd;
+                S.sel.rank = k_lo - p0.n_below;
+                S.sel.shift = p0.win.sh;
+                S.sel.le = p0.n_below;
+            } else {
+                S.sel.lo = kmin;
+                S.sel.width = kmax - kmin + 1u;
+                S.sel.rank = k_lo;
+                S.sel.shift = level_shift(S.sel.width);
+                S.sel.le = 0u;
+            }
+            S.sel.done = 0u;
+            S.sel.count = N;
+        }
+        if (p0.win.on && !prehist) {           // the window lies above the rank: its counts are of no use
+            for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
+        }
+        lds_barrier();
+        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
+        bool listed = false;
+        for (int level = 0; level < 3; ++level) {
+            if (S.sel.done) break;
+            if (level > 0) {
+                if (S.sel.count <= kListCap) { listed = true; break; }
+                for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
+                lds_barrier();
+            }
+            if (!(level == 0 && prehist)) {
+                const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width), sh = uniform(S.sel.shift);
+                // The range check also keeps poisoned slots (key 0x7fc00000) out.  Measured alternatives: all of them
+                // into ONE trash bin is 5x slower (same-address LDS atomics serialise); one trash bin per lane with a
+                // v_min instead of the compare + exec masking is no faster (6.6k vs 6.4k cycles at 32768 slots) --
+                // the pass is bound by the LDS atomic rate (~10 clocks per wave instruction), and masking does fewer.
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    if (sel_used<PERIOD, MAINS>(i, n_tail)) {
+                        const unsigned int d = abs_key(v[i]) - lo;
+                        if (d < wd) atomicAdd(&S.hist[d >> sh], 1u);
+                    }
+                }
+                lds_barrier();
+            }
+            // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank narrows
+            const unsigned int h0 = S.hist[2 * tid], h1 = S.hist[2 * tid + 1];
+            const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
+            if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
+            lds_barrier();
+            unsigned int base = 0u, inside = 0u;
+#pragma unroll
+            for (int k = 0; k < kSelWaves; ++k) { base += (k < wv) ? S.s_wtot[k] : 0u; inside += S.s_wtot[k]; }
+            const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
+            const unsigned int want = S.sel.rank;
+            lds_barrier();
+            if (level == 0 && prehist && want >= inside) {
+                // the rank lies above the window (uniform: every thread sees the same sum): the full-range level after all
+                prehist = false;
+                if (!have_range) {
+                    range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
+                    have_range = true;
+                }
+                for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
+                if (tid == 0) {
+                    S.sel.lo = kmin;
+                    S.sel.width = kmax - kmin + 1u;
+                    S.sel.rank = k_lo;
+                    S.sel.shift = level_shift(S.sel.width);
+                    S.sel.le = 0u;
+                }
+                lds_barrier();
+                --level;
+                continue;
+            }
+            if (want >= excl && want < incl) {     // exactly one thread
+                const bool second = want >= excl + h0;
+                const unsigned int below_b = second ? excl + h0 : excl;
+                const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
+                const unsigned int shv = S.sel.shift, off = bin << shv;
+                S.sel.lo += off;
+                S.sel.count = cnt;
+                if (shv == 0u) {                   // single-key bins: found
+                    S.sel.le += below_b + cnt;
+                    S.sel.width = 0u;
+                    S.sel.done = 1u;
+                } else {
+                    const unsigned int rest = S.sel.width - off, cap = 1u << shv;
+                    S.sel.le += below_b;
+                    S.sel.rank = want - below_b;
+                    S.sel.width = rest < cap ? rest : cap;
+                    S.sel.shift = level_shift(S.sel.width);
+                }
+            }
+            lds_barrier();
+        }
+        OSQ_SSTAMP(3);
+#ifdef OSQ_FINAL_TIMING
+        if (tid == 0 && stamps) { stamps[7] = __builtin_readcyclecounter(); stamps[11] = prehist; stamps[12] = p0.n_below; stamps[13] = k_lo; stamps[14] = S.sel.count; stamps[15] = p0.win.on; }
+#endif
+        unsigned int v_lo, v_hi;     // keys at floor(rank) / ceil(rank)
+        bool shortcut_done = false;  // uniform
+        if (!S.sel.done && listed) {
+            // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
+            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width);
+            const bool need_next = (k_hi != k_lo) && (uniform(S.sel.rank) + 1u >= uniform(S.sel.count));
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (sel_used<PERIOD, MAINS>(i, n_tail)) {
+                    const unsigned int key = abs_key(v[i]);
+                    if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
+                }
+            }
+            if (need_next) {
+                // smallest key at or above the bin's end: keys below it wrap to huge values under the
+                // unsigned subtraction and lose the min (poisoned slots are above every valid key)
+                const unsigned int edge = lo + wd;
+                unsigned int nx = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    if (sel_used<PERIOD, MAINS>(i, n_tail)) nx = min(nx, abs_key(v[i]) - edge);
+                }
+                nx = wave_min_u32(nx);
+                if (lane == 0 && nx < 0x80000000u) atomicMin(&S.s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
+            }
+            lds_barrier();
+            // ---- rank by counting.  Entry `mine` is the key at rank r iff (#keys < mine) <= r < (#keys <= mine): every
+            // holder of the keys at ranks want / want + 1 reports itself and whether it is non-negative -- one barrier
+            // for the two order statistics AND the sign facts of the shortcut below
+            const unsigned int cnt = S.s_fill, want = S.sel.rank;
+            if (static_cast<unsigned int>(tid) < cnt) {
+                const unsigned int ent = S.list[tid], mine = ent & 0x7fffffffu;
+                unsigned int lt = 0u, le = 0u;
+                for (unsigned int j = 0; j < cnt; j += 4u) {        // 16-byte LDS reads; entries at or beyond cnt are stale, never counted
+                    const uint4 o4 = *reinterpret_cast<const uint4*>(&S.list[j]);
+                    const unsigned int o[4] = {o4.x & 0x7fffffffu, o4.y & 0x7fffffffu, o4.z & 0x7fffffffu, o4.w & 0x7fffffffu};
+#pragma unroll
+                    for (unsigned int e = 0; e < 4u; ++e) {
+                        const bool in = j + e < cnt;
+                        lt += (in && o[e] < mine) ? 1u : 0u;
+                        le += (in && o[e] <= mine) ? 1u : 0u;
+                    }
+                }
+                if (lt <= want && want < le) {
+                    S.s_found[0] = mine;
+                    if (!(ent >> 31)) atomicOr(&S.s_pos, 1u);
+                }
+                if (lt <= want + 1u && want + 1u < le) {
+                    S.s_found[1] = mine;
+                    if (!(ent >> 31)) atomicOr(&S.s_pos, 2u);
+                }
+            }
+            lds_barrier();
+            v_lo = S.s_found[0];
+            const bool hi_listed = S.s_found[1] != 0xffffffffu;
+            v_hi = hi_listed ? S.s_found[1] : S.s_next;
+            // Shortcut for the threshold pass.  The keys at ranks floor/ceil are neighbours in sorted order, so
+            // no key lies strictly between them, thr lies in [lo_v, hi_v], and every value with a larger key
+            // is either negative or above thr.  If some element with key lo_v is non-negative, then
+            // max(v[v <= thr]) is lo_v -- or hi_v when thr reaches it and a non-negative element has that
+            // key.  Both facts are in the S.list (it holds every element of the bin, with sign) as long as the
+            // upper key is listed or not reached; otherwise the register pass below decides.
+            if (use_shortcut) {
+                const unsigned int pos = S.s_pos;
+                const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
+                const float d = hi_f - lo_f;
+                const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
+                const bool reaches_hi = hi_f > lo_f && t >= hi_f;
+                if ((pos & 1u) && (!reaches_hi || hi_listed)) {
+                    shortcut_done = true;
+                    result = (reaches_hi && (pos & 2u)) ? hi_f : lo_f;
+                }
+            }
+        } else {
+            // every level ran (massive duplicates): S.sel.lo is the key at rank k_lo, S.sel.le = #keys <= it
+            v_lo = uniform(S.sel.lo);
+            if (k_hi != k_lo && S.sel.le <= k_hi) {           // rank k_hi is the smallest key above
+                unsigned int nx = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const unsigned int key = abs_key(v[i]);
+                    if (sel_used<PERIOD, MAINS>(i, n_tail) && key > v_lo) nx = min(nx, key);
+                }
+                nx = wave_min_u32(nx);
+                if (lane == 0) atomicMin(&S.s_next, nx);
+                lds_barrier();
+                v_hi = S.s_next;
+            } else {
+                v_hi = v_lo;
+            }
+        }
+        if (k_hi == k_lo) v_hi = v_lo;
+        OSQ_SSTAMP(4);
+        const float lo_v = __uint_as_float(v_lo), hi_v = __uint_as_float(v_hi), diff = hi_v - lo_v;
+        float thr = (w < 0.5f) ? __builtin_fmaf(w, diff, lo_v) : __builtin_fmaf(w - 1.0f, diff, hi_v);   // torch lerp
+        thr = __uint_as_float(uniform(__float_as_uint(thr)));
+        if (!shortcut_done) {
+            // ---- max(v[v <= thr]) over the registers
+            float best = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (sel_used<PERIOD, MAINS>(i, n_tail)) best = (v[i] <= thr) ? fmaxf(best, v[i]) : best;
+            }
+            best = wave_max(best);
+            if (lane == 0) atomicMax(&S.s_sel, ordered_bits(best));
+            lds_barrier();
+            result = from_ordered_bits(S.s_sel);
+        }
+    }
+    OSQ_SSTAMP(5);
+    return SideResult{result, any_bad, false};
+}
+
+
+// select_side: one side's statistic of a token array in memory (slots b*T + t, valid iff t < lengths[b]; the arrays
+// were written by an earlier launch: plain loads), computed by the calling 1024-thread workgroup; every thread gets
+// the result.  R4 = 16-byte groups per thread; group g = tid + 1024*j covers slots 4g .. 4g+3.
+template <int R4>
 __device__ __forceinline__ SideResult select_side(const float* src, const int side, const int64_t aB, const int64_t aT,
-                                                  const int64_t* lengths, const unsigned int compact_n, const int prune,
-                                                  const float aq, const int use_shortcut, SelShared& S, long long* stamps,
-                                                  unsigned int* loaded_flag = nullptr, const unsigned int loaded_tag = 0u) {
+                                                  const int64_t* lengths, const int prune, const float aq,
+                                                  const int use_shortcut, SelShared& S, long long* stamps) {
     constexpr int R = 4 * R4;
 
-    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+    const int tid = threadIdx.x;
     const unsigned int Tu = static_cast<unsigned int>(aT);
     const unsigned int groups = static_cast<unsigned int>((aB * aT) >> 2);
     const unsigned int Bm1 = static_cast<unsigned int>(aB) - 1u;
-    const bool straddle = !COMPACT && (Tu & 3u) != 0u;     // T % 4 == 0: the four slots of a group share their sample
+    const bool straddle = (Tu & 3u) != 0u;                 // T % 4 == 0: the four slots of a group share their sample
     const unsigned int flip = side ? 0x80000000u : 0u;     // side 1 works on -token_min
 
     OSQ_SSTAMP(0);
     // ---- lengths first (L2 hits, needed before the data), then every data load, all unconditional.
     // Slot k of a group is valid iff k < rem_a (same sample as slot 0) or, behind the sample boundary
-    // k >= wrap (T % 4 != 0 only), iff k < rem_b.  COMPACT: slot s is valid iff s < compact_n.
+    // k >= wrap (T % 4 != 0 only), iff k < rem_b.
     int rem_a[R4], rem_b[R4], wrap[R4];
-    if (COMPACT) {
-#pragma unroll
-        for (int j = 0; j < R4; ++j) {
-            const unsigned int g = static_cast<unsigned int>(tid) + static_cast<unsigned int>(j) * kSelThreads;
-            rem_a[j] = g < groups ? static_cast<int>(compact_n) - static_cast<int>(4u * g) : 0;
-            rem_b[j] = 0;
-            wrap[j] = 4;
-        }
-    } else {
+    {
         const unsigned int step_b = (4u * kSelThreads) / Tu, step_t = 4u * kSelThreads - step_b * Tu;
         unsigned int bb = (4u * static_cast<unsigned int>(tid)) / Tu, tt = 4u * static_cast<unsigned int>(tid) - bb * Tu;
 #pragma unroll
@@ -124,16 +494,7 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
         }
     }
     float4 raw[R4];
-    if (COMPACT) {
-        // producers are workgroups of this launch (write-through stores): read around this CU's L1 with sc1 loads
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, static_cast<int>(groups * 16u), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < R4; ++j) {
-            const unsigned int g = static_cast<unsigned int>(tid) + static_cast<unsigned int>(j) * kSelThreads;
-            const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (g < groups ? g : groups - 1u) * 16u, 0, 16);
-            raw[j] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-        }
-    } else {
+    {
         const float4* src4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
         for (int j = 0; j < R4; ++j) {
@@ -194,218 +555,9 @@ __device__ __forceinline__ SideResult select_side(const float* src, const int si
             v[4 * j + k] = x;
         }
     }
-    {
-        // every wave leaves its partials in its own LDS words; after ONE barrier every thread folds the sixteen entries
-        amin = wave_min(amin);
-        amax = wave_max(amax);
-        plain = wave_max(plain);
-        const bool wbad = wave_any(bad);
-        n = wave_inclusive_scan_u32(n);
-        if (lane == OSQ_WAVE - 1) S.w_n[wv] = n;
-        if (lane == 0) {
-            S.w_bad[wv] = wbad ? 1u : 0u;
-            S.w_kmin[wv] = __float_as_uint(amin);          // non-negative floats order like their bit patterns
-            S.w_kmax[wv] = __float_as_uint(amax);
-            S.w_plain[wv] = ordered_bits(plain);
-        }
-    }
-    __syncthreads();                           // also: the LDS set-up above is complete
-    unsigned int N = 0u, any_bad_u = 0u, kmin = 0xffffffffu, kmax = 0u, plain_o = 0u;
-#pragma unroll
-    for (int k = 0; k < kSelWaves; k += 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(&S.w_n[k]), b = *reinterpret_cast<const uint4*>(&S.w_bad[k]);
-        const uint4 c = *reinterpret_cast<const uint4*>(&S.w_kmin[k]), d = *reinterpret_cast<const uint4*>(&S.w_kmax[k]);
-        const uint4 e = *reinterpret_cast<const uint4*>(&S.w_plain[k]);
-        N += a.x + a.y + a.z + a.w;
-        any_bad_u |= b.x | b.y | b.z | b.w;
-        kmin = min(min(kmin, min(c.x, c.y)), min(c.z, c.w));
-        kmax = max(max(kmax, max(d.x, d.y)), max(d.z, d.w));
-        plain_o = max(max(plain_o, max(e.x, e.y)), max(e.z, e.w));
-    }
-    N = uniform(N);
-    kmin = uniform(kmin);
-    kmax = uniform(kmax);
+    const SelPass0 p0 = fold_pass0(S, n, bad, amin, amax, plain, 0u, SelWindow{false, 0u, 0u, 0u});
     OSQ_SSTAMP(2);
-    // every thread's loads have returned: the fused launch lets its streaming workgroups use the memory system again
-    if (loaded_flag && tid == 0) __hip_atomic_store(loaded_flag, loaded_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (N == 0u) return SideResult{0.0f, false, true};     // both sides agree: nothing observed
-    const bool any_bad = uniform(any_bad_u) != 0u;
-    float result = from_ordered_bits(uniform(plain_o));
-
-    if (prune && !any_bad) {
-        const float rank = aq * static_cast<float>(N - 1u);
-        const float rlo = floorf(rank);
-        const unsigned int k_lo = static_cast<unsigned int>(rlo);
-        const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
-        const float w = rank - rlo;
-        if (tid == 0) {
-            S.sel.lo = kmin;
-            S.sel.width = kmax - kmin + 1u;
-            S.sel.rank = k_lo;
-            S.sel.shift = level_shift(S.sel.width);
-            S.sel.le = 0u;
-            S.sel.done = 0u;
-            S.sel.count = N;
-        }
-        __syncthreads();
-        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
-        bool listed = false;
-        for (int level = 0; level < 3; ++level) {
-            if (S.sel.done) break;
-            if (level > 0) {
-                if (S.sel.count <= kListCap) { listed = true; break; }
-                for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
-                __syncthreads();
-            }
-            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width), sh = uniform(S.sel.shift);
-            // The range check also keeps poisoned slots (key 0x7fc00000) out.  Measured alternatives: all of them
-            // into ONE trash bin is 5x slower (same-address LDS atomics serialise); one trash bin per lane with a
-            // v_min instead of the compare + exec masking is no faster (6.6k vs 6.4k cycles at 32768 slots) --
-            // the pass is bound by the LDS atomic rate (~10 clocks per wave instruction), and masking does fewer.
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const unsigned int d = abs_key(v[i]) - lo;
-                if (d < wd) atomicAdd(&S.hist[d >> sh], 1u);
-            }
-            __syncthreads();
-            // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank narrows
-            const unsigned int h0 = S.hist[2 * tid], h1 = S.hist[2 * tid + 1];
-            const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
-            if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
-            __syncthreads();
-            unsigned int base = 0u;
-#pragma unroll
-            for (int k = 0; k < kSelWaves; ++k) base += (k < wv) ? S.s_wtot[k] : 0u;
-            const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
-            const unsigned int want = S.sel.rank;
-            __syncthreads();
-            if (want >= excl && want < incl) {     // exactly one thread
-                const bool second = want >= excl + h0;
-                const unsigned int below = second ? excl + h0 : excl;
-                const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
-                const unsigned int shv = S.sel.shift, off = bin << shv;
-                S.sel.lo += off;
-                S.sel.count = cnt;
-                if (shv == 0u) {                   // single-key bins: found
-                    S.sel.le += below + cnt;
-                    S.sel.width = 0u;
-                    S.sel.done = 1u;
-                } else {
-                    const unsigned int rest = S.sel.width - off, cap = 1u << shv;
-                    S.sel.le += below;
-                    S.sel.rank = want - below;
-                    S.sel.width = rest < cap ? rest : cap;
-                    S.sel.shift = level_shift(S.sel.width);
-                }
-            }
-            __syncthreads();
-        }
-        OSQ_SSTAMP(3);
-        unsigned int v_lo, v_hi;     // keys at floor(rank) / ceil(rank)
-        bool shortcut_done = false;  // uniform
-        if (!S.sel.done && listed) {
-            // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
-            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width);
-            const bool need_next = (k_hi != k_lo) && (uniform(S.sel.rank) + 1u >= uniform(S.sel.count));
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const unsigned int key = abs_key(v[i]);
-                if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
-            }
-            if (need_next) {
-                // smallest key at or above the bin's end: keys below it wrap to huge values under the
-                // unsigned subtraction and lose the min (poisoned slots are above every valid key)
-                const unsigned int edge = lo + wd;
-                unsigned int nx = 0xffffffffu;
-#pragma unroll
-                for (int i = 0; i < R; ++i) nx = min(nx, abs_key(v[i]) - edge);
-                nx = wave_min_u32(nx);
-                if (lane == 0 && nx < 0x80000000u) atomicMin(&S.s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
-            }
-            __syncthreads();
-            // ---- rank by counting.  Entry `mine` is the key at rank r iff (#keys < mine) <= r < (#keys <= mine): every
-            // holder of the keys at ranks want / want + 1 reports itself and whether it is non-negative -- one barrier
-            // for the two order statistics AND the sign facts of the shortcut below
-            const unsigned int cnt = S.s_fill, want = S.sel.rank;
-            if (static_cast<unsigned int>(tid) < cnt) {
-                const unsigned int ent = S.list[tid], mine = ent & 0x7fffffffu;
-                unsigned int lt = 0u, le = 0u;
-                for (unsigned int j = 0; j < cnt; j += 4u) {        // 16-byte LDS reads; entries at or beyond cnt are stale, never counted
-                    const uint4 o4 = *reinterpret_cast<const uint4*>(&S.list[j]);
-                    const unsigned int o[4] = {o4.x & 0x7fffffffu, o4.y & 0x7fffffffu, o4.z & 0x7fffffffu, o4.w & 0x7fffffffu};
-#pragma unroll
-                    for (unsigned int e = 0; e < 4u; ++e) {
-                        const bool in = j + e < cnt;
-                        lt += (in && o[e] < mine) ? 1u : 0u;
-                        le += (in && o[e] <= mine) ? 1u : 0u;
-                    }
-                }
-                if (lt <= want && want < le) {
-                    S.s_found[0] = mine;
-                    if (!(ent >> 31)) atomicOr(&S.s_pos, 1u);
-                }
-                if (lt <= want + 1u && want + 1u < le) {
-                    S.s_found[1] = mine;
-                    if (!(ent >> 31)) atomicOr(&S.s_pos, 2u);
-                }
-            }
-            __syncthreads();
-            v_lo = S.s_found[0];
-            const bool hi_listed = S.s_found[1] != 0xffffffffu;
-            v_hi = hi_listed ? S.s_found[1] : S.s_next;
-            // Shortcut for the threshold pass.  The keys at ranks floor/ceil are neighbours in sorted order, so
-            // no key lies strictly between them, thr lies in [lo_v, hi_v], and every value with a larger key
-            // is either negative or above thr.  If some element with key lo_v is non-negative, then
-            // max(v[v <= thr]) is lo_v -- or hi_v when thr reaches it and a non-negative element has that
-            // key.  Both facts are in the S.list (it holds every element of the bin, with sign) as long as the
-            // upper key is listed or not reached; otherwise the register pass below decides.
-            if (use_shortcut) {
-                const unsigned int pos = S.s_pos;
-                const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
-                const float d = hi_f - lo_f;
-                const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
-                const bool reaches_hi = hi_f > lo_f && t >= hi_f;
-                if ((pos & 1u) && (!reaches_hi || hi_listed)) {
-                    shortcut_done = true;
-                    result = (reaches_hi && (pos & 2u)) ? hi_f : lo_f;
-                }
-            }
-        } else {
-            // every level ran (massive duplicates): S.sel.lo is the key at rank k_lo, S.sel.le = #keys <= it
-            v_lo = uniform(S.sel.lo);
-            if (k_hi != k_lo && S.sel.le <= k_hi) {           // rank k_hi is the smallest key above
-                unsigned int nx = 0xffffffffu;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const unsigned int key = abs_key(v[i]);
-                    if (key > v_lo) nx = min(nx, key);
-                }
-                nx = wave_min_u32(nx);
-                if (lane == 0) atomicMin(&S.s_next, nx);
-                __syncthreads();
-                v_hi = S.s_next;
-            } else {
-                v_hi = v_lo;
-            }
-        }
-        if (k_hi == k_lo) v_hi = v_lo;
-        OSQ_SSTAMP(4);
-        const float lo_v = __uint_as_float(v_lo), hi_v = __uint_as_float(v_hi), diff = hi_v - lo_v;
-        float thr = (w < 0.5f) ? __builtin_fmaf(w, diff, lo_v) : __builtin_fmaf(w - 1.0f, diff, hi_v);   // torch lerp
-        thr = __uint_as_float(uniform(__float_as_uint(thr)));
-        if (!shortcut_done) {
-            // ---- max(v[v <= thr]) over the registers
-            float best = -__builtin_inff();
-#pragma unroll
-            for (int i = 0; i < R; ++i) best = (v[i] <= thr) ? fmaxf(best, v[i]) : best;
-            best = wave_max(best);
-            if (lane == 0) atomicMax(&S.s_sel, ordered_bits(best));
-            __syncthreads();
-            result = from_ordered_bits(S.s_sel);
-        }
-    }
-    OSQ_SSTAMP(5);
-    return SideResult{result, any_bad, false};
+    return select_from_registers<R>(v, p0, prune, aq, use_shortcut, S, stamps);
 }
 
 // Rendezvous of the two sides (thread 0 of each side's workgroup): the first arriver leaves
@@ -453,7 +605,7 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #else
     long long* stamps = nullptr;
 #endif
-    const SideResult r = select_side<R4, false>(src, side, a.B, a.T, lengths, 0u, prune, a.q, a.shortcut, S, stamps);
+    const SideResult r = select_side<R4>(src, side, a.B, a.T, lengths, prune, a.q, a.shortcut, S, stamps);
     if (r.empty) return;                       // nothing observed, nothing updated
     if (threadIdx.x == 0) {
         float cur_min, cur_max;

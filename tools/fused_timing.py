@@ -1,6 +1,7 @@
 """Development aid: wall-clock stamps (100 MHz) of the fused observe + fake-quant launch.  `make -C outlier_suppression_amd/csrc dbg` first.
 Streaming workgroups: 0 start, 1 prefix sums + row map done, 2 valid tokens reduced + published (wave 0), 3 arrived,
-4 scale seen by the poller, 5 after the barrier, 6 end.  Selectors: 0 start, 1 all arrived, 2 side selected, 3 end."""
+4 scale seen by the poller, 5 after the barrier, 6 end.  Selectors: 0 start, 1 prefix sums done, 2 side selected, 3 end;
+within the selection: start, LDS ready, every chunk gathered, histogram levels + scan, list + rank, threshold."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +14,13 @@ shape = (256, 128, 768)
 g = torch.Generator().manual_seed(1234)
 full = "full" in sys.argv[1:]
 for a in sys.argv[1:]:
-    if a.startswith("deal="):
-        ops.set_tuning("fused_deal", int(a[5:]))
+    if a.startswith("hint="):
+        ops.set_tuning("select_hint", int(a[5:]))
+    if a.startswith("gate="):
+        ops.set_tuning("fused_gate", int(a[5:]))
 lengths = (torch.full((shape[0],), shape[1]) if full else torch.randint(8, 129, (shape[0],), generator=g)).to(dev)
 xs = [torch.randn(*shape, device=dev) for _ in range(4)]
-dbg = torch.zeros(260 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(260 * 8 + 128, dtype=torch.int64, device=dev)
 assert lib.osq_debug_buffer(dbg.data_ptr()) == 0
 q = mk()
 with torch.no_grad():
@@ -27,14 +30,20 @@ with torch.no_grad():
     dbg.zero_()
     q(xs[2], lengths, 1)
     torch.cuda.synchronize()
-d = dbg.view(260, 8).cpu()
+waves = dbg[2080:].view(2, 16, 4).cpu()
+d = dbg[:2080].view(260, 8).cpu()
 sel = d[256:].reshape(2, 16)
 d = d[:256]
 t0 = int(d[:, 0][d[:, 0] > 0].min())
 us = lambda v: (v.double() - t0) / 100.0
 print("selectors (us since first start): ", [[round(float(x), 2) for x in us(d[b, :4])] for b in range(2)])
 for side in range(2):
-    print(f"select side {side} (issue, loads+pass0, hist+scan, list+rank, threshold) us:", [round(float(x), 2) for x in us(sel[side, :11])], "cnt/total/M/sh/before", sel[side, 11:16].tolist())
+    print(f"select side {side} (start, LDS ready, gathered, hist+scan, list+rank, threshold) us:", [round(float(x), 2) for x in us(sel[side, :11])], "prehist/n_below/k_lo/bin count/window", sel[side, 11:16].tolist())
+for side in range(2):
+    dt = float(sel[side, 3] - sel[side, 2]) / 100.0
+    print(f"side {side}: gathered -> scanned: {dt:.2f} us, {int(sel[side, 7] - sel[side, 6])} shader-clock ticks -> {float(sel[side, 7] - sel[side, 6]) / max(dt, 1e-9) / 1000:.2f} GHz")
+    print(f"side {side} waves: gathered at", [round(float(x), 1) for x in us(waves[side, :, 0])], "first chunk at", [round(float(x), 1) for x in us(waves[side, :, 3])],
+          "rounds", waves[side, :, 1].tolist(), "empty polls", waves[side, :, 2].tolist())
 s = d[2:]
 for k, name in [(0, "start"), (7, "prefix sums"), (1, "mapped"), (2, "A1 done (wave 0)"), (3, "arrived"), (4, "scale seen"), (5, "after barrier"), (6, "end")]:
     v = us(s[:, k])

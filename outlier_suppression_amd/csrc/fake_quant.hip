@@ -20,6 +20,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
 static int g_fq_max_blocks = 8192;
+static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
 static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
 static int g_stream_wt = 1;      // osq_set_tuning("stream_wt", 0): nt stores instead of write-through ones in the LSQ backward and the GELU fake-quant (measured no gain, or a loss, in the LayerNorm site)
 static int g_bwd_blocks = 1792;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n)); tools/bwd_ab.py on MI355X, [256,128,768]:
@@ -183,6 +184,51 @@ __global__ __launch_bounds__(kThreads) void fq_tensor_strided_vec_kernel(
         float4 o, q;
         fq4<false>(load_stream(&x[xa]), o, q, p.scale, p.zp, qmin, qmax);
         store_stream(&y[ya], o);
+    }
+}
+
+// The head split itself -- x is [B, T, h, d] memory, y the dense [B, h, T, d] tensor the batched matmul wants
+// (model/quant_bert.py:128-150) -- walked in MEMORY order of x: every wave-load is 1 KiB of consecutive bytes (the
+// generic strided kernel above walks y and reads 256-byte runs 4 h d bytes apart), every wave-store is 64 / (d / 4) runs
+// of d floats, one per head, and the sixteen tokens a 256-thread workgroup covers in one trip land 16 d floats in a row
+// in each head's plane.  Two divisions by launch constants per float4 (h * d / 4, then T) instead of three.
+struct HeadSplit {
+    MagicDiv row;                 // h * dv float4 per token
+    MagicDiv tokens;              // T
+    unsigned int dv_shift;        // log2(d / 4): d / 4 is a power of two (64 -> 16)
+    unsigned int h, T;
+};
+
+template <int UNROLL, int NT>
+__global__ __launch_bounds__(kThreads) void fq_headsplit_kernel(
+    const float4* __restrict__ x, float4* __restrict__ y, HeadSplit d, unsigned int n4,
+    float* scale_p, void* zp_p, int zp_type, int mode, float g, float qmin, float qmax) {
+    const QParams p = tensor_params(scale_p, zp_p, zp_type, mode, g, qmin, qmax);
+    const unsigned int stride = gridDim.x * kThreads;               // n4 + UNROLL * stride < 2^32 (launcher)
+    const WtStore ywt(y, (NT & 4) ? n4 : 0);
+    auto out_index = [&](unsigned int e) {
+        const unsigned int bt = magic_div(e, d.row), c = e - bt * d.row.d;          // token b*T + t, float4 c of its h * dv
+        const unsigned int b = magic_div(bt, d.tokens), t = bt - b * d.tokens.d;
+        const unsigned int head = c >> d.dv_shift, dd = c & ((1u << d.dv_shift) - 1u);
+        return (((b * d.h + head) * d.T + t) << d.dv_shift) + dd;
+    };
+    unsigned int i = blockIdx.x * kThreads + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = (NT & 1) ? load_stream(&x[i + u * stride]) : x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float4 o, q;
+            fq4<false>(v[u], o, q, p.scale, p.zp, qmin, qmax);
+            const unsigned int yo = out_index(i + u * stride);
+            if (NT & 4) ywt.put(yo, o); else if (NT & 2) store_stream(&y[yo], o); else y[yo] = o;
+        }
+    }
+    for (; i < n4; i += stride) {
+        float4 o, q;
+        fq4<false>(x[i], o, q, p.scale, p.zp, qmin, qmax);
+        y[out_index(i)] = o;
     }
 }
 
@@ -590,6 +636,32 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
     for (int k = 0; k < 3 && vec; ++k)
         vec = x_strides[k] % 4 == 0 && y_strides[k] % 4 == 0 && x_strides[k] >= 0 && y_strides[k] >= 0 &&
               x_strides[k] / 4 < (1ll << 32) && y_strides[k] / 4 < (1ll << 32);
+    // the head split of attention: x = [B,T,h,d] memory seen as [B,h,T,d], y dense; d / 4 a power of two
+    const int64_t dvv = sizes[3] / 4;
+    if (vec && g_fq_headsplit && (dvv & (dvv - 1)) == 0 && dvv >= 1 && dvv <= 64 &&
+        x_strides[0] == sizes[2] * sizes[1] * sizes[3] && x_strides[1] == sizes[3] && x_strides[2] == sizes[1] * sizes[3] &&
+        y_strides[0] == sizes[1] * sizes[2] * sizes[3] && y_strides[1] == sizes[2] * sizes[3] && y_strides[2] == sizes[3] &&
+        sizes[1] * dvv < (1ll << 31) && n / 4 + 4ll * 8192 * kThreads < (1ll << 32)) {
+        HeadSplit hs;
+        hs.row = make_magic(sizes[1] * dvv);
+        hs.tokens = make_magic(sizes[2]);
+        hs.dv_shift = 0;
+        while ((1ll << hs.dv_shift) < dvv) ++hs.dv_shift;
+        hs.h = static_cast<unsigned int>(sizes[1]);
+        hs.T = static_cast<unsigned int>(sizes[2]);
+        const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_STRIDED);
+        const unsigned int n4 = static_cast<unsigned int>(n / 4);
+        const int hgrid = grid_for(n / 4, kThreads * 2, g_fq_max_blocks);
+#define OSQ_HEADSPLIT(NT)                                                                                                  \
+        hipExtLaunchKernelGGL((fq_headsplit_kernel<2, NT>), dim3(hgrid), dim3(kThreads), 0, st, th.start, th.stop, 0,          \
+                              reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), hs, n4, scale, zero_point,   \
+                              zp_type, mode, grad_factor, qmin, qmax)
+        if (g_fq_nt >= 4 && n / 4 <= kWtMaxFloat4) { if (g_fq_nt & 1) OSQ_HEADSPLIT(5); else OSQ_HEADSPLIT(4); }
+        else if ((g_fq_nt & 3) == 3) OSQ_HEADSPLIT(3);
+        else OSQ_HEADSPLIT(1);
+#undef OSQ_HEADSPLIT
+        return check_launch("fake_quant_per_tensor_strided(head split)");
+    }
     if (vec) {
         Strided4v dv;
         dv.size1 = make_magic(sizes[1]);
@@ -718,6 +790,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     OSQ_REQUIRE(key, "set_tuning: null key");
     const std::string k(key);
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
+    else if (k == "fq_headsplit") { osq::g_fq_headsplit = value != 0; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }
     else if (k == "stream_wt") { osq::g_stream_wt = value != 0; }

@@ -52,6 +52,9 @@ for B, T, h, d in ((32, 128, 12, 64), (32, 384, 12, 64), (4, 1024, 16, 64), (256
     ok = torch.equal(y1, ref.permute(0, 2, 1, 3)) and torch.equal(y2, ref.permute(0, 2, 3, 1)) and y1.is_contiguous()
     rows = [("dense", dense, _hip.TIME_FAKE_QUANT, None)]
     rows += [("q/v view", qv, _hip.TIME_FAKE_QUANT_STRIDED, None), ("key view", key, _hip.TIME_FAKE_QUANT_STRIDED, None)]
+    rows += [("q/v view, generic strided kernel", qv, _hip.TIME_FAKE_QUANT_STRIDED, 0), ("key view, generic strided kernel", key, _hip.TIME_FAKE_QUANT_STRIDED, 0)]
     for name, fn, which, knob in rows:
+        ops.set_tuning("fq_headsplit", 1 if knob is None else knob)
         med, mn = timed(fn, which)
+        ops.set_tuning("fq_headsplit", 1)
         print(f"[{B},{T},{h},{d}] {name:32s}: median {med:7.2f} us  min {mn:7.2f} us -> {nbytes / med / 1e3:7.0f} GB/s   bit-equal {ok}", flush=True)

@@ -280,9 +280,6 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
         p0.any_bad = uniform(anyb) != 0u;
     }
     OSQ_SSTAMP(2);
-#ifdef OSQ_FINAL_TIMING
-    if (tid == 0 && stamps) stamps[6] = __builtin_readcyclecounter();
-#endif
     // the extrema are in registers: the streaming workgroups may use the memory system for their padded tokens
     if (tid == 0) __hip_atomic_store(&st->go[side][0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SideResult r{__builtin_nanf(""), true, false};
@@ -292,6 +289,8 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
         r = select_from_registers<R, RG, GC * (CH - 1)>(v, p0, prune, q, shortcut, S, stamps, ntg);
     }
     if (tid == 0) __hip_atomic_store(&st->side[side], side_granule(tag, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    OSQ_SSTAMP(6);
+    OSQ_SDUMP();
 }
 
 __device__ __forceinline__ float4 as_float4(const v4u32& w) {

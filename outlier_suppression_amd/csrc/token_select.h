@@ -39,9 +39,12 @@ struct SelectArgs {
 };
 
 #ifdef OSQ_FINAL_TIMING
-#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0 && stamps) stamps[k] = wall_clock64(); } while (0)
+// stamps go to LDS (a global store in front of a barrier would be what gets measured) and leave at the end (OSQ_SDUMP)
+#define OSQ_SSTAMP(k) do { if (threadIdx.x == 0) S.t_stamp[k] = wall_clock64(); } while (0)
+#define OSQ_SDUMP() do { if (threadIdx.x == 0 && stamps) for (int k_ = 0; k_ < 16; ++k_) stamps[k_] = S.t_stamp[k_]; } while (0)
 #else
 #define OSQ_SSTAMP(k) do { } while (0)
+#define OSQ_SDUMP() do { } while (0)
 #endif
 
 // One CU handles all of a side's values (<= 32768) at 64 lane-operations per clock, so every VALU
@@ -59,9 +62,14 @@ struct alignas(16) SelShared {            // LDS of one selecting workgroup (the
     unsigned int list[kListCap];
     // per-wave partials of pass 0: plain stores, nothing to initialise, no atomics; every thread folds the sixteen entries
     unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves], w_below[kSelWaves];
-    SelState sel;
-    unsigned int s_fill, s_next, s_found[2], s_sel, s_pos, s_late;
-    unsigned int s_wtot[kSelWaves];
+    alignas(16) unsigned int pick[4];                 // what the owner of the wanted rank leaves: bin, keys below it, keys in it
+    alignas(16) unsigned int s_found[2];              // keys at ranks floor / ceil ...
+    unsigned int s_next, s_pos;                       // ... the smallest key above the bin, sign facts: read as ONE 16-byte word
+    unsigned int s_fill, s_sel, s_late, s_pad;
+    alignas(16) unsigned int s_wtot[kSelWaves];
+#ifdef OSQ_FINAL_TIMING
+    long long t_stamp[16];
+#endif
 };
 
 struct SideResult {
@@ -236,38 +244,32 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
             range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
             have_range = true;
         }
-        if (tid == 0) {
-            if (prehist) {
-                S.sel.lo = p0.win.lo;
-                S.sel.width = p0.win.wd;
-                S.sel.rank = k_lo - p0.n_below;
-                S.sel.shift = p0.win.sh;
-                S.sel.le = p0.n_below;
-            } else {
-                S.sel.lo = kmin;
-                S.sel.width = kmax - kmin + 1u;
-                S.sel.rank = k_lo;
-                S.sel.shift = level_shift(S.sel.width);
-                S.sel.le = 0u;
-            }
-            S.sel.done = 0u;
-            S.sel.count = N;
-        }
-        if (p0.win.on && !prehist) {           // the window lies above the rank: its counts are of no use
-            for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
-        }
-        lds_barrier();
-        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
-        bool listed = false;
-        for (int level = 0; level < 3; ++level) {
-            if (S.sel.done) break;
-            if (level > 0) {
-                if (S.sel.count <= kListCap) { listed = true; break; }
+        // The state of the search lives in REGISTERS of every thread (all uniform, all derived from uniform inputs): no
+        // set-up through LDS, no barrier for it.  A level costs two barriers -- the wave totals of the scan and the three
+        // words the thread that owns the wanted rank leaves (bin, keys below it, keys in it) -- plus one for its
+        // histogram when that was not built during the gathering pass.
+        unsigned int sel_lo, sel_width, sel_rank, sel_shift, sel_le, sel_count = N;
+        bool sel_done = false;
+        if (prehist) {
+            sel_lo = p0.win.lo; sel_width = p0.win.wd; sel_rank = k_lo - p0.n_below; sel_shift = p0.win.sh; sel_le = p0.n_below;
+        } else {
+            sel_lo = kmin; sel_width = kmax - kmin + 1u; sel_rank = k_lo; sel_shift = level_shift(sel_width); sel_le = 0u;
+            if (p0.win.on) {                       // the window lies above the rank: its counts are of no use
                 for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
                 lds_barrier();
             }
+        }
+        OSQ_SSTAMP(7);
+        // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
+        bool listed = false;
+        for (int level = 0; level < 3; ++level) {
+            if (sel_done) break;
+            if (level > 0) {
+                if (sel_count <= kListCap) { listed = true; break; }
+                for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;      // everybody read its bins before the last barrier
+                lds_barrier();
+            }
             if (!(level == 0 && prehist)) {
-                const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width), sh = uniform(S.sel.shift);
                 // The range check also keeps poisoned slots (key 0x7fc00000) out.  Measured alternatives: all of them
                 // into ONE trash bin is 5x slower (same-address LDS atomics serialise); one trash bin per lane with a
                 // v_min instead of the compare + exec masking is no faster (6.6k vs 6.4k cycles at 32768 slots) --
@@ -275,24 +277,28 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     if (sel_used<PERIOD, MAINS>(i, n_tail)) {
-                        const unsigned int d = abs_key(v[i]) - lo;
-                        if (d < wd) atomicAdd(&S.hist[d >> sh], 1u);
+                        const unsigned int d = abs_key(v[i]) - sel_lo;
+                        if (d < sel_width) atomicAdd(&S.hist[d >> sel_shift], 1u);
                     }
                 }
                 lds_barrier();
             }
-            // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank narrows
-            const unsigned int h0 = S.hist[2 * tid], h1 = S.hist[2 * tid + 1];
+            // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank reports
+            const uint2 hh = *reinterpret_cast<const uint2*>(&S.hist[2 * tid]);
+            const unsigned int h0 = hh.x, h1 = hh.y;
             const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
             if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
             lds_barrier();
             unsigned int base = 0u, inside = 0u;
 #pragma unroll
-            for (int k = 0; k < kSelWaves; ++k) { base += (k < wv) ? S.s_wtot[k] : 0u; inside += S.s_wtot[k]; }
-            const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
-            const unsigned int want = S.sel.rank;
-            lds_barrier();
-            if (level == 0 && prehist && want >= inside) {
+            for (int k = 0; k < kSelWaves; k += 4) {
+                const uint4 t4 = *reinterpret_cast<const uint4*>(&S.s_wtot[k]);
+                const unsigned int t[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { base += (k + e < wv) ? t[e] : 0u; inside += t[e]; }
+            }
+            if (level == 0) OSQ_SSTAMP(8);
+            if (level == 0 && prehist && sel_rank >= inside) {
                 // the rank lies above the window (uniform: every thread sees the same sum): the full-range level after all
                 prehist = false;
                 if (!have_range) {
@@ -300,48 +306,51 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                     have_range = true;
                 }
                 for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;
-                if (tid == 0) {
-                    S.sel.lo = kmin;
-                    S.sel.width = kmax - kmin + 1u;
-                    S.sel.rank = k_lo;
-                    S.sel.shift = level_shift(S.sel.width);
-                    S.sel.le = 0u;
-                }
+                sel_lo = kmin; sel_width = kmax - kmin + 1u; sel_rank = k_lo; sel_shift = level_shift(sel_width); sel_le = 0u;
                 lds_barrier();
                 --level;
                 continue;
             }
-            if (want >= excl && want < incl) {     // exactly one thread
-                const bool second = want >= excl + h0;
-                const unsigned int below_b = second ? excl + h0 : excl;
-                const unsigned int bin = 2u * tid + (second ? 1u : 0u), cnt = second ? h1 : h0;
-                const unsigned int shv = S.sel.shift, off = bin << shv;
-                S.sel.lo += off;
-                S.sel.count = cnt;
-                if (shv == 0u) {                   // single-key bins: found
-                    S.sel.le += below_b + cnt;
-                    S.sel.width = 0u;
-                    S.sel.done = 1u;
-                } else {
-                    const unsigned int rest = S.sel.width - off, cap = 1u << shv;
-                    S.sel.le += below_b;
-                    S.sel.rank = want - below_b;
-                    S.sel.width = rest < cap ? rest : cap;
-                    S.sel.shift = level_shift(S.sel.width);
-                }
+            const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
+            if (sel_rank >= excl && sel_rank < incl) {     // exactly one thread
+                const bool second = sel_rank >= excl + h0;
+                uint4 pk;
+                pk.x = 2u * static_cast<unsigned int>(tid) + (second ? 1u : 0u);      // the bin
+                pk.y = second ? excl + h0 : excl;                                      // keys of the range below it
+                pk.z = second ? h1 : h0;                                               // keys in it
+                pk.w = 0u;
+                *reinterpret_cast<uint4*>(&S.pick[0]) = pk;
             }
             lds_barrier();
+            {
+                const uint4 pk = *reinterpret_cast<const uint4*>(&S.pick[0]);
+                const unsigned int bin = uniform(pk.x), below_b = uniform(pk.y), cnt = uniform(pk.z);
+                const unsigned int off = bin << sel_shift;
+                sel_lo += off;
+                sel_count = cnt;
+                if (sel_shift == 0u) {             // single-key bins: found
+                    sel_le += below_b + cnt;
+                    sel_width = 0u;
+                    sel_done = true;
+                } else {
+                    const unsigned int rest = sel_width - off, cap = 1u << sel_shift;
+                    sel_le += below_b;
+                    sel_rank -= below_b;
+                    sel_width = rest < cap ? rest : cap;
+                    sel_shift = level_shift(sel_width);
+                }
+            }
         }
         OSQ_SSTAMP(3);
 #ifdef OSQ_FINAL_TIMING
-        if (tid == 0 && stamps) { stamps[7] = __builtin_readcyclecounter(); stamps[11] = prehist; stamps[12] = p0.n_below; stamps[13] = k_lo; stamps[14] = S.sel.count; stamps[15] = p0.win.on; }
+        if (tid == 0) { S.t_stamp[11] = prehist; S.t_stamp[12] = p0.n_below; S.t_stamp[13] = k_lo; S.t_stamp[14] = sel_count; S.t_stamp[15] = p0.win.on; }
 #endif
         unsigned int v_lo, v_hi;     // keys at floor(rank) / ceil(rank)
         bool shortcut_done = false;  // uniform
-        if (!S.sel.done && listed) {
+        if (!sel_done && listed) {
             // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
-            const unsigned int lo = uniform(S.sel.lo), wd = uniform(S.sel.width);
-            const bool need_next = (k_hi != k_lo) && (uniform(S.sel.rank) + 1u >= uniform(S.sel.count));
+            const unsigned int lo = sel_lo, wd = sel_width;
+            const bool need_next = (k_hi != k_lo) && (sel_rank + 1u >= sel_count);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if (sel_used<PERIOD, MAINS>(i, n_tail)) {
@@ -362,10 +371,11 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                 if (lane == 0 && nx < 0x80000000u) atomicMin(&S.s_next, nx + edge);   // >= 2^31: only wrapped keys in this wave
             }
             lds_barrier();
+            OSQ_SSTAMP(9);
             // ---- rank by counting.  Entry `mine` is the key at rank r iff (#keys < mine) <= r < (#keys <= mine): every
             // holder of the keys at ranks want / want + 1 reports itself and whether it is non-negative -- one barrier
             // for the two order statistics AND the sign facts of the shortcut below
-            const unsigned int cnt = S.s_fill, want = S.sel.rank;
+            const unsigned int cnt = S.s_fill, want = sel_rank;
             if (static_cast<unsigned int>(tid) < cnt) {
                 const unsigned int ent = S.list[tid], mine = ent & 0x7fffffffu;
                 unsigned int lt = 0u, le = 0u;
@@ -389,9 +399,10 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                 }
             }
             lds_barrier();
-            v_lo = S.s_found[0];
-            const bool hi_listed = S.s_found[1] != 0xffffffffu;
-            v_hi = hi_listed ? S.s_found[1] : S.s_next;
+            const uint4 fnd = *reinterpret_cast<const uint4*>(&S.s_found[0]);        // s_found[0], s_found[1], s_next, s_pos: one read
+            v_lo = fnd.x;
+            const bool hi_listed = fnd.y != 0xffffffffu;
+            v_hi = hi_listed ? fnd.y : fnd.z;
             // Shortcut for the threshold pass.  The keys at ranks floor/ceil are neighbours in sorted order, so
             // no key lies strictly between them, thr lies in [lo_v, hi_v], and every value with a larger key
             // is either negative or above thr.  If some element with key lo_v is non-negative, then
@@ -399,7 +410,7 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
             // key.  Both facts are in the S.list (it holds every element of the bin, with sign) as long as the
             // upper key is listed or not reached; otherwise the register pass below decides.
             if (use_shortcut) {
-                const unsigned int pos = S.s_pos;
+                const unsigned int pos = fnd.w;
                 const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(k_hi == k_lo ? v_lo : v_hi);
                 const float d = hi_f - lo_f;
                 const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
@@ -410,9 +421,9 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                 }
             }
         } else {
-            // every level ran (massive duplicates): S.sel.lo is the key at rank k_lo, S.sel.le = #keys <= it
-            v_lo = uniform(S.sel.lo);
-            if (k_hi != k_lo && S.sel.le <= k_hi) {           // rank k_hi is the smallest key above
+            // every level ran (massive duplicates): sel_lo is the key at rank k_lo, sel_le = #keys <= it
+            v_lo = sel_lo;
+            if (k_hi != k_lo && sel_le <= k_hi) {             // rank k_hi is the smallest key above
                 unsigned int nx = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -613,7 +624,8 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
             finish_entry(fin, 0, cur_min, cur_max, have_state, st_min, st_max);
     }
 #ifdef OSQ_FINAL_TIMING
-    if (threadIdx.x == 0 && stamps) stamps[6] = wall_clock64();
+    OSQ_SSTAMP(6);
+    OSQ_SDUMP();
 #endif
 }
 

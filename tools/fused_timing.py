@@ -38,10 +38,10 @@ t0 = int(d[:, 0][d[:, 0] > 0].min())
 us = lambda v: (v.double() - t0) / 100.0
 print("selectors (us since first start): ", [[round(float(x), 2) for x in us(d[b, :4])] for b in range(2)])
 for side in range(2):
-    print(f"select side {side} (start, LDS ready, gathered, hist+scan, list+rank, threshold) us:", [round(float(x), 2) for x in us(sel[side, :11])], "prehist/n_below/k_lo/bin count/window", sel[side, 11:16].tolist())
+    print(f"select side {side}: prehist/n_below/k_lo/bin count/window", sel[side, 11:16].tolist())
 for side in range(2):
-    dt = float(sel[side, 3] - sel[side, 2]) / 100.0
-    print(f"side {side}: gathered -> scanned: {dt:.2f} us, {int(sel[side, 7] - sel[side, 6])} shader-clock ticks -> {float(sel[side, 7] - sel[side, 6]) / max(dt, 1e-9) / 1000:.2f} GHz")
+    names = [(0, "start"), (1, "LDS ready"), (2, "gathered+folded"), (7, "level set up"), (8, "level-0 scan done"), (3, "levels done"), (9, "list compacted"), (4, "ranked"), (5, "threshold"), (6, "granule out")]
+    print(f"side {side} selection (LDS stamps):", ", ".join(f"{n} {float(us(sel[side, k])):.2f}" for k, n in names))
     print(f"side {side} waves: gathered at", [round(float(x), 1) for x in us(waves[side, :, 0])], "first chunk at", [round(float(x), 1) for x in us(waves[side, :, 3])],
           "rounds", waves[side, :, 1].tolist(), "empty polls", waves[side, :, 2].tolist())
 s = d[2:]

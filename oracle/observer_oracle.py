@@ -277,6 +277,16 @@ def observe_avg_prune_minmax(st, x, lengths=None, seq_pos=-1):
 MEAN_LIKE_TORCH = None
 
 
+def exact_mean(sq):
+    """Mean with an exactly rounded sum (math.fsum): the order-independent mean.  ``MEAN_LIKE_TORCH = exact_mean`` is the
+    counterpart of the kernels' double-double test mode (osq_set_tuning("mse_sum_order", 64)): with both, kernel and
+    oracle agree bit for bit also in float64 arithmetic (a per-tensor observer's second call on), where a plain sum
+    carries its order in its last bits (tests/test_gpu_parity.py::test_msefast_float64_equals_oracle_with_exact_sums)."""
+    import math
+    a = np.asarray(sq, dtype=np.float64).ravel()
+    return np.float64(math.fsum(a.tolist())) / np.float64(a.size)
+
+
 def mse_loss(x, new_min, new_max, quant_min, quant_max, symmetric):
     """observer.py:423-432 ``loss_fx`` + ``lp_loss`` (p=2).
 

@@ -442,6 +442,71 @@ __device__ __forceinline__ void tensor_search_advance(TensorSearch* ts, double t
                      &ts->scale_d);
 }
 
+// ---- test mode osq_set_tuning("mse_sum_order", 64): the loss summed as a double-double (error ~1e-32 relative), so that
+// its rounding to float64 does not depend on the order of the additions.  In float64 arithmetic (a per-tensor observer's
+// second call on, observer.py:524,549) a plain float64 sum carries its order in its last bits, and near the minimum of a
+// staircase loss that is enough to send Brent down another path: with this mode kernel and oracle (whose mean is then
+// math.fsum, exactly rounded) agree bit for bit on float64 batches too -- what is left against the reference is the
+// rounding noise of ITS sum.  One launch per evaluation only; production sums in plain float64.
+struct DD {
+    double hi, lo;
+};
+__device__ __forceinline__ void dd_add(DD& a, double x) {
+    const double s = a.hi + x, bb = s - a.hi;
+    const double e = (a.hi - (s - bb)) + (x - bb);             // two-sum: a.hi + x = s + e exactly
+    a.hi = s;
+    a.lo += e;
+}
+__device__ __forceinline__ DD dd_join(const DD& a, const DD& b) {
+    const double s = a.hi + b.hi, bb = s - a.hi;
+    const double e = (a.hi - (s - bb)) + (b.hi - bb);
+    const double lo = (a.lo + b.lo) + e;
+    const double hi = s + lo;
+    return DD{hi, lo - (hi - s)};
+}
+__device__ __forceinline__ DD dd_wave_sum(DD v) {
+#pragma unroll
+    for (int off = OSQ_WAVE / 2; off > 0; off >>= 1) {
+        const DD o{__shfl_xor(v.hi, off), __shfl_xor(v.lo, off)};
+        v = dd_join(v, o);
+    }
+    return v;
+}
+constexpr int kDdLoOffset = kMaxBlocks + 8;                  // low words of the published partials (behind the count of the token form)
+
+__device__ __forceinline__ void block_sum_publish_finish_exact(DD part, double* partials, unsigned int* counters,
+                                                               TensorSearch* ts, double count) {
+    __shared__ double sh_hi[kWavesPerBlock], sh_lo[kWavesPerBlock];
+    part = dd_wave_sum(part);
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    if (lane == 0) { sh_hi[wv] = part.hi; sh_lo[wv] = part.lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DD a{0.0, 0.0};
+        for (int k = 0; k < kWavesPerBlock; ++k) a = dd_join(a, DD{sh_hi[k], sh_lo[k]});
+        publish_f64(&partials[blockIdx.x], a.hi);
+        publish_f64(&partials[kDdLoOffset + blockIdx.x], a.lo);
+    }
+    if (grid_last_block(counters, gridDim.x)) {
+        constexpr int kPer = kMaxBlocks / kThreads;
+        DD a{0.0, 0.0};
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned int k = threadIdx.x + j * kThreads;
+            if (k < gridDim.x) a = dd_join(a, DD{consume_f64(&partials[k]), consume_f64(&partials[kDdLoOffset + k])});
+        }
+        a = dd_wave_sum(a);
+        __syncthreads();
+        if (lane == 0) { sh_hi[wv] = a.hi; sh_lo[wv] = a.lo; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            DD tot{0.0, 0.0};
+            for (int k = 0; k < kWavesPerBlock; ++k) tot = dd_join(tot, DD{sh_hi[k], sh_lo[k]});
+            tensor_search_advance(ts, tot.hi + tot.lo, count);
+            grid_reset(counters, gridDim.x);
+        }
+    }
+}
+
 __device__ __forceinline__ void block_sum_publish_finish(double part, double* partials, unsigned int* counters,
                                                          TensorSearch* ts, double count) {
     __shared__ double sh[kWavesPerBlock];
@@ -484,13 +549,26 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
                                                                      const float* __restrict__ xt, int tail, int64_t n,
                                                                      TensorSearch* __restrict__ ts,
                                                                      double* __restrict__ partials,
-                                                                     unsigned int* __restrict__ counters) {
+                                                                     unsigned int* __restrict__ counters, int exact) {
     if (ts->S.done) return;                       // uniform: state only changes between launches
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
     const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    if (exact) {                                  // test mode: every squared error joins a double-double on its own
+        DD dd{0.0, 0.0};
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
+            const float4 a = x[i];
+            const float e[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dd_add(dd, f64 ? sq_err_f64(e[k], sd, z, qmin, qmax) : static_cast<double>(sq_err(e[k], s, z, qmin, qmax)));
+        }
+        if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail)
+            dd_add(dd, f64 ? sq_err_f64(xt[threadIdx.x], sd, z, qmin, qmax) : static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax)));
+        block_sum_publish_finish_exact(dd, partials, counters, ts, static_cast<double>(n));
+        return;
+    }
     double acc = 0.0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += 2 * stride) {
         const float4 a = x[i];
@@ -515,7 +593,7 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
                                                                       TensorSearch* __restrict__ ts,
                                                                       double* __restrict__ partials,
                                                                       unsigned int* __restrict__ counters,
-                                                                      const double* __restrict__ valid_count) {
+                                                                      const double* __restrict__ valid_count, int exact) {
     if (ts->S.done) return;
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
@@ -526,6 +604,21 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
     const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     const int64_t F = v.feat_outer * v.feat_inner;
+    if (exact) {                                  // test mode: every squared error joins a double-double on its own
+        DD dd{0.0, 0.0};
+        for (int64_t tok = wave0; tok < ntok; tok += nwaves) {
+            const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
+            if (lengths && t >= lengths[b]) continue;
+            const float* base = x + b * v.stride_batch + t * v.stride_token;
+            for (int64_t j = lane; j < F; j += OSQ_WAVE) {
+                const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
+                const float xv = base[o * v.stride_outer + i * v.stride_inner];
+                dd_add(dd, f64 ? sq_err_f64(xv, sd, z, qmin, qmax) : static_cast<double>(sq_err(xv, s, z, qmin, qmax)));
+            }
+        }
+        block_sum_publish_finish_exact(dd, partials, counters, ts, valid_count[0]);
+        return;
+    }
     double acc = 0.0;
     for (int64_t tok = wave0; tok < ntok; tok += nwaves) {
         const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
@@ -702,7 +795,7 @@ constexpr int kResWaves = kResThreads / OSQ_WAVE;
 constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
-static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8): 8 = per-row losses summed in ATen's CPU order (test mode)
+static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
@@ -1215,7 +1308,7 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
     const int grid = static_cast<int>((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     const int c = static_cast<int>(cols);
     const TimingHook th = take_timing_hook(OSQ_TIME_MSEFAST_ROWS);
-    if (g_mse_sum_order) {       // test mode: the loss summed in the reference machine's order (see aten_mean_wave)
+    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {       // test mode: the loss summed in the reference machine's order (see aten_mean_wave)
         if (cols < g_mse_sum_order || cols > 64 * 48) return OSQ_ERR_UNSUPPORTED;
         const size_t lds = static_cast<size_t>(kWavesPerBlock) * c * sizeof(float);
 #define OSQ_ROWS_ATEN(M) hipLaunchKernelGGL((msefast_rows_kernel<M, true>), dim3(grid), dim3(kThreads), lds, st, w, rows, c, \
@@ -1256,7 +1349,7 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
-                           ws.doubles(kFamMseFlat), ws.counter(kFamMseFlat));
+                           ws.doubles(kFamMseFlat), ws.counter(kFamMseFlat), g_mse_sum_order == 64 ? 1 : 0);
     return check_launch("msefast_tensor_evals_flat");
 }
 
@@ -1276,7 +1369,8 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     const int grid = grid_for(v.batch * v.tokens, kWavesPerBlock, kMaxBlocks);
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_token_loss_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, vec,
-                           static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count);
+                           static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count,
+                           g_mse_sum_order == 64 ? 1 : 0);
     return check_launch("msefast_tensor_evals_tokens");
 }
 
@@ -1285,7 +1379,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
 static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
-    if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_sum_order = value; return true; }
+    if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }
@@ -1296,7 +1390,7 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
 extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
                                          const int64_t* lengths, void* workspace, osq_stream stream) {
     OSQ_REQUIRE(state && x && workspace, "msefast_tensor_search: null pointer");
-    if (!g_mse_resident) return OSQ_ERR_UNSUPPORTED;
+    if (!g_mse_resident || g_mse_sum_order == 64) return OSQ_ERR_UNSUPPORTED;     // the exact-sum test mode is one launch per evaluation
     ResidentArgs a{};
     a.x = x;
     a.ts = static_cast<TensorSearch*>(state);
@@ -1343,7 +1437,7 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
  * searches fits one osq_msefast_tensor_search_multi launch when there are at most osq_msefast_resident_limits' max_sites
  * of them and their slots add up to at most its max_slots. */
 extern "C" int osq_msefast_resident_slots(int64_t elems) {
-    if (!g_mse_resident || elems <= 0) return 0;
+    if (!g_mse_resident || g_mse_sum_order == 64 || elems <= 0) return 0;
     static int grid = -1;
     if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<kResMaxSlots>), kResThreads);
     if (grid < 1 || grid > kResidentMaxBlocks) return 0;
@@ -1367,7 +1461,7 @@ extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float*
                                                const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                                void* workspace, osq_stream stream) {
     OSQ_REQUIRE(states && xs && ns && views && lengths && workspace && n_sites > 0, "msefast_tensor_search_multi: bad argument");
-    if (!g_mse_resident || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
+    if (!g_mse_resident || g_mse_sum_order == 64 || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
     ResidentMultiArgs a{};
     a.n_sites = n_sites;
     a.spin_limit = g_res_spin_limit ? g_res_spin_limit - 1u : kResSpinLimit;

@@ -728,6 +728,47 @@ def test_msefast_equals_oracle(dev):
             np.testing.assert_allclose(N(ob.max_val), st.max_val, rtol=2e-3 if sym else 3e-2)
 
 
+def test_msefast_float64_equals_oracle_with_exact_sums(dev):
+    """The float64 branch of per-tensor MSEFast (from an observer's second call on the reference searches on a float64 copy
+    of x, observer.py:524,549) pinned at the bit level: with the loss summed order-independently on both sides -- the
+    kernels' double-double test mode, osq_set_tuning("mse_sum_order", 64), and math.fsum in the oracle -- ranges, running
+    means and evaluation counts of EVERY batch are equal, not just close: 1-D and nested 2-D searches, Avg and plain
+    observers, masked and flat inputs.  What test_msefast_equals_oracle tolerates (2e-3 / 3e-2) is therefore the rounding
+    noise of a plain float64 sum and nothing else in the port; the same noise separates the reference from both."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver, AvgMSEFastObserver
+    from oracle import observer_oracle as OB
+    gen = torch.Generator().manual_seed(18)
+    x = torch.randn(8, 32, 96, generator=gen)
+    x[..., 3] *= 12
+    L = torch.randint(4, 33, (8,), generator=gen)
+    ops.set_tuning("mse_sum_order", 64)
+    old_mean = OB.MEAN_LIKE_TORCH
+    OB.MEAN_LIKE_TORCH = OB.exact_mean
+    try:
+        for cls, avg in ((AvgMSEFastObserver, True), (MSEFastObserver, False)):
+            for sym in (True, False):
+                for masked in (True, False):
+                    ob = cls(bit=6, symmetric=sym).to(dev)
+                    st = OB.ObserverState(bit=6, symmetric=sym)
+                    for it in range(3):
+                        xi = x * (1.0 + 0.6 * it)
+                        counter = [0]
+                        if masked:
+                            ob(xi.to(dev), L.to(dev), 1)
+                            OB.observe_msefast(st, xi.numpy(), L.numpy(), 1, average=avg, counter=counter)
+                        else:
+                            ob(xi.to(dev))
+                            OB.observe_msefast(st, xi.numpy(), average=avg, counter=counter)
+                        what = (cls.__name__, sym, masked, it)
+                        assert float(N(ob.min_val)) == float(st.min_val) and float(N(ob.max_val)) == float(st.max_val), \
+                            (what, float(N(ob.min_val)), float(st.min_val), float(N(ob.max_val)), float(st.max_val))
+                        assert int(ob.last_nfev.sum().item()) == counter[0], what
+    finally:
+        OB.MEAN_LIKE_TORCH = old_mean
+        ops.set_tuning("mse_sum_order", 0)
+
+
 def test_mse_grid_equals_oracle(dev):
     """MSEObserver / AvgMSEObserver (brute-force grid, observer.py:285-409): the device search and the oracle evaluate the
     same candidates, sum the same fp32 squared errors in float64 and round the mean to fp32 once, so the argmin -- first

@@ -22,6 +22,11 @@ Every addition is an fp32 addition.  Valid for the serial path: fewer than 32768
 one-thread pool -- beyond that ``parallel_reduce`` splits the vector by the machine's thread count.  Rows of weight
 matrices (768 / 3072 columns: configs[3]'s per-channel searches) are always serial.
 
+float64 (a per-tensor observer's second call on runs on a float64 copy of x, observer.py:524,549): the same algorithm on
+vectors of FOUR doubles (``aten_sum(x, 4, np.float64)``); with a one-thread pool (torch.set_num_threads(1), how
+tests/golden/make_golden.py runs the reference) the serial order also holds at and beyond 32768 elements
+(``serial_only=False``).
+
 Pinned by tests/test_oracle_pinning.py::test_aten_sum_order against torch.sum itself on whatever machine runs the test,
 and by tests/test_oracle_golden.py against the reference-generated rows of tests/golden/msefast_rows.npz (generated on an
 AVX-512 machine: W = 16)."""
@@ -35,7 +40,7 @@ def _ceil_log2(x):
     return 0 if x <= 1 else int(x - 1).bit_length()
 
 
-def _multi_row_sum(rows, nrows):
+def _multi_row_sum(rows, nrows, dtype=F32):
     """multi_row_sum<acc_t, nrows>: ``rows`` is [size, nrows, ...] fp32; returns [nrows, ...]: each of the nrows columns
     summed over `size` with the 4-level cascade.  Trailing dimensions (SIMD lanes, batch) are element-wise."""
     size = rows.shape[0]
@@ -43,7 +48,7 @@ def _multi_row_sum(rows, nrows):
     level_power = max(4, _ceil_log2(size) // num_levels)
     level_step = 1 << level_power
     level_mask = level_step - 1
-    acc = np.zeros((num_levels,) + rows.shape[1:], dtype=F32)
+    acc = np.zeros((num_levels,) + rows.shape[1:], dtype=dtype)
     i = 0
     while i + level_step <= size:
         for _ in range(level_step):
@@ -63,24 +68,25 @@ def _multi_row_sum(rows, nrows):
     return acc[0]
 
 
-def aten_sum_f32(x, vec=16):
-    """torch.sum over the LAST axis of contiguous fp32 data of shape [..., n] with n < SERIAL_LIMIT, as ATen's CPU kernel
-    adds it on a machine whose SIMD vectors hold ``vec`` floats.  Leading axes are independent problems (batched here
-    only for speed: torch would be called once per row)."""
-    x = np.ascontiguousarray(x, dtype=F32)
+def aten_sum(x, vec, dtype, serial_only=True):
+    """torch.sum over the LAST axis of contiguous data of shape [..., n], as ATen's CPU kernel adds it in ``dtype``
+    (np.float32 / np.float64: every addition is one of that type) on a machine whose SIMD vectors hold ``vec`` elements,
+    on the serial path.  Leading axes are independent problems (batched here only for speed)."""
+    F32 = dtype                                     # noqa: N806 -- the body below is written in terms of "the" float type
+    x = np.ascontiguousarray(x, dtype=dtype)
     n = x.shape[-1]
     lead = x.shape[:-1]
-    if n >= SERIAL_LIMIT:
-        raise ValueError("aten_sum_f32 restates the serial path only (fewer than 32768 elements)")
+    if serial_only and n >= SERIAL_LIMIT:
+        raise ValueError("aten_sum restates the serial path only (fewer than 32768 elements, or a one-thread pool)")
     if n < vec:
         # size0 < Vec::size(): scalar_inner_sum -> the same cascade on scalars, 4-way ILP
-        return _scalar_inner_sum(x)
+        return _scalar_inner_sum(x, dtype)
     n_vec = n // vec
     v = np.moveaxis(x[..., :n_vec * vec].reshape(lead + (n_vec, vec)), -2, 0)           # [n_vec, ..., vec]
     ilp = 4
     size_ilp = n_vec // ilp
     grouped = np.moveaxis(v[:size_ilp * ilp].reshape((size_ilp, ilp) + v.shape[1:]), 1, 1)   # [size_ilp, ilp, ..., vec]
-    partial = _multi_row_sum(grouped, ilp)                                                   # [ilp, ..., vec]
+    partial = _multi_row_sum(grouped, ilp, dtype)                                            # [ilp, ..., vec]
     for i in range(size_ilp * ilp, n_vec):
         partial[0] = partial[0] + v[i]
     for k in range(1, ilp):
@@ -94,19 +100,30 @@ def aten_sum_f32(x, vec=16):
     return final
 
 
-def _scalar_inner_sum(x):
+def aten_sum_f32(x, vec=16):
+    """fp32 rows shorter than 32768 elements (the per-channel searches)."""
+    return aten_sum(x, vec, np.float32)
+
+
+def _scalar_inner_sum(x, dtype=F32):
     """scalar_inner_sum (row shorter than one SIMD vector): row_sum on scalars."""
     n = x.shape[-1]
     v = np.moveaxis(x, -1, 0)                                   # [n, ...]
     ilp = 4
     size_ilp = n // ilp
     grouped = v[:size_ilp * ilp].reshape((size_ilp, ilp) + v.shape[1:])
-    partial = _multi_row_sum(grouped, ilp)
+    partial = _multi_row_sum(grouped, ilp, dtype)
     for i in range(size_ilp * ilp, n):
         partial[0] = partial[0] + v[i]
     for k in range(1, ilp):
         partial[0] = partial[0] + partial[k]
-    return partial[0].astype(F32)
+    return partial[0].astype(dtype)
+
+
+def aten_mean(x, vec, dtype, serial_only=True):
+    """torch.mean of a flat tensor: sum_out(...).div_(n) in ``dtype``."""
+    x = np.asarray(x)
+    return (aten_sum(x, vec, dtype, serial_only) / dtype(x.shape[-1])).astype(dtype)
 
 
 def aten_mean_f32(x, vec=16):

@@ -297,17 +297,18 @@ __device__ __forceinline__ double sq_err4(const float4& a, float s, float z, flo
 __device__ __forceinline__ int ceil_log2_i(int x) { return x <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned int>(x - 1)); }
 
 // lane < W: that SIMD lane's partial sum over vectors 0 .. n_vec-1 of sq (vector i = sq[i*W .. i*W + W-1])
-__device__ __forceinline__ float aten_lane_partial(const float* sq, int n_vec, int W, int lane) {
+template <typename T>
+__device__ __forceinline__ T aten_lane_partial(const T* sq, int n_vec, int W, int lane) {
     constexpr int kLevels = 4, kIlp = 4;
     const int size = n_vec / kIlp;
     int level_power = ceil_log2_i(size) / kLevels;
     level_power = level_power < 4 ? 4 : level_power;
     const int level_step = 1 << level_power, level_mask = level_step - 1;
-    float acc[kLevels][kIlp];
+    T acc[kLevels][kIlp];
 #pragma unroll
     for (int j = 0; j < kLevels; ++j)
 #pragma unroll
-        for (int k = 0; k < kIlp; ++k) acc[j][k] = 0.0f;
+        for (int k = 0; k < kIlp; ++k) acc[j][k] = T(0);
     int i = 0;
     while (i + level_step <= size) {
         for (int j = 0; j < level_step; ++j, ++i)
@@ -316,7 +317,7 @@ __device__ __forceinline__ float aten_lane_partial(const float* sq, int n_vec, i
 #pragma unroll
         for (int j = 1; j < kLevels; ++j) {
 #pragma unroll
-            for (int k = 0; k < kIlp; ++k) { acc[j][k] = acc[j][k] + acc[j - 1][k]; acc[j - 1][k] = 0.0f; }
+            for (int k = 0; k < kIlp; ++k) { acc[j][k] = acc[j][k] + acc[j - 1][k]; acc[j - 1][k] = T(0); }
             if ((i & (level_mask << (j * level_power))) != 0) break;
         }
     }
@@ -333,15 +334,16 @@ __device__ __forceinline__ float aten_lane_partial(const float* sq, int n_vec, i
     return acc[0][0];
 }
 
-// the whole wave calls; returns torch's fp32 mean of sq[0..n-1] (n >= W) in every lane
-__device__ __forceinline__ float aten_mean_wave(const float* sq, int n, int W) {
+// the whole wave calls; returns torch's mean (in T) of sq[0..n-1] (n >= W) in every lane
+template <typename T>
+__device__ __forceinline__ T aten_mean_wave(const T* sq, int n, int W) {
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
     const int n_vec = n / W;
-    const float part = lane < W ? aten_lane_partial(sq, n_vec, W, lane) : 0.0f;
-    float fin = 0.0f;
+    const T part = lane < W ? aten_lane_partial<T>(sq, n_vec, W, lane) : T(0);
+    T fin = T(0);
     for (int k = n_vec * W; k < n; ++k) fin = fin + sq[k];
     for (int l = 0; l < W; ++l) fin = fin + __shfl(part, l, OSQ_WAVE);
-    return fin / static_cast<float>(n);
+    return fin / static_cast<T>(n);
 }
 
 // ---------------------------------------------------------------- per-channel: one wave per row
@@ -643,6 +645,72 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
         acc += p;
     }
     block_sum_publish_finish(acc, partials, counters, ts, valid_count[0]);
+}
+
+// Test mode osq_set_tuning("mse_sum_order", 8 | 16) for the PER-TENSOR searches: one workgroup writes the squared errors of
+// one evaluation, in the order remove_padding / flatten lays the elements out (observer.py:72-84), to a scratch array --
+// fp32, or float64 from an observer's second call on (observer.py:524,549) -- and its first wave adds them the way
+// ATen's CPU kernel does (W lanes for fp32, W / 2 for float64: 256-bit vectors), divides in that type and advances the
+// search.  With torch on one thread (as the fixtures were generated) that order holds for any length; the searches are
+// then the reference's own and the ranges of every call equal tests/golden/msefast.npz BIT FOR BIT
+// (tests/test_gpu_parity.py::test_msefast_tensor_equals_reference_in_its_summation_order).  n <= 65536.
+constexpr int kAtenThreads = 1024;
+constexpr int64_t kAtenMaxElems = 65536;
+__global__ __launch_bounds__(kAtenThreads) void msefast_tensor_aten_kernel(const float* __restrict__ x, int64_t n_flat, osq_token_view v,
+                                                                          const int64_t* __restrict__ lengths, int token_mode,
+                                                                          TensorSearch* __restrict__ ts, void* __restrict__ scratch, int W) {
+    if (ts->S.done) return;
+    __shared__ unsigned int pre[kAtenThreads + 1];
+    const float s = ts->scale, z = ts->zp;
+    const double sd = ts->scale_d;
+    const bool f64 = ts->S.f64 != 0;
+    const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
+    float* const sq32 = static_cast<float*>(scratch);
+    double* const sq64 = static_cast<double*>(scratch);
+    int64_t n = n_flat;
+    if (!token_mode) {
+        for (int64_t i = threadIdx.x; i < n; i += kAtenThreads) {
+            if (f64) sq64[i] = sq_err_f64(x[i], sd, z, qmin, qmax); else sq32[i] = sq_err(x[i], s, z, qmin, qmax);
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            unsigned int acc = 0u;
+            for (int64_t b = 0; b < v.batch; ++b) {
+                pre[b] = acc;
+                int64_t l = lengths ? lengths[b] : v.tokens;
+                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
+                acc += static_cast<unsigned int>(l);
+            }
+            pre[v.batch] = acc;
+        }
+        __syncthreads();
+        const int64_t F = v.feat_outer * v.feat_inner;
+        n = static_cast<int64_t>(pre[v.batch]) * F;
+        for (int64_t tok = 0; tok < v.batch * v.tokens; ++tok) {                // uniform loop, threads stride the features
+            const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
+            if (static_cast<unsigned int>(t) >= pre[b + 1] - pre[b]) continue;
+            const float* base = x + b * v.stride_batch + t * v.stride_token;
+            const int64_t out0 = (static_cast<int64_t>(pre[b]) + t) * F;
+            for (int64_t j = threadIdx.x; j < F; j += kAtenThreads) {
+                const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
+                const float xv = base[o * v.stride_outer + i * v.stride_inner];
+                if (f64) sq64[out0 + j] = sq_err_f64(xv, sd, z, qmin, qmax); else sq32[out0 + j] = sq_err(xv, s, z, qmin, qmax);
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < OSQ_WAVE) {
+        double mean;
+        if (f64) mean = aten_mean_wave<double>(sq64, static_cast<int>(n), W / 2);
+        else mean = static_cast<double>(aten_mean_wave<float>(sq32, static_cast<int>(n), W));
+        if (threadIdx.x == 0) {
+            ts->S.tell(mean);
+            if (!ts->S.done)
+                loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
+                             &ts->scale_d);
+        }
+    }
 }
 
 // number of observed elements = F * sum(min(len, T)) (observer.py:72-84), as a double for the mean
@@ -1346,6 +1414,13 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     Workspace ws(workspace);
     const int64_t n4 = n / 4;
     const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
+    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {        // test mode: the reference machine's summation order
+        OSQ_REQUIRE(n >= 16 && n <= kAtenMaxElems, "msefast_tensor_evals_flat: the summation-order test mode takes 16..65536 elements");
+        for (int e = 0; e < n_evals; ++e)
+            hipLaunchKernelGGL(msefast_tensor_aten_kernel, dim3(1), dim3(kAtenThreads), 0, st, x, n, osq_token_view{}, nullptr, 0,
+                               static_cast<TensorSearch*>(state), static_cast<void*>(ws.doubles(0)), g_mse_sum_order);
+        return check_launch("msefast_tensor_evals_flat(aten order)");
+    }
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
@@ -1361,6 +1436,14 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_evals_tokens: empty view");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
+    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {        // test mode: the reference machine's summation order
+        OSQ_REQUIRE(v.batch <= kAtenThreads && v.batch * v.tokens * v.feat_outer * v.feat_inner <= kAtenMaxElems && v.batch * v.tokens * v.feat_outer * v.feat_inner >= 16,
+                    "msefast_tensor_evals_tokens: the summation-order test mode takes 16..65536 elements, at most 1024 samples");
+        for (int e = 0; e < n_evals; ++e)
+            hipLaunchKernelGGL(msefast_tensor_aten_kernel, dim3(1), dim3(kAtenThreads), 0, st, x, int64_t(0), v, lengths, 1,
+                               static_cast<TensorSearch*>(state), static_cast<void*>(ws.doubles(0)), g_mse_sum_order);
+        return check_launch("msefast_tensor_evals_tokens(aten order)");
+    }
     double* count = ws.doubles(kFamMseTokens) + kMaxBlocks;        // behind the partials
     hipLaunchKernelGGL(msefast_valid_count_kernel, dim3(1), dim3(64), 0, st, lengths, v.batch, v.tokens,
                        v.feat_outer * v.feat_inner, count);
@@ -1390,7 +1473,7 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
 extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n, const osq_token_view* view,
                                          const int64_t* lengths, void* workspace, osq_stream stream) {
     OSQ_REQUIRE(state && x && workspace, "msefast_tensor_search: null pointer");
-    if (!g_mse_resident || g_mse_sum_order == 64) return OSQ_ERR_UNSUPPORTED;     // the exact-sum test mode is one launch per evaluation
+    if (!g_mse_resident || g_mse_sum_order != 0) return OSQ_ERR_UNSUPPORTED;     // the exact-sum test mode is one launch per evaluation
     ResidentArgs a{};
     a.x = x;
     a.ts = static_cast<TensorSearch*>(state);
@@ -1437,7 +1520,7 @@ extern "C" int osq_msefast_tensor_search(void* state, const float* x, int64_t n,
  * searches fits one osq_msefast_tensor_search_multi launch when there are at most osq_msefast_resident_limits' max_sites
  * of them and their slots add up to at most its max_slots. */
 extern "C" int osq_msefast_resident_slots(int64_t elems) {
-    if (!g_mse_resident || g_mse_sum_order == 64 || elems <= 0) return 0;
+    if (!g_mse_resident || g_mse_sum_order != 0 || elems <= 0) return 0;
     static int grid = -1;
     if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_resident_multi_kernel<kResMaxSlots>), kResThreads);
     if (grid < 1 || grid > kResidentMaxBlocks) return 0;
@@ -1461,7 +1544,7 @@ extern "C" int osq_msefast_tensor_search_multi(void* const* states, const float*
                                                const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                                void* workspace, osq_stream stream) {
     OSQ_REQUIRE(states && xs && ns && views && lengths && workspace && n_sites > 0, "msefast_tensor_search_multi: bad argument");
-    if (!g_mse_resident || g_mse_sum_order == 64 || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
+    if (!g_mse_resident || g_mse_sum_order != 0 || n_sites > kResidentMaxSites) return OSQ_ERR_UNSUPPORTED;
     ResidentMultiArgs a{};
     a.n_sites = n_sites;
     a.spin_limit = g_res_spin_limit ? g_res_spin_limit - 1u : kResSpinLimit;

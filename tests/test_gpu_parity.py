@@ -952,6 +952,35 @@ def test_msefast_searches_of_a_forward_share_a_launch(dev):
         assert all(torch.equal(u, v) for u, v in zip(a[:4], b[:4])) and a[4] == b[4], (k, a, b)
 
 
+def test_msefast_tensor_equals_reference_in_its_summation_order(golden, dev):
+    """osq_set_tuning("mse_sum_order", 8): the per-tensor searches add their squared errors in the order torch's CPU kernel
+    added them on the fixture machine -- fp32 in 8 lanes on the first call, float64 in 4 lanes from an observer's second
+    call on (observer.py:524,549) -- and every statistic after every call of tests/golden/msefast.npz (the reference's
+    own run: 1-D symmetric, one-sided, nested 2-D, per-channel rows, two three-batch Avg sequences) is reproduced BIT FOR
+    BIT, with the reference's number of loss evaluations."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import observer as OBS
+    g = golden("msefast")
+    ops.set_tuning("mse_sum_order", 8)
+    try:
+        for k in range(int(g["n"])):
+            cls, bit, sym, ch_axis, reps, nfev, osd = (str(v) for v in g[f"c{k}_info"])
+            bit, sym, ch_axis, reps, nfev = int(bit), bool(int(sym)), int(ch_axis), int(reps), int(nfev)
+            ob = getattr(OBS, cls)(bit=bit, symmetric=sym, ch_axis=ch_axis).to(dev)
+            x = g[f"c{k}_x"]
+            evals = 0
+            for r in range(reps):
+                ob(torch.from_numpy(x[r] if reps > 1 else x).to(dev))
+                evals += int(ob.last_nfev.sum().item())
+                got_min, got_max = N(ob.min_val).reshape(-1), N(ob.max_val).reshape(-1)
+                assert np.array_equal(got_min.astype(np.float64), g[f"c{k}_min"][r].reshape(-1).astype(np.float64)) and \
+                    np.array_equal(got_max.astype(np.float64), g[f"c{k}_max"][r].reshape(-1).astype(np.float64)), \
+                    (k, cls, r, got_min, g[f"c{k}_min"][r], got_max, g[f"c{k}_max"][r])
+            assert evals == nfev, (k, cls, evals, nfev)
+    finally:
+        ops.set_tuning("mse_sum_order", 0)
+
+
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_against_reference(golden, name, dev):
     """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;

@@ -137,6 +137,38 @@ def test_msefast(golden):
         assert abs(counter[0] - nfev) <= max(6, 0.35 * nfev), (counter[0], nfev)
 
 
+def aten_order_mean(sq):
+    """torch's CPU mean as the fixture machine computed it (one thread): fp32 in 8 SIMD lanes, float64 in 4."""
+    from oracle.aten_sum import aten_mean
+    sq = np.asarray(sq)
+    dt = np.float64 if sq.dtype == np.float64 else np.float32
+    return aten_mean(sq.reshape(-1), 4 if dt is np.float64 else 8, dt, serial_only=False)
+
+
+def test_msefast_equals_reference_in_its_summation_order(golden):
+    """The same fixtures with the loss summed the way the reference's torch summed it (oracle/aten_sum.py; no torch in the
+    loop): every statistic after every call -- per-tensor 1-D and nested 2-D searches, the one-sided cases, per-channel
+    rows, and the three-batch Avg sequences whose second and third call run in float64 (observer.py:524,549) -- equals
+    the reference's BIT FOR BIT, and so does the number of loss evaluations.  The summation order is the whole
+    difference between test_msefast above and the reference."""
+    g = golden("msefast")
+    OB.MEAN_LIKE_TORCH = aten_order_mean
+    try:
+        for k in range(int(g["n"])):
+            cls, bit, sym, ch_axis, reps, nfev, osd = (str(v) for v in g[f"c{k}_info"])
+            bit, sym, ch_axis, reps, nfev = int(bit), bool(int(sym)), int(ch_axis), int(reps), int(nfev)
+            st = OB.ObserverState(bit=bit, symmetric=sym, ch_axis=ch_axis)
+            x = g[f"c{k}_x"]
+            counter = [0]
+            for r in range(reps):
+                OB.observe_msefast(st, x[r] if reps > 1 else x, average=cls.startswith("Avg"), counter=counter)
+                assert np.array_equal(st.min_val, g[f"c{k}_min"][r]) and np.array_equal(st.max_val, g[f"c{k}_max"][r]), (k, r)
+                assert np.asarray(st.min_val).dtype == g[f"c{k}_min"].dtype
+            assert counter[0] == nfev, (k, counter[0], nfev)
+    finally:
+        OB.MEAN_LIKE_TORCH = None
+
+
 from _msefast_rows import MSEFAST_ROW_BOUNDS, msefast_row_weights, msefast_row_deviation  # noqa: E402
 
 

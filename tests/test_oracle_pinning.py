@@ -116,5 +116,20 @@ def test_aten_sum_order():
             t = torch.from_numpy(x)
             assert np.float32(t.sum().item()) == aten_sum_f32(x, 8), (n, rep)
             assert np.float32(t.mean().item()) == aten_mean_f32(x, 8), (n, rep)
+    # float64 (a per-tensor MSEFast observer's second call on, observer.py:524,549): 256-bit vectors hold FOUR doubles; and with
+    # a one-thread pool (how tests/golden/make_golden.py runs the reference) the serial order holds beyond 32768 elements
+    from oracle.aten_sum import aten_mean, aten_sum
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for n in [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 512, 1000, 2048, 4097, 12345, 32767, 32768, 50000, 100001]:
+            x = (rng.standard_normal(n) ** 2 * rng.choice([1e-6, 1.0, 1e3])).astype(np.float64)
+            t = torch.from_numpy(x)
+            assert np.float64(t.sum().item()) == aten_sum(x, 4, np.float64, serial_only=False), n
+            assert np.float64(t.mean().item()) == aten_mean(x, 4, np.float64, serial_only=False), n
+            xf = x.astype(np.float32)
+            assert np.float32(torch.from_numpy(xf).sum().item()) == aten_sum(xf, 8, np.float32, serial_only=False), n
+    finally:
+        torch.set_num_threads(threads)
     x = (rng.standard_normal((9, 3072)) ** 2).astype(np.float32)           # leading axes are independent rows
     assert np.array_equal(aten_sum_f32(x, 8), np.array([torch.from_numpy(r).sum().item() for r in x], dtype=np.float32))

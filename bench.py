@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 SHAPE = (256, 128, 768)          # BASELINE.json: BERT-base 256 x 128 x 768 activations
 PERCENTILE = 0.95
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+COPY_RATE_GBS = 6290.0   # float4 copy kernel on MI355X (MI355X_MICROARCH.md): the practical ceiling of a read + write stream
 GIB = float(1 << 30)
 
 
@@ -1057,6 +1058,10 @@ def main():
                      # the ALGORITHMIC 12 B per element of SURVEY 8d, `frac_physical` the 8 B that move
                      "achieved_physical": round(traffic / (k_avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                      "frac_physical": round(traffic / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                     # what a float4 copy kernel reaches on this part (MI355X_MICROARCH.md, chip-level parameters: 6.29 TB/s
+                     # measured = 79 % of the 8 TB/s specification): the physical rate as a fraction of THAT
+                     "copy_rate": COPY_RATE_GBS,
+                     "frac_physical_of_copy_rate": round(traffic / (k_avg_ms * 1e-3) / 1e9 / COPY_RATE_GBS, 4) if traffic else None,
                      "avg_launch_us": round(k_avg_ms * 1e3, 2), "median_launch_us": round(k_ms[len(k_ms) // 2] * 1e3, 2),
                      "launches_timed": len(k_ms), "algorithmic_bytes_per_launch": probe_bytes},
     }

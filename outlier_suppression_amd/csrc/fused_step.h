@@ -98,9 +98,9 @@ __device__ __forceinline__ unsigned long long side_granule(unsigned int tag, con
 // the hinted window, histogram of the window): the LDS atomics of the first histogram level -- what a CU spends most of
 // a selection on -- happen while the streaming workgroups are still arriving.
 // One CU retires an instruction of a 16-wave workgroup in ~8 clocks, so the registers are packed: with CH = ceil(cmax/64),
-// chunk i's first 64 (CH - 1) values fill registers i (CH - 1) .. -- always full --, and the TAILS (cmax - 64 (CH - 1)
-// values or one less) of 64 / tpad chunks share one register (tpad = the tail length rounded up to a power of two):
-// 18 registers per lane instead of 32 at the bench lengths.  noinline: one copy of the selection per CH for the four
+// a chunk's first 64 (CH - 1) values fill CH - 1 registers -- always full --, and the TAILS (cmax - 64 (CH - 1) values or
+// one less) of the four chunks of a group share 1, 2 or 4 registers (tpad = the tail length rounded up to a power of
+// two, 64 / tpad chunks per register): 20 registers per lane instead of 32 at the bench lengths.  noinline: one copy of the selection per CH for the four
 // kernel instantiations; the function publishes the side's granule itself, so that what the call costs at its end
 // (callee-saved registers coming back from scratch) is behind the hand-off, not in front of it.
 template <int CH>

@@ -298,6 +298,42 @@ def gen_msefast():
     save("msefast", **out)
 
 
+def gen_msefast_masked():
+    """Per-tensor MSEFast / AvgMSEFast on MASKED activations (observation_mask + seq_pos: remove_padding lays the valid
+    tokens out sample after sample, observer.py:72-84), three batches each, so that the second and third call run on a
+    float64 copy of x (observer.py:524,549): statistics after every call and the total number of loss evaluations.
+    Same torch.set_num_threads(1) as everything here: the sums inside the loss run ATen's serial cascade."""
+    gen = torch.Generator().manual_seed(777)
+    out = {}
+    k = 0
+    specs = [("AvgMSEFastObserver", (4, 16, 32), 6, False, 1), ("AvgMSEFastObserver", (4, 16, 32), 6, True, 1),
+             ("MSEFastObserver", (3, 12, 48), 4, False, 1), ("AvgMSEFastObserver", (2, 4, 10, 16), 6, False, 2)]
+    for cls_name, shape, bit, sym, seq_pos in specs:
+        ob = QM.ObserverDict[cls_name](bit=bit, symmetric=sym, ch_axis=-1)
+        nfev = [0]
+        orig = ob.loss_fx
+
+        def counted(*a, _orig=orig, **kw):
+            nfev[0] += 1
+            return _orig(*a, **kw)
+        ob.loss_fx = counted
+        xs, lens, mins, maxs = [], [], [], []
+        for r in range(3):
+            x = activation_like(gen, shape) * (1.0 + 0.4 * r)
+            T = shape[seq_pos]
+            L = torch.randint(1, T + 1, (shape[0],), generator=gen)
+            L[int(torch.randint(0, shape[0], (1,), generator=gen))] = T
+            ob(x, L, seq_pos)
+            xs.append(x.numpy()); lens.append(L.numpy())
+            mins.append(np.asarray(ob.min_val.numpy()).copy()); maxs.append(np.asarray(ob.max_val.numpy()).copy())
+        out[f"c{k}_x"], out[f"c{k}_len"] = np.stack(xs), np.stack(lens)
+        out[f"c{k}_min"], out[f"c{k}_max"] = np.stack(mins), np.stack(maxs)
+        out[f"c{k}_info"] = np.array([cls_name, str(bit), str(int(sym)), str(seq_pos), str(nfev[0]), ob.one_side_dist])
+        k += 1
+    out["n"] = k
+    save("msefast_masked", **out)
+
+
 MSEFAST_ROW_CASES = (("w768", 901, 2048, 768, 4), ("w3072", 902, 2048, 3072, 4), ("w768_6bit", 903, 1024, 768, 6))
 
 
@@ -473,6 +509,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "other":
         gen_other_observers()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "msefast_masked":
+        gen_msefast_masked()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "msefast_rows":
         gen_msefast_rows()
         sys.exit(0)
@@ -481,6 +520,7 @@ if __name__ == "__main__":
     gen_qparams()
     gen_observers()
     gen_msefast()
+    gen_msefast_masked()
     gen_msefast_rows()
     gen_modules()
     gen_gamma()

@@ -981,6 +981,31 @@ def test_msefast_tensor_equals_reference_in_its_summation_order(golden, dev):
         ops.set_tuning("mse_sum_order", 0)
 
 
+def test_msefast_masked_tensor_equals_reference_in_its_summation_order(golden, dev):
+    """The same test mode on MASKED activations (tests/golden/msefast_masked.npz: observation_mask + seq_pos, one case a
+    [B,h,T,d] tensor with the tokens on axis 2; three batches each, the later ones searched in float64): the kernel lays the
+    squared errors out in remove_padding's order (observer.py:72-84) and every statistic after every call, and the number
+    of loss evaluations, equal the reference's run bit for bit."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import observer as OBS
+    g = golden("msefast_masked")
+    ops.set_tuning("mse_sum_order", 8)
+    try:
+        for k in range(int(g["n"])):
+            cls, bit, sym, seq_pos, nfev, osd = (str(v) for v in g[f"c{k}_info"])
+            ob = getattr(OBS, cls)(bit=int(bit), symmetric=bool(int(sym)), ch_axis=-1).to(dev)
+            evals = 0
+            for r in range(3):
+                ob(torch.from_numpy(g[f"c{k}_x"][r]).to(dev), torch.from_numpy(g[f"c{k}_len"][r]).to(dev), int(seq_pos))
+                evals += int(ob.last_nfev.sum().item())
+                assert np.array_equal(N(ob.min_val).reshape(-1).astype(np.float64), g[f"c{k}_min"][r].reshape(-1)) and \
+                    np.array_equal(N(ob.max_val).reshape(-1).astype(np.float64), g[f"c{k}_max"][r].reshape(-1)), \
+                    (k, cls, r, N(ob.min_val), g[f"c{k}_min"][r], N(ob.max_val), g[f"c{k}_max"][r])
+            assert evals == int(nfev), (k, cls, evals, nfev)
+    finally:
+        ops.set_tuning("mse_sum_order", 0)
+
+
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_against_reference(golden, name, dev):
     """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;

@@ -169,6 +169,26 @@ def test_msefast_equals_reference_in_its_summation_order(golden):
         OB.MEAN_LIKE_TORCH = None
 
 
+def test_msefast_masked_equals_reference_in_its_summation_order(golden):
+    """The masked per-tensor searches (observation_mask + seq_pos: remove_padding's element order, observer.py:72-84; one
+    case a [B,h,T,d] tensor with the tokens on axis 2), three batches each -- the later ones in float64 --, reference run
+    by tests/golden/make_golden.py::gen_msefast_masked: statistics after every call and the number of loss evaluations
+    bit-equal once the loss is summed in ATen's order."""
+    g = golden("msefast_masked")
+    OB.MEAN_LIKE_TORCH = aten_order_mean
+    try:
+        for k in range(int(g["n"])):
+            cls, bit, sym, seq_pos, nfev, osd = (str(v) for v in g[f"c{k}_info"])
+            st = OB.ObserverState(bit=int(bit), symmetric=bool(int(sym)), ch_axis=-1)
+            counter = [0]
+            for r in range(3):
+                OB.observe_msefast(st, g[f"c{k}_x"][r], g[f"c{k}_len"][r], int(seq_pos), average=cls.startswith("Avg"), counter=counter)
+                assert np.array_equal(st.min_val, g[f"c{k}_min"][r]) and np.array_equal(st.max_val, g[f"c{k}_max"][r]), (k, r)
+            assert st.one_side_dist == osd and counter[0] == int(nfev), (k, counter[0], nfev)
+    finally:
+        OB.MEAN_LIKE_TORCH = None
+
+
 from _msefast_rows import MSEFAST_ROW_BOUNDS, msefast_row_weights, msefast_row_deviation  # noqa: E402
 
 

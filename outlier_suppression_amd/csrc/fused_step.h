@@ -128,15 +128,21 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, static_cast<int>(total * 4u), 0x00020000);
     OSQ_SSTAMP(0);
 
-    // A wave's sixteen chunks form four GROUPS of four (chunks 4 j .. 4 j + 3): a group is loaded and absorbed once its
-    // four workgroups have arrived -- one uniform test per group and round: on a 16-wave workgroup every instruction of
-    // the polling loop costs ~8 clocks, per-chunk tests made a round longer than the arrivals are apart.
+    // A wave's sixteen chunks form GROUPS (chunks GC j .. GC j + GC - 1): a group is loaded and absorbed once all its
+    // workgroups have arrived -- one uniform test per group and round: on a 16-wave workgroup every instruction of the
+    // polling loop costs ~8 clocks, per-chunk tests made a round longer than the arrivals are apart.  Two groups of eight
+    // measured best (bench step kernel 36.9 us; four groups 37.3, eight 38.1, one 37.1; all tokens valid 49.5 / 49.3 / 50.6 /
+    // 49.4 -- tools/ab_step.py on one box, -DOSQ_FUSED_GROUPS=n builds).
     // Tails: tlen values (or tlen - 1) per chunk behind its full blocks; the tails of a group share ntg registers.
-    constexpr int NG = 4, GC = NC / NG;                              // groups, chunks per group
+#ifndef OSQ_FUSED_GROUPS
+#define OSQ_FUSED_GROUPS 2
+#endif
+    constexpr int NG = OSQ_FUSED_GROUPS, GC = NC / NG;               // groups, chunks per group
+    constexpr unsigned int kGroupMask = (1u << GC) - 1u;
     const unsigned int cmax = qv + (rv ? 1u : 0u);                   // V > 0: 64 (CH - 1) < cmax <= 64 CH
     const unsigned int tlen = cmax - static_cast<unsigned int>(OSQ_WAVE * (CH - 1));
     const unsigned int lt = tlen <= 1u ? 0u : 32u - static_cast<unsigned int>(__builtin_clz(tlen - 1u));   // tpad = 1 << lt >= tlen
-    const unsigned int cpr = lt <= 4u ? static_cast<unsigned int>(GC) : 1u << (6u - lt);                   // chunks per tail register: 4, 2, 1
+    const unsigned int cpr = (64u >> lt) >= static_cast<unsigned int>(GC) ? static_cast<unsigned int>(GC) : 64u >> lt;   // chunks per tail register: 4, 2, 1
     const unsigned int ntg = static_cast<unsigned int>(GC) / cpr;                                          // tail registers per group: 1, 2, 4
     // registers: [group j: 4 (CH - 1) full blocks][group j: 4 tail registers, ntg of them in use], j = 0..3
     constexpr int RG = GC * (CH - 1) + GC;                           // per group
@@ -164,7 +170,7 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
     unsigned int gdone = 0u, below = 0u;                              // groups that are in
 #pragma unroll
     for (int j = 0; j < NG; ++j)
-        if (((want >> (GC * j)) & 0xfu) == 0u) gdone |= 1u << j;      // nothing to wait for
+        if (((want >> (GC * j)) & kGroupMask) == 0u) gdone |= 1u << j;      // nothing to wait for
     bool bad = false;
     const unsigned int* const flags = &st->flag[wv * NC];
     // One value: sign, NaN flag, and -- hinted -- below-the-window count and the window's histogram.  The range of the
@@ -194,7 +200,7 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
         unsigned int ready = 0u;
 #pragma unroll
         for (int j = 0; j < NG; ++j)
-            if (((missing >> (GC * j)) & 0xfu) == 0u) ready |= 1u << j;
+            if (((missing >> (GC * j)) & kGroupMask) == 0u) ready |= 1u << j;
         const unsigned int newly = uniform(ready & ~gdone);
 #ifdef OSQ_FINAL_TIMING
         if (newly) { if (!dbg_rounds) dbg_first = wall_clock64(); ++dbg_rounds; } else ++dbg_empty;

@@ -90,7 +90,8 @@ size_t      osq_workspace_bytes(void);
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
  *   threshold pass; "select_hint" 0 = the selectors of the one-launch observe + fake-quant step do not pre-histogram a window around the
- *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "mse_sum_order" 8 | 16 | 64 = test modes of the MSEFast loss: per-row sums in ATen's CPU order for 8- / 16-lane SIMD
+ *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "bwd_sum_order" 8 = test mode of the per-tensor LSQ / LSQ+ backward: the gradient sums in
+ *   autograd's decomposition and ATen's CPU order, fp32 (<= 32768 elements); "mse_sum_order" 8 | 16 | 64 = test modes of the MSEFast loss: per-row sums in ATen's CPU order for 8- / 16-lane SIMD
  *   (oracle/aten_sum.py), or per-tensor sums as double-doubles, i.e. order-independent (64; one launch per evaluation); 0 = off;
  *   "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
  *   of the one-launch resident form (the last three exist so that tests can drive every implementation);

@@ -143,6 +143,36 @@ def lsqplus_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant
     return dx.astype(F32), dscale, dzp
 
 
+def lsqplus_backward_per_tensor_reference_order(x, grad_out, scale, zero_point, quant_min, quant_max, grad_factor, vec=8):
+    """The same gradients with the reductions done the way autograd does them on the reference's CPU (one thread):
+    scale.grad and zero_point.grad are each the fp32 sum of TWO ``sum_to_size`` reductions -- mul backward and div
+    backward for the scale, add backward and sub backward for the zero point (util_quant.py:48-55) --, every reduction
+    torch's fp32 ``sum`` in ATen's order (oracle/aten_sum.py), then grad_scale's factor (util_quant.py:70-71) as an fp32
+    multiplication.  Equal to the reference's own run (tests/golden/lsqplus.npz) bit for bit.
+    Returns (dx [fp32], dscale [fp32 scalar], dzero_point [fp32 scalar])."""
+    from .aten_sum import aten_sum
+    x = _f32(x)
+    gy = _f32(grad_out)
+    s, z = lsqplus_effective_params(scale, zero_point, grad_factor)
+    s = F32(s.reshape(-1)[0])
+    z = F32(z.reshape(-1)[0])
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        u = x / s
+        x_int = round_ste_value(u) + z
+        inside = (x_int >= F32(quant_min)) & (x_int <= F32(quant_max))
+        xq = np.clip(x_int, F32(quant_min), F32(quant_max))
+        g_mul = gy * s
+        g_in = np.where(inside, g_mul, F32(0))
+        dx = g_in / s
+        ds_mul = gy * (xq - z)
+        ds_div = -g_in * ((x / s) / s)
+    total = lambda a: aten_sum(np.ascontiguousarray(a, dtype=F32).reshape(-1), vec, np.float32, serial_only=False)   # noqa: E731
+    g = F32(grad_factor)
+    dscale = F32(F32(total(ds_mul) + total(ds_div)) * g)
+    dzp = F32(F32(total(g_in) + total(-g_mul)) * g)
+    return dx.astype(F32), dscale, dzp
+
+
 def lsqplus_grad_factor(numel, quant_max, channels=None):
     """fake_quant.py:195-204: ``1/sqrt(numel*qmax)`` or ``1/sqrt(numel/C*qmax)`` (Python float)."""
     if channels is None:

@@ -19,6 +19,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // tuning knobs of the dense per-tensor kernel (osq_set_tuning): loads in flight per lane, grid cap, and
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
+static int g_bwd_sum_order = 0;      // osq_set_tuning("bwd_sum_order", 0 | 8): 8 = the LSQ / LSQ+ gradients summed in ATen's CPU order (test mode, lsq_bwd_tensor_aten_kernel)
 static int g_fq_max_blocks = 8192;
 static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
 static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
@@ -469,6 +470,49 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
     }
 }
 
+// Test mode osq_set_tuning("bwd_sum_order", 8): the two gradients summed the way autograd sums them on the reference's
+// CPU -- FOUR reductions, each torch's fp32 `sum` in ATen's order (osq_device.h): scale.grad = (sum(gy * (xq - z)) +
+// sum(-g_in * ((x / s) / s))) * g and zero_point.grad = (sum(g_in) + sum(-g_mul)) * g, every operation fp32 (mul backward,
+// div backward, add / sub backward reduced with sum_to_size, then grad_scale's factor; util_quant.py:48-55, 70-71).  One
+// workgroup writes the four term arrays to scratch, its first four waves add one each.  The results equal the
+// reference-generated tests/golden/lsqplus.npz BIT FOR BIT (tests/test_gpu_parity.py::test_lsqplus_gradients_equal_
+// reference_in_its_summation_order); production sums in float64.  n <= 32768.
+constexpr int kBwdAtenThreads = 1024;
+constexpr int64_t kBwdAtenMaxElems = 32768;
+__global__ __launch_bounds__(kBwdAtenThreads) void lsq_bwd_tensor_aten_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx, int n,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp, float* __restrict__ terms, int W) {
+    const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
+    const float s = p.scale, z = p.zp;
+    for (int i = threadIdx.x; i < n; i += kBwdAtenThreads) {
+        float x_int;
+        const float q = quantize_value(x[i], s, z, qmin, qmax, &x_int);
+        const bool inside = (x_int >= qmin) && (x_int <= qmax);
+        const float g_mul = gy[i] * s;
+        const float g_in = inside ? g_mul : 0.0f;
+        dx[i] = g_in / s;
+        terms[i] = gy[i] * (q - z);
+        terms[n + i] = (-g_in) * ((x[i] / s) / s);
+        terms[2 * n + i] = g_in;
+        terms[3 * n + i] = -g_mul;
+    }
+    __threadfence_block();
+    __syncthreads();
+    __shared__ float sums[4];
+    const int w = threadIdx.x / OSQ_WAVE;
+    if (w < 4) {
+        const float t = aten_sum_wave<float>(terms + static_cast<int64_t>(w) * n, n, W);
+        if ((threadIdx.x & (OSQ_WAVE - 1)) == 0) sums[w] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ds = sums[0] + sums[1], dz = sums[2] + sums[3];
+        if (dscale) dscale[0] = (mode == OSQ_PARAM_FIXED) ? ds : ds * g;
+        if (dzp) dzp[0] = (mode == OSQ_PARAM_LSQPLUS) ? dz * g : dz;
+    }
+}
+
 // per-channel backward on [rows = outer*channels, inner]: one workgroup per channel,
 // no cross-workgroup reduction needed.
 __global__ __launch_bounds__(kThreads) void lsq_bwd_channel_kernel(
@@ -739,6 +783,12 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     const int tail = static_cast<int>(n - n4 * 4);
     const int grid = grid_for(n4, kThreads * 2, g_bwd_blocks);
     Workspace ws(workspace);
+    if (g_bwd_sum_order) {        // test mode: the reference machine's summation order
+        OSQ_REQUIRE(n >= 16 && n <= kBwdAtenMaxElems, "lsq_backward_per_tensor: the summation-order test mode takes 16..32768 elements");
+        hipLaunchKernelGGL(lsq_bwd_tensor_aten_kernel, dim3(1), dim3(kBwdAtenThreads), 0, st, x, grad_out, grad_x, static_cast<int>(n), scale,
+                           zero_point, zp_type, mode, grad_factor, qmin, qmax, grad_scale, grad_zero_point, ws.floats(0), g_bwd_sum_order);
+        return check_launch("lsq_backward_per_tensor(aten order)");
+    }
     const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
@@ -790,6 +840,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     OSQ_REQUIRE(key, "set_tuning: null key");
     const std::string k(key);
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
+    else if (k == "bwd_sum_order") { OSQ_REQUIRE(value == 0 || value == 8 || value == 16, "bwd_sum_order must be 0, 8 or 16"); osq::g_bwd_sum_order = value; }
     else if (k == "fq_headsplit") { osq::g_fq_headsplit = value != 0; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }

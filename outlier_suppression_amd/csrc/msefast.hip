@@ -294,57 +294,7 @@ __device__ __forceinline__ double sq_err4(const float4& a, float s, float z, flo
 // in LDS): the searches are then the reference's own, iterate for iterate, and the ranges equal the reference-generated
 // fixtures BIT FOR BIT (tests/test_gpu_parity.py::test_msefast_rows_equal_reference_in_its_summation_order).  The default
 // stays the exact (float64) sum: it is the correctly rounded loss, and it does not depend on a vector width.
-__device__ __forceinline__ int ceil_log2_i(int x) { return x <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned int>(x - 1)); }
-
-// lane < W: that SIMD lane's partial sum over vectors 0 .. n_vec-1 of sq (vector i = sq[i*W .. i*W + W-1])
-template <typename T>
-__device__ __forceinline__ T aten_lane_partial(const T* sq, int n_vec, int W, int lane) {
-    constexpr int kLevels = 4, kIlp = 4;
-    const int size = n_vec / kIlp;
-    int level_power = ceil_log2_i(size) / kLevels;
-    level_power = level_power < 4 ? 4 : level_power;
-    const int level_step = 1 << level_power, level_mask = level_step - 1;
-    T acc[kLevels][kIlp];
-#pragma unroll
-    for (int j = 0; j < kLevels; ++j)
-#pragma unroll
-        for (int k = 0; k < kIlp; ++k) acc[j][k] = T(0);
-    int i = 0;
-    while (i + level_step <= size) {
-        for (int j = 0; j < level_step; ++j, ++i)
-#pragma unroll
-            for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
-#pragma unroll
-        for (int j = 1; j < kLevels; ++j) {
-#pragma unroll
-            for (int k = 0; k < kIlp; ++k) { acc[j][k] = acc[j][k] + acc[j - 1][k]; acc[j - 1][k] = T(0); }
-            if ((i & (level_mask << (j * level_power))) != 0) break;
-        }
-    }
-    for (; i < size; ++i)
-#pragma unroll
-        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
-#pragma unroll
-    for (int j = 1; j < kLevels; ++j)
-#pragma unroll
-        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + acc[j][k];
-    for (int v = size * kIlp; v < n_vec; ++v) acc[0][0] = acc[0][0] + sq[v * W + lane];
-#pragma unroll
-    for (int k = 1; k < kIlp; ++k) acc[0][0] = acc[0][0] + acc[0][k];
-    return acc[0][0];
-}
-
-// the whole wave calls; returns torch's mean (in T) of sq[0..n-1] (n >= W) in every lane
-template <typename T>
-__device__ __forceinline__ T aten_mean_wave(const T* sq, int n, int W) {
-    const int lane = threadIdx.x & (OSQ_WAVE - 1);
-    const int n_vec = n / W;
-    const T part = lane < W ? aten_lane_partial<T>(sq, n_vec, W, lane) : T(0);
-    T fin = T(0);
-    for (int k = n_vec * W; k < n; ++k) fin = fin + sq[k];
-    for (int l = 0; l < W; ++l) fin = fin + __shfl(part, l, OSQ_WAVE);
-    return fin / static_cast<T>(n);
-}
+// (ceil_log2_i, aten_lane_partial, aten_sum_wave, aten_mean_wave: osq_device.h -- the LSQ backward has the same test mode)
 
 // ---------------------------------------------------------------- per-channel: one wave per row
 

@@ -283,6 +283,68 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// ---- ATen's CPU summation order (test modes: osq_set_tuning("mse_sum_order" / "bwd_sum_order", 8)) ----------------
+// torch's CPU `sum` of a contiguous vector adds in the order of cascade_sum / vectorized_inner_sum
+// (aten/src/ATen/native/cpu/SumKernel.cpp; restated and pinned against torch.sum in oracle/aten_sum.py): W SIMD lanes,
+// lane l owning elements l, l + W, ...; per lane four interleaved accumulators, each a 4-level cascade; then the n % W
+// trailing scalars and the W lanes, in order, onto a scalar.  W = 8 for fp32 and 4 for float64 (256-bit vectors, also on
+// AVX-512 machines).  Lanes 0..W-1 of a wave play the SIMD lanes.
+__device__ __forceinline__ int ceil_log2_i(int x) { return x <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned int>(x - 1)); }
+
+// lane < W: that SIMD lane's partial sum over vectors 0 .. n_vec-1 of sq (vector i = sq[i*W .. i*W + W-1])
+template <typename T>
+__device__ __forceinline__ T aten_lane_partial(const T* sq, int n_vec, int W, int lane) {
+    constexpr int kLevels = 4, kIlp = 4;
+    const int size = n_vec / kIlp;
+    int level_power = ceil_log2_i(size) / kLevels;
+    level_power = level_power < 4 ? 4 : level_power;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    T acc[kLevels][kIlp];
+#pragma unroll
+    for (int j = 0; j < kLevels; ++j)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[j][k] = T(0);
+    int i = 0;
+    while (i + level_step <= size) {
+        for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+            for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
+#pragma unroll
+        for (int j = 1; j < kLevels; ++j) {
+#pragma unroll
+            for (int k = 0; k < kIlp; ++k) { acc[j][k] = acc[j][k] + acc[j - 1][k]; acc[j - 1][k] = T(0); }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < size; ++i)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + sq[(i * kIlp + k) * W + lane];
+#pragma unroll
+    for (int j = 1; j < kLevels; ++j)
+#pragma unroll
+        for (int k = 0; k < kIlp; ++k) acc[0][k] = acc[0][k] + acc[j][k];
+    for (int v = size * kIlp; v < n_vec; ++v) acc[0][0] = acc[0][0] + sq[v * W + lane];
+#pragma unroll
+    for (int k = 1; k < kIlp; ++k) acc[0][0] = acc[0][0] + acc[0][k];
+    return acc[0][0];
+}
+
+// the whole wave calls; returns torch's sum (in T) of sq[0..n-1] (n >= W) in every lane
+template <typename T>
+__device__ __forceinline__ T aten_sum_wave(const T* sq, int n, int W) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int n_vec = n / W;
+    const T part = lane < W ? aten_lane_partial<T>(sq, n_vec, W, lane) : T(0);
+    T fin = T(0);
+    for (int k = n_vec * W; k < n; ++k) fin = fin + sq[k];
+    for (int l = 0; l < W; ++l) fin = fin + __shfl(part, l, OSQ_WAVE);
+    return fin;
+}
+// ... and torch's mean: sum_out(...).div_(n) in T
+template <typename T>
+__device__ __forceinline__ T aten_mean_wave(const T* sq, int n, int W) { return aten_sum_wave<T>(sq, n, W) / static_cast<T>(n); }
+
+
 // ---- last-workgroup-finishes pattern, without release fences ---------------------------
 // A release fence at agent scope is `buffer_wbl2` = write back the whole XCD L2; issued by
 // every workgroup of a 2048-block grid it serialises (measured: 108 us for a 96 MiB min/max

@@ -142,6 +142,28 @@ def test_lsqplus_golden(golden, eq32, dev):
     np.testing.assert_allclose(N(z.grad), g["pc_dzp"], rtol=2e-5, atol=1e-7)
 
 
+def test_lsqplus_gradients_equal_reference_in_its_summation_order(golden, eq32, dev):
+    """osq_set_tuning("bwd_sum_order", 8): the backward adds its four reductions in fp32 in the order torch's CPU kernel
+    does (lsq_bwd_tensor_aten_kernel) -- scale.grad and zero_point.grad then equal the reference's own autograd run
+    (tests/golden/lsqplus.npz) BIT FOR BIT, like y and dx always do."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import util_quant as U
+    g = golden("lsqplus")
+    ops.set_tuning("bwd_sum_order", 8)
+    try:
+        for k in range(int(g["n"])):
+            scale, zp, qmin, qmax, gf = g[f"c{k}_meta"]
+            x = T(g[f"c{k}_x"], dev).requires_grad_(True)
+            s = torch.tensor([scale], dtype=torch.float32, device=dev, requires_grad=True)
+            z = torch.tensor([zp], dtype=torch.float32, device=dev, requires_grad=True)
+            y = U.fake_quantize_learnableplus_per_tensor_affine_training(x, s, z, int(qmin), int(qmax), gf)
+            y.backward(T(g[f"c{k}_gy"], dev))
+            assert eq32(N(y), g[f"c{k}_y"]) and eq32(N(x.grad), g[f"c{k}_dx"])
+            assert eq32(N(s.grad), g[f"c{k}_ds"]) and eq32(N(z.grad), g[f"c{k}_dzp"]), (k, N(s.grad), g[f"c{k}_ds"], N(z.grad), g[f"c{k}_dzp"])
+    finally:
+        ops.set_tuning("bwd_sum_order", 0)
+
+
 def test_lsq_backward_determinism_and_size(dev):
     """Grid-wide reduction: same bits run to run, and correct at a size with many workgroups."""
     from outlier_suppression_amd import ops

@@ -37,6 +37,17 @@ def test_fake_quant_per_channel_and_rowwise_minmax(golden, eq32):
         assert eq32(xq, g[f"pc{k}_xq"]) and eq32(y, g[f"pc{k}_y"])
 
 
+def test_lsqplus_gradients_equal_reference_in_its_summation_order(golden, eq32):
+    """scale.grad and zero_point.grad of the reference's own backward (fp32 sums in autograd's decomposition and ATen's
+    order) reproduced bit for bit: the 2e-5 of test_lsqplus_forward_backward is the summation order and nothing else."""
+    g = golden("lsqplus")
+    for k in range(int(g["n"])):
+        scale, zp, qmin, qmax, gf = g[f"c{k}_meta"]
+        dx, ds, dzp = FQ.lsqplus_backward_per_tensor_reference_order(g[f"c{k}_x"], g[f"c{k}_gy"], F32(scale), F32(zp), int(qmin), int(qmax), gf)
+        assert eq32(dx, g[f"c{k}_dx"])
+        assert ds == g[f"c{k}_ds"][0] and dzp == g[f"c{k}_dzp"][0], (k, ds, g[f"c{k}_ds"], dzp, g[f"c{k}_dzp"])
+
+
 def test_lsqplus_forward_backward(golden, eq32):
     g = golden("lsqplus")
     for k in range(int(g["n"])):

@@ -173,6 +173,33 @@ def lsqplus_backward_per_tensor_reference_order(x, grad_out, scale, zero_point, 
     return dx.astype(F32), dscale, dzp
 
 
+def lsqplus_backward_per_channel_reference_order(x, grad_out, scale, zero_point, quant_min, quant_max, grad_factor, vec=8):
+    """Per-channel (ch_axis = 0, x = [channels, inner]) counterpart: sum_to_size reduces every row with torch's fp32 ``sum``
+    over the contiguous inner axis (the same cascade per row).  Returns (dx, dscale [channels], dzero_point [channels]),
+    equal to tests/golden/lsqplus.npz's ``pc_*`` bit for bit."""
+    from .aten_sum import aten_sum
+    x = _f32(x)
+    gy = _f32(grad_out)
+    s, z = lsqplus_effective_params(scale, zero_point, grad_factor)
+    s = np.asarray(s, F32).reshape(-1, 1)
+    z = np.asarray(z, F32).reshape(-1, 1)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        u = x / s
+        x_int = round_ste_value(u) + z
+        inside = (x_int >= F32(quant_min)) & (x_int <= F32(quant_max))
+        xq = np.clip(x_int, F32(quant_min), F32(quant_max))
+        g_mul = gy * s
+        g_in = np.where(inside, g_mul, F32(0))
+        dx = g_in / s
+        ds_mul = gy * (xq - z)
+        ds_div = -g_in * ((x / s) / s)
+    rows = lambda a: aten_sum(np.ascontiguousarray(a, dtype=F32), vec, np.float32)   # noqa: E731
+    g = F32(grad_factor)
+    dscale = ((rows(ds_mul) + rows(ds_div)).astype(F32) * g).astype(F32)
+    dzp = ((rows(g_in) + rows(-g_mul)).astype(F32) * g).astype(F32)
+    return dx.astype(F32), dscale, dzp
+
+
 def lsqplus_grad_factor(numel, quant_max, channels=None):
     """fake_quant.py:195-204: ``1/sqrt(numel*qmax)`` or ``1/sqrt(numel/C*qmax)`` (Python float)."""
     if channels is None:

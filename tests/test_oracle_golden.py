@@ -46,6 +46,9 @@ def test_lsqplus_gradients_equal_reference_in_its_summation_order(golden, eq32):
         dx, ds, dzp = FQ.lsqplus_backward_per_tensor_reference_order(g[f"c{k}_x"], g[f"c{k}_gy"], F32(scale), F32(zp), int(qmin), int(qmax), gf)
         assert eq32(dx, g[f"c{k}_dx"])
         assert ds == g[f"c{k}_ds"][0] and dzp == g[f"c{k}_dzp"][0], (k, ds, g[f"c{k}_ds"], dzp, g[f"c{k}_dzp"])
+    qmin, qmax, gf = int(g["pc_meta"][1]), int(g["pc_meta"][2]), g["pc_meta"][3]
+    dx, ds, dzp = FQ.lsqplus_backward_per_channel_reference_order(g["pc_x"], g["pc_gy"], g["pc_scale"], g["pc_zp"], qmin, qmax, gf)
+    assert eq32(dx, g["pc_dx"]) and eq32(ds, g["pc_ds"]) and eq32(dzp, g["pc_dzp"])
 
 
 def test_lsqplus_forward_backward(golden, eq32):

@@ -275,6 +275,11 @@ def observe_avg_prune_minmax(st, x, lengths=None, seq_pos=-1):
 # the reference RUN ON THE SAME MACHINE set ``MEAN_LIKE_TORCH = lambda sq: torch.from_numpy(sq).mean().numpy()`` to show
 # that the summation order is the only difference (tests/test_oracle_vs_reference_live.py).
 MEAN_LIKE_TORCH = None
+# Per-channel searches are the exception: a row is shorter than ATen's 32768-element grain, so the reference adds it serially,
+# in an order that depends only on the vector width of torch's sum kernel (8 fp32 lanes on x86, AVX2 and AVX-512 alike:
+# oracle/aten_sum.py) -- part of what "the reference CPU path" computes, whatever the host's thread count.  The oracle (and
+# the kernels, osq_set_tuning("mse_rows_order", 8)) therefore sum ROWS in that order by default; None = the exact sum.
+ROW_SUM_VEC = 8
 
 
 def exact_mean(sq):
@@ -393,9 +398,18 @@ def observe_msefast(st, x, lengths=None, seq_pos=-1, average=False, counter=None
     else:
         rows = _to_channel_rows(x, st.ch_axis)
         best_min, best_max = rows.min(axis=1), rows.max(axis=1)
-        for c in range(rows.shape[0]):
-            lo, hi = search(rows[c], best_min[c], best_max[c], st, counter)
-            best_min[c], best_max[c] = lo, hi  # assignment into fp32 tensors (observer.py:504,516)
+        global MEAN_LIKE_TORCH
+        row_order = MEAN_LIKE_TORCH is None and ROW_SUM_VEC is not None and rows.shape[1] < 32768 and rows.dtype == F32
+        if row_order:
+            from .aten_sum import aten_mean_f32
+            MEAN_LIKE_TORCH = lambda sq: aten_mean_f32(sq, ROW_SUM_VEC)      # noqa: E731
+        try:
+            for c in range(rows.shape[0]):
+                lo, hi = search(rows[c], best_min[c], best_max[c], st, counter)
+                best_min[c], best_max[c] = lo, hi  # assignment into fp32 tensors (observer.py:504,516)
+        finally:
+            if row_order:
+                MEAN_LIKE_TORCH = None
     if average:
         st._avg_update(best_min, best_max)
     else:

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __r
                                                                 int sum_width = 0) {
     extern __shared__ float sq_stage[];          // ATEN: cols floats per wave
     const int lane = threadIdx.x & (OSQ_WAVE - 1);
-    const int64_t row = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
+    const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / OSQ_WAVE;   // blockDim.x: 256, or 64 for long rows in ATEN mode
     if (row >= rows) return;
     const float* xr = w + row * cols;
     constexpr int R = MAXV > 0 ? MAXV : 1;
@@ -333,17 +333,22 @@ __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __r
         // every squared error (an fp32 value) is added in float64 from the first addition on: the total is then the
         // exact sum to ~1e-16 whatever the order, and its fp32-rounded mean is THE correctly rounded loss -- the same
         // number oracle/observer_oracle.py::mse_loss computes, so the search is iterate-for-iterate the oracle's
-        if (ATEN && MAXV > 0) {
+        if (ATEN) {
             float* sq = sq_stage + (threadIdx.x / OSQ_WAVE) * cols;
+            if (MAXV > 0) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int j = lane + k * OSQ_WAVE;
-                if (j < cols) sq[j] = sq_err(cache[k], s, z, qmin_f, qmax_f);
+                for (int k = 0; k < R; ++k) {
+                    const int j = lane + k * OSQ_WAVE;
+                    if (j < cols) sq[j] = sq_err(cache[k], s, z, qmin_f, qmax_f);
+                }
+            } else {
+                for (int j = lane; j < cols; j += OSQ_WAVE) sq[j] = sq_err(xr[j], s, z, qmin_f, qmax_f);
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            S.tell(static_cast<double>(aten_mean_wave(sq, cols, sum_width)));
+            // rows shorter than one SIMD vector: ATen's scalar_inner_sum (four interleaved scalar accumulators)
+            S.tell(static_cast<double>(cols >= sum_width ? aten_mean_wave(sq, cols, sum_width) : aten_sum_short(sq, cols) / static_cast<float>(cols)));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             continue;
         }
@@ -813,6 +818,7 @@ constexpr int kResWaves = kResThreads / OSQ_WAVE;
 constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
+static int g_mse_rows_order = 8;                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
 static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
@@ -1326,11 +1332,36 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
     const int grid = static_cast<int>((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     const int c = static_cast<int>(cols);
     const TimingHook th = take_timing_hook(OSQ_TIME_MSEFAST_ROWS);
-    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {       // test mode: the loss summed in the reference machine's order (see aten_mean_wave)
-        if (cols < g_mse_sum_order || cols > 64 * 48) return OSQ_ERR_UNSUPPORTED;
+    // Per-channel rows are summed in the REFERENCE's order by default (osq_set_tuning("mse_rows_order", 8)): a row is shorter
+    // than ATen's 32768-element grain, so torch adds it serially in an order fixed by its 256-bit vectors whatever the
+    // host's thread count -- the searches are then the reference's own, iterate for iterate, and the weight ranges, hence
+    // the integer weights, come out bit-equal to the reference CPU path (BASELINE north_star).  1.4-2x the time of the
+    // order-free kernel (134 495 rows of RoBERTa-base: 37 ms instead of 21).  Rows outside 8..3072 columns, and
+    // "mse_rows_order" 0, take the order-free sum.
+    const bool forced = g_mse_sum_order == 8 || g_mse_sum_order == 16;
+    const int order = forced ? g_mse_sum_order : g_mse_rows_order;
+    if (order && cols > 64 * 48 && cols < 32768) {
+        // long rows (BART-large's 4096-column fc2): one wave per workgroup, the row re-read, its squared errors in up to 128 KiB of LDS
+        static bool big_lds = false;
+        if (!big_lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msefast_rows_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                OSQ_REQUIRE(!forced, "msefast_rows: cannot reserve the LDS of the summation-order mode for rows this long");
+            } else {
+                big_lds = true;
+            }
+        }
+        if (big_lds) {
+            hipExtLaunchKernelGGL((msefast_rows_kernel<0, true>), dim3(static_cast<unsigned int>(rows)), dim3(OSQ_WAVE), static_cast<size_t>(c) * sizeof(float), st,
+                                  th.start, th.stop, 0, w, rows, c, quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev, order);
+            return check_launch("msefast_rows(reference summation order, long rows)");
+        }
+    }
+    if (forced && cols >= 32768) return OSQ_ERR_UNSUPPORTED;
+    if (order && cols <= 64 * 48) {
         const size_t lds = static_cast<size_t>(kWavesPerBlock) * c * sizeof(float);
-#define OSQ_ROWS_ATEN(M) hipLaunchKernelGGL((msefast_rows_kernel<M, true>), dim3(grid), dim3(kThreads), lds, st, w, rows, c, \
-                                            quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev, g_mse_sum_order)
+#define OSQ_ROWS_ATEN(M) hipExtLaunchKernelGGL((msefast_rows_kernel<M, true>), dim3(grid), dim3(kThreads), lds, st, th.start, th.stop, 0, w, rows, c, \
+                                            quant_min, quant_max, symmetric, one_side, two_d, best_min, best_max, nfev, order)
         if (cols <= 64 * 4) OSQ_ROWS_ATEN(4);
         else if (cols <= 64 * 16) OSQ_ROWS_ATEN(16);
         else OSQ_ROWS_ATEN(48);
@@ -1412,6 +1443,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
 static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
+    if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;

@@ -340,6 +340,18 @@ __device__ __forceinline__ T aten_sum_wave(const T* sq, int n, int W) {
     for (int l = 0; l < W; ++l) fin = fin + __shfl(part, l, OSQ_WAVE);
     return fin;
 }
+// n < W: scalar_inner_sum -- four interleaved scalar accumulators (the cascade never flushes below 16 x 4 elements), the
+// left-overs onto the first, then the four in order.  Every lane computes it.
+template <typename T>
+__device__ __forceinline__ T aten_sum_short(const T* sq, int n) {
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    const int size = n / 4;
+    for (int i = 0; i < size; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] + sq[i * 4 + k];
+    for (int i = size * 4; i < n; ++i) acc[0] = acc[0] + sq[i];
+    return ((acc[0] + acc[1]) + acc[2]) + acc[3];
+}
 // ... and torch's mean: sum_out(...).div_(n) in T
 template <typename T>
 __device__ __forceinline__ T aten_mean_wave(const T* sq, int n, int W) { return aten_sum_wave<T>(sq, n, W) / static_cast<T>(n); }

@@ -684,7 +684,10 @@ def test_msefast_equals_oracle(dev):
     from outlier_suppression_amd.quantization.observer import MSEFastObserver, AvgMSEFastObserver
     from oracle import observer_oracle as OB
     gen = torch.Generator().manual_seed(8)
-    for cols, bit, rows in ((768, 4, 48), (3072, 4, 24), (200, 6, 24), (3100, 4, 6), (96, 4, 24), (768, 6, 16)):
+    # (rows are summed in the reference's order on both sides, observer_oracle.ROW_SUM_VEC / "mse_rows_order": 8 lanes; 4096
+    # and 9000 columns take the long-row form of that kernel, 5 and 7 columns ATen's scalar path)
+    for cols, bit, rows in ((768, 4, 48), (3072, 4, 24), (200, 6, 24), (3100, 4, 6), (96, 4, 24), (768, 6, 16), (4096, 4, 6),
+                            (9000, 4, 3), (5, 4, 12), (7, 6, 12), (8, 4, 12)):
         w = torch.randn(rows, cols, generator=gen) * 0.05
         ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
         ob(w.to(dev))
@@ -1030,11 +1033,12 @@ def test_msefast_masked_tensor_equals_reference_in_its_summation_order(golden, d
 
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_against_reference(golden, name, dev):
-    """Every row of the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;
-    tests/golden/make_golden.py::gen_msefast_rows): how far the kernel's ranges are from the reference's, and what that
-    does to the integers.  Measured: median relative range error 2e-5, 99th percentile 2e-4, x_quant entries that
-    differ 1.5e-5 .. 4e-5 of all entries.  (The kernel equals the oracle exactly; the oracle equals the reference
-    exactly once its loss is summed in torch's order: tests/test_oracle_vs_reference_live.py.)"""
+    """The ORDER-FREE variant (osq_set_tuning("mse_rows_order", 0): the loss summed exactly and rounded once) on every row of
+    the reference-generated fixture (2048 rows of 768 and of 3072 columns at 4 bit, 1024 rows at 6 bit;
+    tests/golden/make_golden.py::gen_msefast_rows): how far its ranges are from the reference's, and what that does to the
+    integers.  Measured: median relative range error 2e-5, 99th percentile 2e-4, x_quant entries that differ
+    1.5e-5 .. 4e-5 of all entries -- which is why the DEFAULT sums rows in the reference's order
+    (test_msefast_rows_equal_reference_in_its_summation_order: bit-equal)."""
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization.observer import MSEFastObserver
     from _msefast_rows import MSEFAST_ROW_BOUNDS, msefast_row_weights
@@ -1042,7 +1046,12 @@ def test_msefast_rows_against_reference(golden, name, dev):
     seed, rows, cols, bit, ref_nfev = (int(v) for v in g[name + "_info"])
     w = torch.from_numpy(msefast_row_weights(seed, rows, cols)).to(dev)
     ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
-    ob(w)
+    ops.set_tuning("mse_rows_order", 0)
+    try:
+        ob(w)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("mse_rows_order", 8)
     ref_min, ref_max = T(g[name + "_min"], dev), T(g[name + "_max"], dev)
     rel = ((ob.max_val - ref_max).abs() / ref_max).cpu().numpy()
     b = MSEFAST_ROW_BOUNDS
@@ -1060,11 +1069,11 @@ def test_msefast_rows_against_reference(golden, name, dev):
 
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_equal_reference_in_its_summation_order(golden, name, dev):
-    """osq_set_tuning("mse_sum_order", 8): the per-row kernel adds its squared errors in the order torch's CPU kernel adds
-    them (8 SIMD lanes, 4 interleaved cascades per lane; restated in oracle/aten_sum.py and pinned against torch.sum).
-    Every one of the fixture's 5120 reference-generated rows then comes out BIT-EQUAL -- min_val, max_val, hence every
-    scale and every x_quant entry -- and the evaluation count equals the reference's exactly: the whole distance
-    between the default (exact-sum) kernel and the reference is that summation order."""
+    """The DEFAULT per-row kernel adds its squared errors in the order torch's CPU kernel adds them (8 SIMD lanes, 4
+    interleaved cascades per lane; restated in oracle/aten_sum.py and pinned against torch.sum; a row is shorter than
+    ATen's parallel grain, so that order is the reference's whatever the host's thread count).  Every one of the fixture's
+    5120 reference-generated rows comes out BIT-EQUAL -- min_val, max_val, hence every scale and every x_quant entry --
+    and the evaluation count equals the reference's exactly."""
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization.observer import MSEFastObserver
     from _msefast_rows import msefast_row_weights
@@ -1072,12 +1081,8 @@ def test_msefast_rows_equal_reference_in_its_summation_order(golden, name, dev):
     seed, rows, cols, bit, ref_nfev = (int(v) for v in g[name + "_info"])
     w = torch.from_numpy(msefast_row_weights(seed, rows, cols)).to(dev)
     ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
-    ops.set_tuning("mse_sum_order", 8)
-    try:
-        ob(w)
-        torch.cuda.synchronize()
-    finally:
-        ops.set_tuning("mse_sum_order", 0)
+    ob(w)
+    torch.cuda.synchronize()
     assert np.array_equal(N(ob.max_val), g[name + "_max"]) and np.array_equal(N(ob.min_val), g[name + "_min"])
     assert int(ob.last_nfev.sum().item()) == ref_nfev
     s_a, z_a = ob.calculate_qparams(ob.min_val, ob.max_val)

@@ -209,13 +209,19 @@ from _msefast_rows import MSEFAST_ROW_BOUNDS, msefast_row_weights, msefast_row_d
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_vs_reference(golden, name):
     """BERT-base row lengths, per-channel symmetric MSEFast (observer.py:496-517): the first 192 rows of the
-    reference-generated fixture through the exact-sum oracle."""
+    reference-generated fixture through the oracle with ORDER-FREE sums (ROW_SUM_VEC = None): how far exactly rounded
+    losses take the ranges from the reference's -- the default sums rows in the reference's order and is bit-equal
+    (next test)."""
     g = golden("msefast_rows")
     seed, rows, cols, bit, _ = (int(v) for v in g[name + "_info"])
     n = 192
     w = msefast_row_weights(seed, rows, cols)[:n]
     st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
-    OB.observe_msefast(st, w)
+    vec, OB.ROW_SUM_VEC = OB.ROW_SUM_VEC, None
+    try:
+        OB.observe_msefast(st, w)
+    finally:
+        OB.ROW_SUM_VEC = vec
     assert np.array_equal(st.min_val, -st.max_val)
     rel, xq_mismatch, _ = msefast_row_deviation(w, st.min_val, st.max_val, g[name + "_min"][:n], g[name + "_max"][:n],
                                                 st.quant_min, st.quant_max)
@@ -227,20 +233,15 @@ def test_msefast_rows_vs_reference(golden, name):
 
 @pytest.mark.parametrize("name", ["w768", "w3072", "w768_6bit"])
 def test_msefast_rows_equal_reference_in_its_summation_order(golden, name):
-    """The same rows with the loss summed the way the fixture machine's torch summed it (oracle/aten_sum.py, a numpy
-    restatement -- no torch in the loop): every range equals the reference's BIT FOR BIT.  The summation order is the
-    whole difference between the exact-sum searches above and the reference."""
-    from oracle.aten_sum import aten_mean_f32
+    """The same rows through the oracle as it is: rows are summed the way torch's CPU kernel sums them (oracle/aten_sum.py,
+    a numpy restatement -- no torch in the loop; observer_oracle.ROW_SUM_VEC = 8): every range equals the reference's BIT
+    FOR BIT.  The summation order is the whole difference between the order-free searches above and the reference."""
     g = golden("msefast_rows")
     seed, rows, cols, bit, _ = (int(v) for v in g[name + "_info"])
     n = 128
     w = msefast_row_weights(seed, rows, cols)[:n]
     st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
-    OB.MEAN_LIKE_TORCH = lambda sq: aten_mean_f32(sq, 8)
-    try:
-        OB.observe_msefast(st, w)
-    finally:
-        OB.MEAN_LIKE_TORCH = None
+    OB.observe_msefast(st, w)
     assert st.max_val.dtype == g[name + "_max"].dtype
     assert np.array_equal(st.max_val, g[name + "_max"][:n]) and np.array_equal(st.min_val, g[name + "_min"][:n])
 

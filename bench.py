@@ -166,14 +166,23 @@ def kernel_table(dev, xs, lengths, reps=20):
         return sum(out) / len(out)
 
     rows = {}
+    # What this clock reads for a launch that moves (almost) nothing: a 4 KiB fake-quant.  The site-size rows below sit on
+    # this floor (a [32,128,768] site is 6.6-25 MB: 1-4 us of HBM time): their bandwidth fractions say "too small a tensor for
+    # one launch", `us_above_floor` says how much of the launch is the kernel's own
+    tiny = torch.randn(1024, device=dev)
+    with torch.no_grad():
+        floor_us = timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(tiny, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
+    rows["launch floor (fake-quant of 4 KiB)"] = {"avg_us": round(floor_us, 2),
+                                                  "bound": "launch: dispatch + one HBM round trip + completion, as the dispatch events see it"}
 
     def add(name, us, nbytes):
         if "token_select" in name:     # two workgroups per problem on one CU each: exact order statistics, not a stream
             rows[name] = {"avg_us": round(us, 2), "bound": "one CU per side: VALU issue + LDS atomic rate (not HBM)",
-                          "token_slots_MB": round(nbytes / 1e6, 2)}
+                          "token_slots_MB": round(nbytes / 1e6, 2), "us_above_floor": round(us - floor_us, 2)}
             return
         rows[name] = {"avg_us": round(us, 2), "bound": "hbm", "algorithmic_MB": round(nbytes / 1e6, 1),
-                      "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3)}
+                      "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3),
+                      "us_above_floor": round(us - floor_us, 2)}
 
     with torch.no_grad():
         add("fake_quant_forward", timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(

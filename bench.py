@@ -541,10 +541,13 @@ def calibration_extra(dev, rank, world, which):
             b["token_type_ids"] = torch.zeros_like(b["input_ids"])
         task, mtype, grid = "squad", "bert", {"iters": 90, "step": 0.0033}
         out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
-    elif which == 4:
-        cfg = T.BartConfig(d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12, decoder_attention_heads=12,
-                           encoder_ffn_dim=3072, decoder_ffn_dim=3072, max_position_embeddings=1024, dropout=0.0,
-                           attention_dropout=0.0, activation_dropout=0.0)
+    elif which in (4, 5):
+        # 4: bart-base dimensions, what the reference's shipped config points at (exp/xsum/twc_fine_gamma/config.yaml:44);
+        # 5 (opt-in, --calib-configs ...,5): bart-large dimensions, what BASELINE.json's configs[4] names
+        d_model, layers, heads, ffn = (768, 6, 12, 3072) if which == 4 else (1024, 12, 16, 4096)
+        cfg = T.BartConfig(d_model=d_model, encoder_layers=layers, decoder_layers=layers, encoder_attention_heads=heads,
+                           decoder_attention_heads=heads, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, max_position_embeddings=1024,
+                           dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
         fp = T.BartForConditionalGeneration(cfg).eval().to(dev)
         batches = masked_batches(64, 4, 1024, 50265, 256)
         for b in batches:
@@ -554,8 +557,10 @@ def calibration_extra(dev, rank, world, which):
             b["decoder_input_ids"] = (torch.randint(1000, 49000, (4, 62), generator=g) * dm + (1 - dm)).to(dev)
             b["decoder_attention_mask"] = dm.to(dev)
         task, mtype, grid = "summ", "bart", {"iters": 30, "step": 0.01}
-        out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, bart-base dimensions (the reference's shipped "
-                         "config), 256 samples (64 x ([4,1024] source, [4,62] target)), 30 candidates, learn-scale 3 epochs")
+        out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, " +
+                         ("bart-base dimensions (the reference's shipped config)" if which == 4 else
+                          "bart-LARGE dimensions (d 1024, 16 heads, 12 + 12 layers, ffn 4096: what BASELINE.json names)") +
+                         ", 256 samples (64 x ([4,1024] source, [4,62] target)), 30 candidates, learn-scale 3 epochs")
     else:
         cfg = T.RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, num_labels=3,
                               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
@@ -804,7 +809,7 @@ def main():
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel timing table")
     ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
-    ap.add_argument("--calib-configs", default="0,1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured")
+    ap.add_argument("--calib-configs", default="0,1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured (5 = configs[4] at bart-large dimensions, opt-in: ~1.5 min)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -1085,13 +1090,13 @@ def main():
                 out["calibration_config0"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if 1 in wanted:
             out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
-        for which in (2, 3, 4):
+        for which in (2, 3, 4, 5):
             if which not in wanted:
                 continue
             try:          # a failure here must not cost the headline line
-                out[f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
+                out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
             except Exception as e:
-                out[f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         if rank == 0:
             try:

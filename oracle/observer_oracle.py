@@ -270,7 +270,8 @@ def observe_avg_prune_minmax(st, x, lengths=None, seq_pos=-1):
 # ---------------------------------------------------------------------------
 
 # How the squared errors are averaged.  The reference's ``.pow(2).mean()`` is torch's sum, whose order depends on the
-# build's vector width (ATen cascade_sum) -- not part of the algorithm.  Default: exact (float64) sum, rounded to the
+# build's vector width (ATen cascade_sum) -- not part of the algorithm.  Default FOR PER-TENSOR searches (rows: ROW_SUM_VEC
+# below): exact (float64) sum, rounded to the
 # tensor's dtype once; the device kernels do the same, so kernel and oracle agree bit for bit.  Tests that compare with
 # the reference RUN ON THE SAME MACHINE set ``MEAN_LIKE_TORCH = lambda sq: torch.from_numpy(sq).mean().numpy()`` to show
 # that the summation order is the only difference (tests/test_oracle_vs_reference_live.py).

@@ -283,17 +283,19 @@ __device__ __forceinline__ double sq_err4(const float4& a, float s, float z, flo
            (static_cast<double>(sq_err(a.z, s, z, qmin, qmax)) + static_cast<double>(sq_err(a.w, s, z, qmin, qmax)));
 }
 
-// ---------------------------------------------------------------- the reference machine's summation order (test mode)
+// ---------------------------------------------------------------- the reference machine's summation order
 //
 // The reference's loss is torch's CPU `mean` of n fp32 squared errors: sum_out(...).div_(n), and the sum adds in the
 // order of ATen's cascade_sum / vectorized_inner_sum (aten/src/ATen/native/cpu/SumKernel.cpp; restated and pinned in
 // oracle/aten_sum.py): W = 8 SIMD lanes (the sum kernel is dispatched at AVX2 width also on AVX-512 machines), lane l
 // owning elements l, l + 8, ...; per lane four interleaved accumulators, each a 4-level cascade; then the n % 8
-// trailing scalars and the 8 lanes, in order, onto a scalar.  osq_set_tuning("mse_sum_order", 8) makes the per-row
-// kernel add in exactly that order (fp32 additions, lanes 0..7 of the wave playing the SIMD lanes, squared errors staged
-// in LDS): the searches are then the reference's own, iterate for iterate, and the ranges equal the reference-generated
-// fixtures BIT FOR BIT (tests/test_gpu_parity.py::test_msefast_rows_equal_reference_in_its_summation_order).  The default
-// stays the exact (float64) sum: it is the correctly rounded loss, and it does not depend on a vector width.
+// trailing scalars and the 8 lanes, in order, onto a scalar.  For a per-channel ROW (< 32768 elements: below ATen's
+// parallel grain) that order is what every x86 host computes, so the per-row kernel adds in exactly that order BY DEFAULT
+// (osq_set_tuning("mse_rows_order", 8); fp32 additions, lanes 0..7 of the wave playing the SIMD lanes, squared errors
+// staged in LDS): the searches are the reference's own, iterate for iterate, and the ranges equal the reference-generated
+// fixtures BIT FOR BIT (tests/test_gpu_parity.py::test_msefast_rows_equal_reference_in_its_summation_order).  Per-TENSOR
+// searches keep the order-free sum -- the correctly rounded loss: beyond 32768 elements torch's order depends on the host's
+// thread count -- and take the reference's order only in the test mode osq_set_tuning("mse_sum_order", 8).
 // (ceil_log2_i, aten_lane_partial, aten_sum_wave, aten_mean_wave: osq_device.h -- the LSQ backward has the same test mode)
 
 // ---------------------------------------------------------------- per-channel: one wave per row

@@ -90,9 +90,11 @@ size_t      osq_workspace_bytes(void);
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
  *   threshold pass; "select_hint" 0 = the selectors of the one-launch observe + fake-quant step do not pre-histogram a window around the
- *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "bwd_sum_order" 8 = test mode of the per-tensor LSQ / LSQ+ backward: the gradient sums in
- *   autograd's decomposition and ATen's CPU order, fp32 (<= 32768 elements); "mse_sum_order" 8 | 16 | 64 = test modes of the MSEFast loss: per-row sums in ATen's CPU order for 8- / 16-lane SIMD
- *   (oracle/aten_sum.py), or per-tensor sums as double-doubles, i.e. order-independent (64; one launch per evaluation); 0 = off;
+ *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "bwd_sum_order" 8 | 16 = the per-tensor LSQ / LSQ+ backward
+ *   adds the parameter gradients in autograd's decomposition and ATen's one-thread CPU order, fp32, any length (osq_lsq_backward_per_tensor_ordered);
+ *   "mse_sum_order" 8 | 16 = the MSEFast losses (rows and per-tensor searches of any length, osq_msefast_tensor_evals_ordered) are added in ATen's one-thread CPU
+ *   order for 8- / 16-lane SIMD (oracle/aten_sum.py) -- these two are the STRICT switch of the package: results equal to the reference run on a one-thread host bit for
+ *   bit, at the price of one launch per loss evaluation; "mse_sum_order" 64 = per-tensor sums as double-doubles, i.e. order-independent (test mode; one launch per evaluation); 0 = off;
  *   "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
  *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
  *   "fused_spin_limit" / "mse_spin_limit" n: bound of the cross-workgroup waits of the two persistent launch families
@@ -172,6 +174,17 @@ int osq_lsq_backward_per_tensor(const float* x, const float* grad_out, float* gr
                                 int mode, float grad_factor, int quant_min, int quant_max,
                                 float* grad_scale, float* grad_zero_point,
                                 void* workspace, osq_stream stream);
+
+/* The same backward with "bwd_sum_order" 8 / 16 set: grad_scale / grad_zero_point are the FOUR fp32 reductions autograd
+ * forms on the reference's CPU (mul + div backward, add + sub backward; util_quant.py:48-55,70-71), each added in the order
+ * of torch.sum on a one-thread host (csrc/aten_order.h), for any n.  scratch: osq_ordered_sum_scratch_bytes(n, 4) bytes of
+ * device memory, contents irrelevant.  x, grad_out, grad_x: contiguous, no alignment requirement. */
+size_t osq_ordered_sum_scratch_bytes(int64_t n, int n_sums);
+int osq_lsq_backward_per_tensor_ordered(const float* x, const float* grad_out, float* grad_x, int64_t n,
+                                        const float* scale, const void* zero_point, int zp_type,
+                                        int mode, float grad_factor, int quant_min, int quant_max,
+                                        float* grad_scale, float* grad_zero_point,
+                                        void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream);
 
 /* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner]. */
 int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,
@@ -402,6 +415,16 @@ int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_t n, int n_
 int osq_msefast_tensor_evals_tokens(void* state, const float* x, const osq_token_view* view,
                                     const int64_t* lengths, int n_evals,
                                     void* workspace, osq_stream stream);
+/* Loss evaluations in the REFERENCE's summation order ("mse_sum_order" 8 / 16; observer.py:420-432 on a one-thread host):
+ * x_flat holds the observed elements in the order remove_padding / flatten lays them out (observer.py:72-84) -- the tensor
+ * itself when it is dense and unmasked, otherwise the copy osq_gather_valid_tokens makes (out: batch * tokens * features
+ * floats; count_out: device int64 that receives the number of elements kept).  n: elements (an upper bound when n_device,
+ * nullable, points at the device-side count).  scratch: osq_ordered_sum_scratch_bytes(n, 1) bytes.  One launch per
+ * evaluation; _evals_flat / _evals_tokens refuse to run while the order is set. */
+int osq_gather_valid_tokens(const float* x, const osq_token_view* view, const int64_t* lengths, float* out,
+                            int64_t* count_out, osq_stream stream);
+int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat, int64_t n, const int64_t* n_device, int n_evals,
+                                     void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream);
 /* The whole per-tensor search in ONE persistent launch (between _begin and _commit; replaces the _evals_* / _done loop):
  * the valid part of the tensor is loaded once into the registers of a one-workgroup-per-CU grid, every loss
  * evaluation is one exchange of per-workgroup partial sums through the workspace.  view == NULL: x is flat, n

@@ -100,6 +100,62 @@ def aten_sum(x, vec, dtype, serial_only=True):
     return final
 
 
+def aten_sum_flat(x, vec, dtype):
+    """``aten_sum(x, vec, dtype, serial_only=False)`` for ONE flat vector of any length, with the cascade's levels walked
+    block-wise: every level-0 block (2^p rows), level-1 chunk (2^p blocks) and level-2 unit (2^p chunks) is an independent
+    left-to-right sum that starts from zero, so all blocks of a level are added side by side (numpy over the block axis)
+    -- the additions and their order are those of ``_multi_row_sum``, which walks the rows one by one (pinned against it
+    and against torch.sum on one thread up to 40 M elements, tests/test_oracle_pinning.py).  This is what makes the
+    reference's order affordable at the per-tensor sites of configs[3] ([32,128,768] ... [32,128,3072], millions of
+    elements per loss evaluation); the device kernels (csrc/aten_order.h) decompose the sum the same way."""
+    x = np.ascontiguousarray(x, dtype=dtype).ravel()
+    n = x.size
+    if n < vec:
+        return _scalar_inner_sum(x, dtype)
+    n_vec = n // vec
+    nc = 4 * vec                                  # 4 interleaved accumulators x vec lanes = independent columns
+    size = n_vec // 4                             # rows every column's cascade sees
+    power = max(4, _ceil_log2(size) // 4)
+    step = 1 << power
+    rows = x[:size * nc].reshape(size, nc)
+
+    def seq(a):                                   # [groups, len, nc] -> [groups, nc]: 0 + a[:, 0] + a[:, 1] + ... in order
+        acc = np.zeros((a.shape[0], a.shape[2]), dtype=dtype)
+        for j in range(a.shape[1]):
+            acc = acc + a[:, j]
+        return acc
+
+    def chain(a):                                 # [len, nc] -> [nc]
+        return seq(a[None])[0]
+
+    blocks = size // step
+    lv0 = seq(rows[:blocks * step].reshape(blocks, step, nc))
+    chunks = blocks // step
+    lv1 = seq(lv0[:chunks * step].reshape(chunks, step, nc))
+    units = chunks // step
+    lv2 = seq(lv1[:units * step].reshape(units, step, nc))
+    acc3 = chain(lv2)
+    acc2 = chain(lv1[units * step:])              # what the levels still hold when the rows run out
+    acc1 = chain(lv0[chunks * step:])
+    acc0 = chain(rows[blocks * step:])
+    col = (((acc0 + acc1) + acc2) + acc3).reshape(4, vec)
+    for v in range(size * 4, n_vec):              # left-over vectors join accumulator 0
+        col[0] = col[0] + x[v * vec:(v + 1) * vec]
+    lanes = ((col[0] + col[1]) + col[2]) + col[3]
+    final = dtype(0)
+    for k in range(n_vec * vec, n):
+        final = dtype(final + x[k])
+    for lane in range(vec):
+        final = dtype(final + lanes[lane])
+    return final
+
+
+def aten_mean_flat(x, vec, dtype):
+    """torch.mean of a flat tensor of any length on one thread: sum_out(...).div_(n) in ``dtype``."""
+    x = np.asarray(x)
+    return dtype(aten_sum_flat(x, vec, dtype) / dtype(x.size))
+
+
 def aten_sum_f32(x, vec=16):
     """fp32 rows shorter than 32768 elements (the per-channel searches)."""
     return aten_sum(x, vec, np.float32)

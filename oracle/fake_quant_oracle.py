@@ -150,7 +150,7 @@ def lsqplus_backward_per_tensor_reference_order(x, grad_out, scale, zero_point, 
     torch's fp32 ``sum`` in ATen's order (oracle/aten_sum.py), then grad_scale's factor (util_quant.py:70-71) as an fp32
     multiplication.  Equal to the reference's own run (tests/golden/lsqplus.npz) bit for bit.
     Returns (dx [fp32], dscale [fp32 scalar], dzero_point [fp32 scalar])."""
-    from .aten_sum import aten_sum
+    from .aten_sum import aten_sum_flat
     x = _f32(x)
     gy = _f32(grad_out)
     s, z = lsqplus_effective_params(scale, zero_point, grad_factor)
@@ -166,7 +166,7 @@ def lsqplus_backward_per_tensor_reference_order(x, grad_out, scale, zero_point, 
         dx = g_in / s
         ds_mul = gy * (xq - z)
         ds_div = -g_in * ((x / s) / s)
-    total = lambda a: aten_sum(np.ascontiguousarray(a, dtype=F32).reshape(-1), vec, np.float32, serial_only=False)   # noqa: E731
+    total = lambda a: aten_sum_flat(a, vec, np.float32)   # noqa: E731  (any length: the one-thread order)
     g = F32(grad_factor)
     dscale = F32(F32(total(ds_mul) + total(ds_div)) * g)
     dzp = F32(F32(total(g_in) + total(-g_mul)) * g)

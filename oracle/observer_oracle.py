@@ -283,14 +283,37 @@ MEAN_LIKE_TORCH = None
 ROW_SUM_VEC = 8
 
 
+def exact_sum(a):
+    """Correctly rounded float64 sum of non-negative values, independent of any order.  Up to 200 000 elements:
+    math.fsum (exact by construction).  Beyond (the per-tensor sites of configs[3]: millions of squared errors per loss
+    evaluation, hundreds of evaluations per search): a pairwise tree of error-free two-sums in NumPy -- every addition's
+    rounding error is kept in a second word, so the pair (hi, lo) carries the sum to ~2^-100 relative; for non-negative
+    terms (no cancellation) hi + lo rounds to the same double as the exact sum unless that sum lies within ~2^-100 of a
+    rounding boundary.  Pinned against math.fsum in tests/test_oracle_pinning.py::test_exact_sum."""
+    import math
+    a = np.asarray(a, dtype=np.float64).ravel()
+    if a.size <= 200000:
+        return np.float64(math.fsum(a.tolist()))
+    hi, lo = a, np.zeros_like(a)
+    while hi.size > 1:
+        if hi.size & 1:
+            hi, lo = np.append(hi, 0.0), np.append(lo, 0.0)
+        x, y = hi[0::2], hi[1::2]
+        s = x + y
+        bb = s - x
+        err = (x - (s - bb)) + (y - bb)                 # two-sum: x + y = s + err exactly
+        lo = (lo[0::2] + lo[1::2]) + err
+        hi = s
+    return np.float64(hi[0] + lo[0])
+
+
 def exact_mean(sq):
-    """Mean with an exactly rounded sum (math.fsum): the order-independent mean.  ``MEAN_LIKE_TORCH = exact_mean`` is the
+    """Mean with an exactly rounded sum: the order-independent mean.  ``MEAN_LIKE_TORCH = exact_mean`` is the
     counterpart of the kernels' double-double test mode (osq_set_tuning("mse_sum_order", 64)): with both, kernel and
     oracle agree bit for bit also in float64 arithmetic (a per-tensor observer's second call on), where a plain sum
     carries its order in its last bits (tests/test_gpu_parity.py::test_msefast_float64_equals_oracle_with_exact_sums)."""
-    import math
     a = np.asarray(sq, dtype=np.float64).ravel()
-    return np.float64(math.fsum(a.tolist())) / np.float64(a.size)
+    return exact_sum(a) / np.float64(a.size)
 
 
 def mse_loss(x, new_min, new_max, quant_min, quant_max, symmetric):

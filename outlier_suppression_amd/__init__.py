@@ -7,3 +7,45 @@ every scale-clip-round-dequant pass is a hand-written gfx950 HIP kernel reached
 through the C ABI in ``include/osq_hip.h``.  There is no CPU path.
 """
 __version__ = "0.1.0"
+
+
+def set_strict(on=True, simd_width=8):
+    """STRICT switch: sums in the REFERENCE's own order.
+
+    Two numbers of the path are sums over a whole activation: the loss of a per-tensor MSEFast search
+    (`.pow(2).mean()`, quantization/observer.py:420-432) and the LSQ / LSQ+ parameter gradients (autograd's `sum_to_size`,
+    quantization/util_quant.py:29-67).  The reference adds them with torch.sum on the CPU, whose order (ATen's
+    cascade_sum) depends on the host's SIMD width and -- beyond 32768 elements -- on its thread count.  By default this
+    package returns the correctly rounded sum instead (float64 / exact accumulation, rounded once: order-free, same
+    bits on every machine), which can differ from ONE particular reference run in the last bits of the sum -- and, for
+    MSEFast, in which of two tied candidates of its staircase loss the search keeps.
+
+    ``set_strict(True)`` makes both sums follow torch's order on a ONE-thread host with ``simd_width`` fp32 lanes per
+    vector (8: x86 torch, AVX2 and AVX-512 builds alike; float64 sums use half as many), at any length: min_val /
+    max_val / scale / zero_point of every MSEFast observer and scale.grad / zero_point.grad of every learnable quantizer
+    then equal that reference run bit for bit (tests/test_gpu_strict_order.py, fixtures made by running the reference at
+    BERT-base site sizes).  Price: per-tensor MSEFast searches take one launch per loss evaluation instead of one
+    persistent launch per search (BASELINE configs[3]'s activation pass: see DESIGN.md), the LSQ+ backward runs at
+    ~60 % of its default rate.  Per-channel (row) searches follow the reference's order in either mode.
+    Also settable from the environment: OSQ_STRICT=1."""
+    from . import ops
+    if simd_width not in (8, 16):
+        raise ValueError("simd_width must be 8 or 16")
+    ops.set_tuning("mse_sum_order", simd_width if on else 0)
+    ops.set_tuning("bwd_sum_order", simd_width if on else 0)
+
+
+def set_fast(on=True):
+    """Opt into the fusions that are NOT bit-comparable with the eager sequence (today: the one-launch LayerNorm site,
+    util_layernorm.FUSE_LAYERNORM -- see there for the bound)."""
+    from . import util_layernorm
+    util_layernorm.FUSE_LAYERNORM = bool(on)
+
+
+def _apply_environment():
+    """OSQ_STRICT=1 / OSQ_FAST=1: the two switches above from the environment, applied when the library is first loaded."""
+    import os
+    if os.environ.get("OSQ_STRICT", "0") not in ("", "0"):
+        set_strict(True, int(os.environ.get("OSQ_STRICT_SIMD", "8")))
+    if os.environ.get("OSQ_FAST", "0") not in ("", "0"):
+        set_fast(True)

@@ -66,6 +66,8 @@ SIGNATURES = {
     "osq_fake_quant_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_weights_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_lsq_backward_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P]),
+    "osq_ordered_sum_scratch_bytes": (ctypes.c_size_t, [_L, _I]),
+    "osq_lsq_backward_per_tensor_ordered": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, ctypes.c_size_t, _P, _P]),
     "osq_lsq_backward_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "osq_lsq_sanitize": (_I, [_P, _P, _L, _F, _I, _I, _P]),
     "osq_calculate_qparams": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P]),
@@ -88,6 +90,8 @@ SIGNATURES = {
     "osq_msefast_tensor_begin": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "osq_msefast_tensor_evals_flat": (_I, [_P, _P, _L, _I, _P, _P]),
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
+    "osq_gather_valid_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
+    "osq_msefast_tensor_evals_ordered": (_I, [_P, _P, _L, _P, _I, _P, ctypes.c_size_t, _P, _P]),
     "osq_msefast_tensor_search": (_I, [_P, _P, _L, ctypes.POINTER(TokenView), _P, _P, _P]),
     "osq_msefast_resident_slots": (_I, [_L]),
     "osq_msefast_resident_limits": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
@@ -133,6 +137,8 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+    from . import _apply_environment
+    _apply_environment()      # OSQ_STRICT / OSQ_FAST
     return _lib
 
 

@@ -187,9 +187,9 @@ def calibrate_sharded(model, batches, forward, n_batches=None, group=None, selec
             forward(model, batch)
     finally:
         cap.disarm()
+    check_persistent_collectively("calibrate_sharded", group, cap.table.device)     # before the gather: no rank enters it alone
     ordered = gather_batch_table(cap.table, n_batches, group)
     replay(ordered, qs)
-    ops.check_persistent("calibrate_sharded")
     return ordered
 
 
@@ -228,27 +228,58 @@ def _site_cost(name, q, numel, channels):
 
 
 def probe_sites(model, batch, forward, quantizers):
-    """One forward with every selected observer off: (numel, channels) of the tensor each quantizer is called with
-    (0, 1 for quantizers the forward does not reach).  Weight quantizers are called with their operator's weight."""
+    """One forward with EVERY quantizer of the model switched off -- observers and fake-quant of the selected sites and of
+    all others (a weight observer left enabled would otherwise see batch 0 twice, and the one-process pass, which never
+    probes, would no longer be what the ranks reproduce) -- returning (numel, channels) of the tensor each selected
+    quantizer is called with (0, 1 for quantizers the forward does not reach).  Weight quantizers are called with their
+    operator's weight.  Every flag is restored afterwards."""
+    from .quantization.fake_quant import QuantizeBase
     seen = {}
-    handles, saved = [], []
+    handles = []
     for i, (_, q) in enumerate(quantizers):
         def hook(mod, args, kwargs, i=i):
             x = args[0] if args else kwargs.get("X")
             if x is not None and i not in seen:
                 seen[i] = (x.numel(), 1 if mod.ch_axis == -1 else x.shape[mod.ch_axis])
         handles.append(q.register_forward_pre_hook(hook, with_kwargs=True))
-        saved.append((q.observer_enabled, q.fake_quant_enabled))
-        q.observer_enabled, q.fake_quant_enabled = 0, 0
+    every = [m for m in model.modules() if isinstance(m, QuantizeBase)]
+    every += [q for _, q in quantizers if not any(q is m for m in every)]
+    saved = [(m.observer_enabled, m.fake_quant_enabled) for m in every]
+    for m in every:
+        m.observer_enabled, m.fake_quant_enabled = 0, 0
     try:
         with torch.no_grad():
             forward(model, batch)
     finally:
         for h in handles:
             h.remove()
-        for (_, q), (o, f) in zip(quantizers, saved):
-            q.observer_enabled, q.fake_quant_enabled = o, f
+        for m, (o, f) in zip(every, saved):
+            m.observer_enabled, m.fake_quant_enabled = o, f
     return [seen.get(i, (0, 1)) for i in range(len(quantizers))]
+
+
+def check_persistent_collectively(where, group=None, device=None):
+    """ops.check_persistent for code that is about to enter (or has just left) a collective: a time-out of a persistent
+    launch on ONE rank must not leave the others waiting in the gather, or carrying on with that rank's NaN-poisoned
+    rows.  Every rank catches its own time-out, the group agrees on MAX(failed), and every rank raises."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    failure = None
+    try:
+        ops.check_persistent(where)
+    except ops.PersistentLaunchTimeout as exc:
+        if world == 1:
+            raise
+        failure = exc
+    if world == 1:
+        return
+    on_host = device is None or dist.get_backend(group) == "gloo"      # gloo (CPU tests, ranks sharing a GPU): a host flag
+    flag = torch.tensor([1.0 if failure is not None else 0.0], dtype=torch.float32, device="cpu" if on_host else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if failure is not None:
+        raise failure
+    if flag.item() != 0.0:
+        raise ops.PersistentLaunchTimeout(f"outlier_suppression_amd ({where}): a persistent launch timed out on another rank of "
+                                          "the group; this rank's copy of the exchanged statistics is invalid as well.")
 
 
 def deal_sites(costs, world):
@@ -380,7 +411,7 @@ def calibrate_owned_sites(model, batches, forward, group=None, select=lambda nam
     finally:
         for _, q in qs:
             q.observer_enabled = 1
-    ops.check_persistent("calibrate_owned_sites")
+    check_persistent_collectively("calibrate_owned_sites", group, dev)
     if world == 1:
         return {"owner": owner, "collective_s": 0.0}
     collective_s = exchange_site_states(qs, [ch for _, ch in geo], owner, rank, world, dev, group)

@@ -1,0 +1,234 @@
+// torch's CPU `sum` of a contiguous vector in ITS order, for vectors of any length, on the whole chip.
+//
+// Reference: the loss of MSEFast is `(pred - tgt).abs().pow(2).mean()` (quantization/observer.py:420-432) and the LSQ / LSQ+
+// parameter gradients are `sum_to_size` reductions of autograd (quantization/util_quant.py:29-67); both are torch.sum of
+// a contiguous CPU tensor = ATen's cascade_sum / vectorized_inner_sum (aten/src/ATen/native/cpu/SumKernel.cpp; restated
+// and pinned against torch.sum in oracle/aten_sum.py).  With torch on ONE thread that order is defined for every length:
+//
+//   * the vector is read as n / W SIMD vectors of W lanes; vector i belongs to interleaved accumulator i % 4 -- so the
+//     first size * 4W elements (size = n / W / 4) form `size` ROWS of NC = 4W independent COLUMNS, element (row, col) at
+//     row * NC + col;
+//   * every column is added by a four-level cascade with step S = 2^P, P = max(4, ceil_log2(size) / 4): level 0 adds S
+//     consecutive rows, is added to level 1 and cleared; level 1 is added to level 2 after S level-0 flushes (S^2 rows),
+//     level 2 to level 3 after S^3 rows; when the rows run out the levels are added to level 0 in order 1, 2, 3;
+//   * the n / W % 4 left-over vectors are added to accumulator 0, accumulators 1, 2, 3 to accumulator 0 in that order,
+//     then the n % W trailing scalars one by one to a scalar that starts at 0, then the W lanes in order.
+//
+// A level-0 BLOCK (S rows), a level-1 CHUNK (S blocks) and a level-2 UNIT (S chunks) are left-to-right sums that start
+// from zero and depend on nothing else: that is the parallelism.  Stage 1 (`cascade_units`, every workgroup): a
+// workgroup takes chunks; thread (block, column) adds its S rows in order, the block sums meet in LDS, thread (column)
+// adds the S block sums in order and publishes the chunk's NC column sums.  Stage 2 (`cascade_finish`, the workgroup that
+// arrives last): thread (unit, column) adds S chunk sums in order, thread (column) adds the unit sums in order (level 3),
+// then the open levels, and one thread folds the columns, left-overs, tail and lanes.  Same additions, same order, as the
+// one-thread CPU kernel -- for any n; the elements are produced on the fly by `term(e, out[NS])` (NS sums share a pass:
+// the LSQ+ backward has four), called exactly once per element over both stages.
+//
+// Scratch (caller's): NS * (chunks + 2) * NC values of T, see cascade_scratch_bytes.  P <= 5 (n < 2^25 * NC).
+#pragma once
+#include "osq_device.h"
+
+namespace osq {
+
+struct CascadeGeom {
+    int64_t n, n_vec, size, blocks, chunks;
+    int W, NC, P, S, tail_blocks, tail_rows;
+};
+
+__host__ __device__ inline int cascade_ceil_log2(int64_t x) {
+    int p = 0;
+    while ((static_cast<int64_t>(1) << p) < x) ++p;
+    return p;
+}
+
+__host__ __device__ inline CascadeGeom cascade_geom(int64_t n, int W) {
+    CascadeGeom g;
+    g.n = n;
+    g.W = W;
+    g.NC = 4 * W;
+    g.n_vec = n / W;
+    g.size = g.n_vec / 4;
+    const int p = cascade_ceil_log2(g.size) / 4;
+    g.P = p < 4 ? 4 : p;
+    g.S = 1 << g.P;
+    g.blocks = g.size >> g.P;
+    g.chunks = g.blocks >> g.P;
+    g.tail_blocks = static_cast<int>(g.blocks - (g.chunks << g.P));
+    g.tail_rows = static_cast<int>(g.size - (g.blocks << g.P));
+    return g;
+}
+
+// bytes of scratch one ordered sum of n elements (NS sums, values of elem_size bytes, W lanes) publishes
+inline size_t cascade_scratch_bytes(int64_t n, int W, int ns, size_t elem_size) {
+    const CascadeGeom g = cascade_geom(n, W);
+    return static_cast<size_t>(ns) * static_cast<size_t>(g.chunks + 2) * static_cast<size_t>(g.NC) * elem_size;
+}
+constexpr int kCascadeMaxP = 5;
+
+template <typename T> __device__ __forceinline__ void cascade_publish(T* p, T v);
+template <> __device__ __forceinline__ void cascade_publish<float>(float* p, float v) { publish_f32(p, v); }
+template <> __device__ __forceinline__ void cascade_publish<double>(double* p, double v) { publish_f64(p, v); }
+
+// sc1 loads through a buffer descriptor: agent-scope like consume_f32 / consume_f64, but plain loads to the compiler, so
+// the S loads of a chain are all in flight before the first addition (ordered atomic loads are consumed one round trip at
+// a time)
+typedef unsigned int cascade_v2u32 __attribute__((ext_vector_type(2)));
+struct CascadeReader {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ CascadeReader(const void* base, size_t bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000)) {}
+    __device__ __forceinline__ float get_f32(int64_t idx) const {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<unsigned int>(idx * 4), 0, 16));
+    }
+    __device__ __forceinline__ double get_f64(int64_t idx) const {
+        const cascade_v2u32 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, static_cast<unsigned int>(idx * 8), 0, 16);
+        return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(w.y) << 32) | w.x));
+    }
+    template <typename T> __device__ __forceinline__ T get(int64_t idx) const;
+};
+template <> __device__ __forceinline__ float CascadeReader::get<float>(int64_t idx) const { return get_f32(idx); }
+template <> __device__ __forceinline__ double CascadeReader::get<double>(int64_t idx) const { return get_f64(idx); }
+
+// ---- stage 1: every workgroup; `lds` holds NS * S * NC values of T
+template <typename T, int NS, int THREADS, typename Term>
+__device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restrict__ part, T* lds, Term term) {
+    const int64_t units = g.chunks + 1;                     // the last one is what the levels still hold at the end
+    const int64_t sstride = (g.chunks + 2) * g.NC;          // part[s][m][c]; m == chunks: open level 1, chunks + 1: open level 0
+    const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
+    for (int64_t m = blockIdx.x; m < units; m += gridDim.x) {
+        const bool full = m < g.chunks;
+        const int nblk = full ? g.S : g.tail_blocks;
+        const int ntask = (nblk + ((!full && g.tail_rows) ? 1 : 0)) << nc_shift;
+        for (int task = threadIdx.x; task < ntask; task += THREADS) {
+            const int blk = task >> nc_shift, c = task & (g.NC - 1);
+            const bool open0 = blk >= nblk;                 // the rows behind the last full block: they stay in level 0
+            const int64_t row0 = open0 ? (g.blocks << g.P) : (((m << g.P) + blk) << g.P);
+            const int nrows = open0 ? g.tail_rows : g.S;
+            T acc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = T(0);
+            for (int r = 0; r < nrows; ++r) {
+                T t[NS];
+                term(((row0 + r) << nc_shift) + c, t);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s] = acc[s] + t[s];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (open0) cascade_publish<T>(&part[s * sstride + ((g.chunks + 1) << nc_shift) + c], acc[s]);
+                else lds[(((s << g.P) + blk) << nc_shift) + c] = acc[s];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < (NS << nc_shift); t += THREADS) {
+            const int s = t >> nc_shift, c = t & (g.NC - 1);
+            T acc = T(0);
+            for (int b = 0; b < nblk; ++b) acc = acc + lds[(((s << g.P) + b) << nc_shift) + c];
+            cascade_publish<T>(&part[s * sstride + (m << nc_shift) + c], acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- stage 2: the last workgroup; `lds` holds lds_values values of T (>= NS * NC + NC); the sums arrive in out[] of thread 0
+template <typename T, int NS, int THREADS, typename Term>
+__device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __restrict__ part, T* lds, int lds_values, Term term,
+                                               T (&out)[NS]) {
+    if (g.n < g.W) {                                        // scalar_inner_sum: four interleaved scalars, no cascade below 64 elements
+        if (threadIdx.x == 0) {
+            T acc[NS][4];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[s][k] = T(0);
+            const int size = static_cast<int>(g.n / 4);
+            for (int i = 0; i < size; ++i)
+                for (int k = 0; k < 4; ++k) {
+                    T t[NS];
+                    term(i * 4 + k, t);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) acc[s][k] = acc[s][k] + t[s];
+                }
+            for (int64_t i = static_cast<int64_t>(size) * 4; i < g.n; ++i) {
+                T t[NS];
+                term(i, t);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s][0] = acc[s][0] + t[s];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) out[s] = ((acc[s][0] + acc[s][1]) + acc[s][2]) + acc[s][3];
+        }
+        return;
+    }
+    const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
+    const int64_t sstride = (g.chunks + 2) * g.NC;
+    const int64_t units2 = g.chunks >> g.P;                 // full level-2 units
+    const CascadeReader rd(part, static_cast<size_t>(NS) * static_cast<size_t>(sstride) * sizeof(T));
+    T* const col = lds;                                     // [NS][NC]
+    T* const tile = lds + (NS << nc_shift);                 // [QT][NC]
+    const int QT = (lds_values - (NS << nc_shift)) >> nc_shift;
+    for (int s = 0; s < NS; ++s) {
+        const int64_t base = s * sstride;
+        T acc3 = T(0);
+        for (int64_t q0 = 0; q0 < units2; q0 += QT) {
+            const int nq = static_cast<int>(units2 - q0 < QT ? units2 - q0 : QT);
+            for (int task = threadIdx.x; task < (nq << nc_shift); task += THREADS) {
+                const int q = task >> nc_shift, c = task & (g.NC - 1);
+                const int64_t first = base + ((((q0 + q) << g.P)) << nc_shift) + c;
+                T a = T(0);
+                for (int j0 = 0; j0 < g.S; j0 += 16) {
+                    T v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = rd.get<T>(first + (static_cast<int64_t>(j0 + j) << nc_shift));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) a = a + v[j];
+                }
+                tile[(q << nc_shift) + c] = a;
+            }
+            __syncthreads();
+            if (static_cast<int>(threadIdx.x) < g.NC)
+                for (int q = 0; q < nq; ++q) acc3 = acc3 + tile[(q << nc_shift) + threadIdx.x];
+            __syncthreads();
+        }
+        if (static_cast<int>(threadIdx.x) < g.NC) {
+            const int c = threadIdx.x;
+            T acc2 = T(0);
+            for (int64_t m = units2 << g.P; m < g.chunks; ++m) acc2 = acc2 + rd.get<T>(base + (m << nc_shift) + c);
+            const T acc1 = rd.get<T>(base + (g.chunks << nc_shift) + c);
+            T acc0 = g.tail_rows ? rd.get<T>(base + ((g.chunks + 1) << nc_shift) + c) : T(0);
+            acc0 = acc0 + acc1;
+            acc0 = acc0 + acc2;
+            acc0 = acc0 + acc3;
+            col[(s << nc_shift) + c] = acc0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int64_t v = g.size * 4; v < g.n_vec; ++v)      // left-over vectors join accumulator 0
+            for (int l = 0; l < g.W; ++l) {
+                T t[NS];
+                term(v * g.W + l, t);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) col[(s << nc_shift) + l] = col[(s << nc_shift) + l] + t[s];
+            }
+        T fin[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fin[s] = T(0);
+        for (int64_t k = g.n_vec * g.W; k < g.n; ++k) {     // trailing scalars
+            T t[NS];
+            term(k, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) fin[s] = fin[s] + t[s];
+        }
+        for (int l = 0; l < g.W; ++l)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const T* cs = col + (s << nc_shift);
+                const T lane = ((cs[l] + cs[g.W + l]) + cs[2 * g.W + l]) + cs[3 * g.W + l];
+                fin[s] = fin[s] + lane;
+            }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) out[s] = fin[s];
+    }
+}
+
+}  // namespace osq

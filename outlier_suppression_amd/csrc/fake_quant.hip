@@ -9,6 +9,7 @@
 #include <string>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
+#include "aten_order.h"
 #include "osq_host.h"
 
 namespace osq {
@@ -19,7 +20,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // tuning knobs of the dense per-tensor kernel (osq_set_tuning): loads in flight per lane, grid cap, and
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
-static int g_bwd_sum_order = 0;      // osq_set_tuning("bwd_sum_order", 0 | 8): 8 = the LSQ / LSQ+ gradients summed in ATen's CPU order (test mode, lsq_bwd_tensor_aten_kernel)
+static int g_bwd_sum_order = 0;      // osq_set_tuning("bwd_sum_order", 0 | 8 | 16): the LSQ / LSQ+ gradients summed in ATen's one-thread CPU order on 8- / 16-lane vectors (strict switch, lsq_bwd_tensor_ordered_kernel)
 static int g_fq_max_blocks = 8192;
 static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
 static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
@@ -470,46 +471,48 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
     }
 }
 
-// Test mode osq_set_tuning("bwd_sum_order", 8): the two gradients summed the way autograd sums them on the reference's
-// CPU -- FOUR reductions, each torch's fp32 `sum` in ATen's order (osq_device.h): scale.grad = (sum(gy * (xq - z)) +
-// sum(-g_in * ((x / s) / s))) * g and zero_point.grad = (sum(g_in) + sum(-g_mul)) * g, every operation fp32 (mul backward,
-// div backward, add / sub backward reduced with sum_to_size, then grad_scale's factor; util_quant.py:48-55, 70-71).  One
-// workgroup writes the four term arrays to scratch, its first four waves add one each.  The results equal the
-// reference-generated tests/golden/lsqplus.npz BIT FOR BIT (tests/test_gpu_parity.py::test_lsqplus_gradients_equal_
-// reference_in_its_summation_order); production sums in float64.  n <= 32768.
-constexpr int kBwdAtenThreads = 1024;
-constexpr int64_t kBwdAtenMaxElems = 32768;
-__global__ __launch_bounds__(kBwdAtenThreads) void lsq_bwd_tensor_aten_kernel(
-    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx, int n,
+// osq_set_tuning("bwd_sum_order", 8) -- part of the package's strict switch: the two gradients summed the way autograd
+// sums them on the reference's CPU -- FOUR reductions, each torch's fp32 `sum` in ATen's one-thread order (aten_order.h):
+// scale.grad = (sum(gy * (xq - z)) + sum(-g_in * ((x / s) / s))) * g and zero_point.grad = (sum(g_in) + sum(-g_mul)) * g,
+// every operation fp32 (mul backward, div backward, add / sub backward reduced with sum_to_size, then grad_scale's factor;
+// util_quant.py:48-55, 70-71).  Any length: the four sums share one pass over x and gy -- every workgroup adds level-1
+// chunks of the cascade and writes grad_x on the way, the workgroup that arrives last adds the upper levels.  The results
+// equal the reference-generated tests/golden/lsqplus.npz BIT FOR BIT (tests/test_gpu_parity.py::test_lsqplus_gradients_
+// equal_reference_in_its_summation_order) and torch's own autograd run on one thread at site size; the default sums in float64.
+constexpr int kBwdOrdThreads = 512;
+constexpr int kBwdOrdLdsBytes = 32 * 1024;                    // stage 1: 4 sums x S x NC fp32 values (<= 4 x 32 x 64 x 4 B)
+__global__ __launch_bounds__(kBwdOrdThreads) void lsq_bwd_tensor_ordered_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx, int64_t n,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
-    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp, float* __restrict__ terms, int W) {
+    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp, float* __restrict__ part,
+    unsigned int* __restrict__ counters, int W) {
+    __shared__ float lds[kBwdOrdLdsBytes / 4];
     const QParams p = effective_params(scale_p[0], load_zp(zp_p, zp_type), mode, g);
     const float s = p.scale, z = p.zp;
-    for (int i = threadIdx.x; i < n; i += kBwdAtenThreads) {
+    const CascadeGeom geom = cascade_geom(n, W);
+    auto term = [=](int64_t i, float (&t)[4]) {
         float x_int;
-        const float q = quantize_value(x[i], s, z, qmin, qmax, &x_int);
+        const float xv = x[i], gv = gy[i];
+        const float q = quantize_value(xv, s, z, qmin, qmax, &x_int);
         const bool inside = (x_int >= qmin) && (x_int <= qmax);
-        const float g_mul = gy[i] * s;
+        const float g_mul = gv * s;
         const float g_in = inside ? g_mul : 0.0f;
         dx[i] = g_in / s;
-        terms[i] = gy[i] * (q - z);
-        terms[n + i] = (-g_in) * ((x[i] / s) / s);
-        terms[2 * n + i] = g_in;
-        terms[3 * n + i] = -g_mul;
-    }
-    __threadfence_block();
-    __syncthreads();
-    __shared__ float sums[4];
-    const int w = threadIdx.x / OSQ_WAVE;
-    if (w < 4) {
-        const float t = aten_sum_wave<float>(terms + static_cast<int64_t>(w) * n, n, W);
-        if ((threadIdx.x & (OSQ_WAVE - 1)) == 0) sums[w] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float ds = sums[0] + sums[1], dz = sums[2] + sums[3];
-        if (dscale) dscale[0] = (mode == OSQ_PARAM_FIXED) ? ds : ds * g;
-        if (dzp) dzp[0] = (mode == OSQ_PARAM_LSQPLUS) ? dz * g : dz;
+        t[0] = gv * (q - z);
+        t[1] = (-g_in) * ((xv / s) / s);
+        t[2] = g_in;
+        t[3] = -g_mul;
+    };
+    cascade_units<float, 4, kBwdOrdThreads>(geom, part, lds, term);
+    if (grid_last_block(counters, gridDim.x)) {
+        float sums[4];
+        cascade_finish<float, 4, kBwdOrdThreads>(geom, part, lds, kBwdOrdLdsBytes / 4, term, sums);
+        if (threadIdx.x == 0) {
+            const float ds = sums[0] + sums[1], dz = sums[2] + sums[3];
+            if (dscale) dscale[0] = (mode == OSQ_PARAM_FIXED) ? ds : ds * g;
+            if (dzp) dzp[0] = (mode == OSQ_PARAM_LSQPLUS) ? dz * g : dz;
+            grid_reset(counters, gridDim.x);
+        }
     }
 }
 
@@ -685,7 +688,10 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
     if (vec && g_fq_headsplit && (dvv & (dvv - 1)) == 0 && dvv >= 1 && dvv <= 64 &&
         x_strides[0] == sizes[2] * sizes[1] * sizes[3] && x_strides[1] == sizes[3] && x_strides[2] == sizes[1] * sizes[3] &&
         y_strides[0] == sizes[1] * sizes[2] * sizes[3] && y_strides[1] == sizes[2] * sizes[3] && y_strides[2] == sizes[3] &&
-        sizes[1] * dvv < (1ll << 31) && n / 4 + 4ll * 8192 * kThreads < (1ll << 32)) {
+        sizes[1] * dvv < (1ll << 31)) {
+        // index arithmetic of the kernel: i + u * stride in 32 bits, u < 4.  n / 4 < 2^30 (vec, above: also what makes the
+        // multiply-shift divisions exact, MagicDiv) and the grid is capped at 8192 workgroups whatever "fq_max_blocks" says:
+        // 2^30 + 4 * 8192 * 256 < 2^32
         HeadSplit hs;
         hs.row = make_magic(sizes[1] * dvv);
         hs.tokens = make_magic(sizes[2]);
@@ -695,7 +701,7 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
         hs.T = static_cast<unsigned int>(sizes[2]);
         const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_STRIDED);
         const unsigned int n4 = static_cast<unsigned int>(n / 4);
-        const int hgrid = grid_for(n / 4, kThreads * 2, g_fq_max_blocks);
+        const int hgrid = grid_for(n / 4, kThreads * 2, std::min(g_fq_max_blocks, 8192));
 #define OSQ_HEADSPLIT(NT)                                                                                                  \
         hipExtLaunchKernelGGL((fq_headsplit_kernel<2, NT>), dim3(hgrid), dim3(kThreads), 0, st, th.start, th.stop, 0,          \
                               reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), hs, n4, scale, zero_point,   \
@@ -783,12 +789,7 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     const int tail = static_cast<int>(n - n4 * 4);
     const int grid = grid_for(n4, kThreads * 2, g_bwd_blocks);
     Workspace ws(workspace);
-    if (g_bwd_sum_order) {        // test mode: the reference machine's summation order
-        OSQ_REQUIRE(n >= 16 && n <= kBwdAtenMaxElems, "lsq_backward_per_tensor: the summation-order test mode takes 16..32768 elements");
-        hipLaunchKernelGGL(lsq_bwd_tensor_aten_kernel, dim3(1), dim3(kBwdAtenThreads), 0, st, x, grad_out, grad_x, static_cast<int>(n), scale,
-                           zero_point, zp_type, mode, grad_factor, qmin, qmax, grad_scale, grad_zero_point, ws.floats(0), g_bwd_sum_order);
-        return check_launch("lsq_backward_per_tensor(aten order)");
-    }
+    OSQ_REQUIRE(!g_bwd_sum_order, "lsq_backward_per_tensor: with \"bwd_sum_order\" set the backward goes through osq_lsq_backward_per_tensor_ordered");
     const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
@@ -796,6 +797,26 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
                        grad_scale, grad_zero_point, ws.doubles(kFamLsqBackward), ws.counter(kFamLsqBackward),
                        (stream_write_through() && n4 <= kWtMaxFloat4) ? 1 : 0);
     return check_launch("lsq_backward_per_tensor");
+}
+
+extern "C" int osq_lsq_backward_per_tensor_ordered(const float* x, const float* grad_out, float* grad_x, int64_t n,
+                                                   const float* scale, const void* zero_point, int zp_type,
+                                                   int mode, float grad_factor, int quant_min, int quant_max,
+                                                   float* grad_scale, float* grad_zero_point,
+                                                   void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream) {
+    OSQ_REQUIRE(n > 0 && x && grad_out && grad_x && scale && zero_point && scratch && workspace, "lsq_backward_per_tensor_ordered: null pointer or n <= 0");
+    OSQ_REQUIRE(g_bwd_sum_order == 8 || g_bwd_sum_order == 16,
+                "lsq_backward_per_tensor_ordered: set \"bwd_sum_order\" to the reference machine's SIMD width (8 or 16) first");
+    OSQ_REQUIRE(scratch_bytes >= cascade_scratch_bytes(n, g_bwd_sum_order, 4, 4), "lsq_backward_per_tensor_ordered: scratch smaller than osq_ordered_sum_scratch_bytes(n, 4)");
+    const CascadeGeom geom = cascade_geom(n, g_bwd_sum_order);
+    OSQ_REQUIRE(geom.P <= kCascadeMaxP, "lsq_backward_per_tensor_ordered: tensor too large");
+    Workspace ws(workspace);
+    const int grid = static_cast<int>(std::min<int64_t>(geom.chunks + 1, kMaxBlocks));
+    hipLaunchKernelGGL(lsq_bwd_tensor_ordered_kernel, dim3(grid), dim3(kBwdOrdThreads), 0, static_cast<hipStream_t>(stream), x, grad_out,
+                       grad_x, n, scale, zero_point, zp_type, mode, grad_factor, static_cast<float>(quant_min),
+                       static_cast<float>(quant_max), grad_scale, grad_zero_point, static_cast<float*>(scratch),
+                       ws.counter(kFamLsqBackward), g_bwd_sum_order);
+    return check_launch("lsq_backward_per_tensor_ordered");
 }
 
 extern "C" int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,

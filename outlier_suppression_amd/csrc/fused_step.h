@@ -43,7 +43,9 @@ constexpr unsigned int kFusedSpinLimit = 1u << 21;
 struct FusedState {                       // lives in the caller's workspace; ALL-ZERO before the first launch (or after a reset)
     // Arrival flags: streaming workgroup g stores this launch's tag into flag[(g % 16) * 16 + g / 16] once its extrema
     // have left its CU (selector wave w polls the sixteen words of its own 64-byte line).  A tag is never reused, so
-    // nothing has to be reset between launches and a workgroup arriving after a time-out cannot disturb a later launch.
+    // nothing has to be reset between launches.  After a TIME-OUT that no longer holds -- a streaming workgroup that
+    // becomes resident after workgroup 2 has advanced the epoch computes the next launch's tag -- which is why every
+    // reader of a raised status (osq_fused_step_status, osq_persistent_status) wipes this block before the next launch.
     unsigned int flag[256];
     unsigned int epoch, pad0[15];             // launches completed on this workspace
     unsigned long long side[16];              // side[0], side[1]: one granule per selector (tag30 << 34 | empty << 33 | bad << 32 | value bits), adjacent: one 16-byte poll reads both
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             }
             if (fin.zp_type != OSQ_ZP_FLOAT32) z = static_cast<float>(static_cast<int32_t>(z));   // what a reader of the int32 buffer sees
         }
-        if (blockIdx.x == 2u)                              // ... and closes the launch's bookkeeping: the epoch moves on (every workgroup read it at its start)
+        if (blockIdx.x == 2u)                              // ... and closes the launch's bookkeeping: the epoch moves on (every workgroup read it at its start -- unless a time-out let one start late: see FusedState)
             __hip_atomic_store(&st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_word[2] = __float_as_uint(s);
         s_word[3] = __float_as_uint(z);

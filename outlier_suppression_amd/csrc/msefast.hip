@@ -18,9 +18,11 @@
 // fp32, summed in float64 from the first addition on, the mean rounded to fp32 once (the
 // reference's torch mean is an fp32 sum whose order depends on the machine's vector width).
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
+#include "aten_order.h"
 #include "osq_host.h"
 
 namespace osq {
@@ -604,69 +606,95 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
     block_sum_publish_finish(acc, partials, counters, ts, valid_count[0]);
 }
 
-// Test mode osq_set_tuning("mse_sum_order", 8 | 16) for the PER-TENSOR searches: one workgroup writes the squared errors of
-// one evaluation, in the order remove_padding / flatten lays the elements out (observer.py:72-84), to a scratch array --
-// fp32, or float64 from an observer's second call on (observer.py:524,549) -- and its first wave adds them the way
-// ATen's CPU kernel does (W lanes for fp32, W / 2 for float64: 256-bit vectors), divides in that type and advances the
-// search.  With torch on one thread (as the fixtures were generated) that order holds for any length; the searches are
-// then the reference's own and the ranges of every call equal tests/golden/msefast.npz BIT FOR BIT
-// (tests/test_gpu_parity.py::test_msefast_tensor_equals_reference_in_its_summation_order).  n <= 65536.
-constexpr int kAtenThreads = 1024;
-constexpr int64_t kAtenMaxElems = 65536;
-__global__ __launch_bounds__(kAtenThreads) void msefast_tensor_aten_kernel(const float* __restrict__ x, int64_t n_flat, osq_token_view v,
-                                                                          const int64_t* __restrict__ lengths, int token_mode,
-                                                                          TensorSearch* __restrict__ ts, void* __restrict__ scratch, int W) {
+// osq_set_tuning("mse_sum_order", 8 | 16) for the PER-TENSOR searches -- the strict switch of the package
+// (outlier_suppression_amd.set_strict): the squared errors of one evaluation are added the way ATen's CPU kernel adds a
+// contiguous vector on one thread (aten_order.h: W lanes for fp32, W / 2 for float64 -- 256-bit vectors), in the order
+// remove_padding / flatten lays the elements out (observer.py:72-84), the sum is divided in that type and the search
+// advances.  Any length: every workgroup adds level-1 chunks of the cascade (8192 fp32 elements), the workgroup that
+// arrives last adds the upper levels and plays scipy's step -- one launch per evaluation.  The searches are then the
+// reference's own on a one-thread host, and the ranges of every call equal tests/golden/msefast*.npz BIT FOR BIT, at
+// BERT-base site sizes included (tests/test_gpu_parity.py::test_msefast_*_equals_reference_in_its_summation_order,
+// ::test_msefast_site_size_equals_reference_in_its_summation_order).  A masked / strided site is first gathered into
+// the flat layout the reference's remove_padding builds (gather_valid_tokens_kernel: once per search, not per evaluation).
+constexpr int kOrdThreads = 512;
+constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
+__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
+                                                                            const int64_t* __restrict__ n_dev,
+                                                                            TensorSearch* __restrict__ ts, void* __restrict__ scratch,
+                                                                            unsigned int* __restrict__ counters, int W) {
     if (ts->S.done) return;
-    __shared__ unsigned int pre[kAtenThreads + 1];
+    __shared__ double lds_raw[kOrdLdsBytes / 8];
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
     const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
-    float* const sq32 = static_cast<float*>(scratch);
-    double* const sq64 = static_cast<double*>(scratch);
-    int64_t n = n_flat;
-    if (!token_mode) {
-        for (int64_t i = threadIdx.x; i < n; i += kAtenThreads) {
-            if (f64) sq64[i] = sq_err_f64(x[i], sd, z, qmin, qmax); else sq32[i] = sq_err(x[i], s, z, qmin, qmax);
+    const int64_t n = n_dev ? n_dev[0] : n_host;
+    if (f64) {
+        const CascadeGeom g = cascade_geom(n, W / 2);
+        auto term = [=](int64_t e, double (&t)[1]) { t[0] = sq_err_f64(x[e], sd, z, qmin, qmax); };
+        double* part = static_cast<double*>(scratch);
+        double* lds = lds_raw;
+        cascade_units<double, 1, kOrdThreads>(g, part, lds, term);
+        if (grid_last_block(counters, gridDim.x)) {
+            double sum[1];
+            cascade_finish<double, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 8, term, sum);
+            if (threadIdx.x == 0) {
+                ts->S.tell(sum[0] / static_cast<double>(n));
+                if (!ts->S.done)
+                    loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
+                                 &ts->scale_d);
+                grid_reset(counters, gridDim.x);
+            }
         }
     } else {
-        if (threadIdx.x == 0) {
-            unsigned int acc = 0u;
-            for (int64_t b = 0; b < v.batch; ++b) {
-                pre[b] = acc;
-                int64_t l = lengths ? lengths[b] : v.tokens;
-                l = l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
-                acc += static_cast<unsigned int>(l);
-            }
-            pre[v.batch] = acc;
-        }
-        __syncthreads();
-        const int64_t F = v.feat_outer * v.feat_inner;
-        n = static_cast<int64_t>(pre[v.batch]) * F;
-        for (int64_t tok = 0; tok < v.batch * v.tokens; ++tok) {                // uniform loop, threads stride the features
-            const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
-            if (static_cast<unsigned int>(t) >= pre[b + 1] - pre[b]) continue;
-            const float* base = x + b * v.stride_batch + t * v.stride_token;
-            const int64_t out0 = (static_cast<int64_t>(pre[b]) + t) * F;
-            for (int64_t j = threadIdx.x; j < F; j += kAtenThreads) {
-                const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
-                const float xv = base[o * v.stride_outer + i * v.stride_inner];
-                if (f64) sq64[out0 + j] = sq_err_f64(xv, sd, z, qmin, qmax); else sq32[out0 + j] = sq_err(xv, s, z, qmin, qmax);
+        const CascadeGeom g = cascade_geom(n, W);
+        auto term = [=](int64_t e, float (&t)[1]) { t[0] = sq_err(x[e], s, z, qmin, qmax); };
+        float* part = static_cast<float*>(scratch);
+        float* lds = reinterpret_cast<float*>(lds_raw);
+        cascade_units<float, 1, kOrdThreads>(g, part, lds, term);
+        if (grid_last_block(counters, gridDim.x)) {
+            float sum[1];
+            cascade_finish<float, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 4, term, sum);
+            if (threadIdx.x == 0) {
+                ts->S.tell(static_cast<double>(sum[0] / static_cast<float>(n)));
+                if (!ts->S.done)
+                    loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
+                                 &ts->scale_d);
+                grid_reset(counters, gridDim.x);
             }
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x < OSQ_WAVE) {
-        double mean;
-        if (f64) mean = aten_mean_wave<double>(sq64, static_cast<int>(n), W / 2);
-        else mean = static_cast<double>(aten_mean_wave<float>(sq32, static_cast<int>(n), W));
-        if (threadIdx.x == 0) {
-            ts->S.tell(mean);
-            if (!ts->S.done)
-                loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
-                             &ts->scale_d);
-        }
+}
+
+// remove_padding (observer.py:72-84) as a copy: out[(valid token j) * F + f] for the tokens t < lengths[b], sample by
+// sample, features in the view's (outer, inner) order; count_out[0] = elements written.  One wave per token.
+__global__ __launch_bounds__(kThreads) void gather_valid_tokens_kernel(const float* __restrict__ x, osq_token_view v,
+                                                                       const int64_t* __restrict__ lengths,
+                                                                       float* __restrict__ out, int64_t* __restrict__ count_out) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    const int64_t tok = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / OSQ_WAVE;
+    const int64_t F = v.feat_outer * v.feat_inner;
+    auto len_of = [&](int64_t b) -> int64_t {
+        int64_t l = lengths ? lengths[b] : v.tokens;
+        return l < 0 ? 0 : (l > v.tokens ? v.tokens : l);
+    };
+    if (tok == 0 && count_out) {                                // wave 0 of workgroup 0: the total
+        int64_t tot = 0;
+        for (int64_t b = lane; b < v.batch; b += OSQ_WAVE) tot += len_of(b);
+        for (int off = OSQ_WAVE / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) count_out[0] = tot * F;
+    }
+    if (tok >= v.batch * v.tokens) return;
+    const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
+    if (t >= len_of(b)) return;
+    int64_t pre = 0;                                            // valid tokens of the samples before b
+    for (int64_t k = lane; k < b; k += OSQ_WAVE) pre += len_of(k);
+    for (int off = OSQ_WAVE / 2; off > 0; off >>= 1) pre += __shfl_xor(pre, off);
+    const float* base = x + b * v.stride_batch + t * v.stride_token;
+    float* dst = out + (pre + t) * F;
+    for (int64_t j = lane; j < F; j += OSQ_WAVE) {
+        const int64_t o = j / v.feat_inner, i = j - o * v.feat_inner;
+        dst[j] = base[o * v.stride_outer + i * v.stride_inner];
     }
 }
 
@@ -1338,20 +1366,20 @@ extern "C" int osq_msefast_rows(const float* w, int64_t rows, int64_t cols, int 
     // than ATen's 32768-element grain, so torch adds it serially in an order fixed by its 256-bit vectors whatever the
     // host's thread count -- the searches are then the reference's own, iterate for iterate, and the weight ranges, hence
     // the integer weights, come out bit-equal to the reference CPU path (BASELINE north_star).  1.4-2x the time of the
-    // order-free kernel (134 495 rows of RoBERTa-base: 37 ms instead of 21).  Rows outside 8..3072 columns, and
-    // "mse_rows_order" 0, take the order-free sum.
+    // order-free kernel (134 495 rows of RoBERTa-base: 37 ms instead of 21).  Rows of 1 .. 3072 columns: registers + LDS
+    // (ATen's scalar path below one SIMD vector); 3073 .. 32767 columns: the long-row form below; rows of 32768 columns
+    // and more (beyond ATen's serial grain), and "mse_rows_order" 0, take the order-free sum.
     const bool forced = g_mse_sum_order == 8 || g_mse_sum_order == 16;
     const int order = forced ? g_mse_sum_order : g_mse_rows_order;
     if (order && cols > 64 * 48 && cols < 32768) {
         // long rows (BART-large's 4096-column fc2): one wave per workgroup, the row re-read, its squared errors in up to 128 KiB of LDS
-        static bool big_lds = false;
-        if (!big_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msefast_rows_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) != hipSuccess) {
-                (void)hipGetLastError();
-                OSQ_REQUIRE(!forced, "msefast_rows: cannot reserve the LDS of the summation-order mode for rows this long");
-            } else {
-                big_lds = true;
-            }
+        // the attribute is per DEVICE (a process may drive several): set before every such launch -- a host-side call of
+        // microseconds in front of a search of milliseconds; on failure the order-free kernel below takes the rows
+        bool big_lds = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msefast_rows_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            OSQ_REQUIRE(!forced, "msefast_rows: cannot reserve the LDS of the summation-order mode for rows this long");
+            big_lds = false;
         }
         if (big_lds) {
             hipExtLaunchKernelGGL((msefast_rows_kernel<0, true>), dim3(static_cast<unsigned int>(rows)), dim3(OSQ_WAVE), static_cast<size_t>(c) * sizeof(float), st,
@@ -1397,13 +1425,8 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     Workspace ws(workspace);
     const int64_t n4 = n / 4;
     const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
-    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {        // test mode: the reference machine's summation order
-        OSQ_REQUIRE(n >= 16 && n <= kAtenMaxElems, "msefast_tensor_evals_flat: the summation-order test mode takes 16..65536 elements");
-        for (int e = 0; e < n_evals; ++e)
-            hipLaunchKernelGGL(msefast_tensor_aten_kernel, dim3(1), dim3(kAtenThreads), 0, st, x, n, osq_token_view{}, nullptr, 0,
-                               static_cast<TensorSearch*>(state), static_cast<void*>(ws.doubles(0)), g_mse_sum_order);
-        return check_launch("msefast_tensor_evals_flat(aten order)");
-    }
+    OSQ_REQUIRE(g_mse_sum_order != 8 && g_mse_sum_order != 16,
+                "msefast_tensor_evals_flat: with \"mse_sum_order\" 8 / 16 the evaluations go through osq_msefast_tensor_evals_ordered");
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
@@ -1419,14 +1442,8 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_evals_tokens: empty view");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
-    if (g_mse_sum_order == 8 || g_mse_sum_order == 16) {        // test mode: the reference machine's summation order
-        OSQ_REQUIRE(v.batch <= kAtenThreads && v.batch * v.tokens * v.feat_outer * v.feat_inner <= kAtenMaxElems && v.batch * v.tokens * v.feat_outer * v.feat_inner >= 16,
-                    "msefast_tensor_evals_tokens: the summation-order test mode takes 16..65536 elements, at most 1024 samples");
-        for (int e = 0; e < n_evals; ++e)
-            hipLaunchKernelGGL(msefast_tensor_aten_kernel, dim3(1), dim3(kAtenThreads), 0, st, x, int64_t(0), v, lengths, 1,
-                               static_cast<TensorSearch*>(state), static_cast<void*>(ws.doubles(0)), g_mse_sum_order);
-        return check_launch("msefast_tensor_evals_tokens(aten order)");
-    }
+    OSQ_REQUIRE(g_mse_sum_order != 8 && g_mse_sum_order != 16,
+                "msefast_tensor_evals_tokens: with \"mse_sum_order\" 8 / 16 the site is gathered (osq_gather_valid_tokens) and evaluated by osq_msefast_tensor_evals_ordered");
     double* count = ws.doubles(kFamMseTokens) + kMaxBlocks;        // behind the partials
     hipLaunchKernelGGL(msefast_valid_count_kernel, dim3(1), dim3(64), 0, st, lengths, v.batch, v.tokens,
                        v.feat_outer * v.feat_inner, count);
@@ -1438,6 +1455,47 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
                            static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count,
                            g_mse_sum_order == 64 ? 1 : 0);
     return check_launch("msefast_tensor_evals_tokens");
+}
+
+// ---- the reference's summation order at any length (aten_order.h)
+extern "C" size_t osq_ordered_sum_scratch_bytes(int64_t n, int n_sums) {
+    if (n <= 0 || n_sums <= 0) return 0;
+    // the widest of the forms a caller may run: fp32 on 8 / 16 lanes, float64 on 4 / 8
+    size_t b = cascade_scratch_bytes(n, 8, n_sums, 4);
+    b = std::max(b, cascade_scratch_bytes(n, 16, n_sums, 4));
+    b = std::max(b, cascade_scratch_bytes(n, 4, n_sums, 8));
+    b = std::max(b, cascade_scratch_bytes(n, 8, n_sums, 8));
+    return b + 256;
+}
+
+extern "C" int osq_gather_valid_tokens(const float* x, const osq_token_view* view, const int64_t* lengths, float* out,
+                                       int64_t* count_out, osq_stream stream) {
+    OSQ_REQUIRE(x && view && out, "gather_valid_tokens: null pointer");
+    const osq_token_view v = *view;
+    OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "gather_valid_tokens: empty view");
+    const int64_t tokens = v.batch * v.tokens;
+    OSQ_REQUIRE(tokens < (1ll << 31) * kWavesPerBlock, "gather_valid_tokens: too many tokens");
+    hipLaunchKernelGGL(gather_valid_tokens_kernel, dim3(static_cast<unsigned>((tokens + kWavesPerBlock - 1) / kWavesPerBlock)),
+                       dim3(kThreads), 0, static_cast<hipStream_t>(stream), x, v, lengths, out, count_out);
+    return check_launch("gather_valid_tokens");
+}
+
+extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat, int64_t n, const int64_t* n_device, int n_evals,
+                                                void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream) {
+    OSQ_REQUIRE(state && x_flat && n > 0 && scratch && workspace && n_evals >= 0, "msefast_tensor_evals_ordered: bad argument");
+    OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
+                "msefast_tensor_evals_ordered: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
+    OSQ_REQUIRE(scratch_bytes >= osq_ordered_sum_scratch_bytes(n, 1), "msefast_tensor_evals_ordered: scratch smaller than osq_ordered_sum_scratch_bytes(n, 1)");
+    OSQ_REQUIRE(cascade_geom(n, g_mse_sum_order / 2).P <= kCascadeMaxP, "msefast_tensor_evals_ordered: tensor too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace ws(workspace);
+    // one workgroup per level-1 chunk of the cascade in its finest form (float64: 256 rows x W / 2 x 4 columns), at most 2048
+    const CascadeGeom g = cascade_geom(n, g_mse_sum_order / 2);
+    const int grid = static_cast<int>(std::min<int64_t>(g.chunks + 1, kMaxBlocks));
+    for (int e = 0; e < n_evals; ++e)
+        hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreads), 0, st, x_flat, n, n_device,
+                           static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order);
+    return check_launch("msefast_tensor_evals_ordered");
 }
 
 // osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 in the environment (the switch for processes that SHARE a GPU:

@@ -1664,9 +1664,15 @@ extern "C" int osq_fused_step_status(void* workspace, int* status_out, osq_strea
     FusedState* fs = static_cast<FusedState*>(Workspace(workspace).fused());
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned int v = 0u;
-    if (hipMemcpyAsync(&v, &fs->status, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemsetAsync(&fs->status, 0, sizeof(v), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (hipMemcpyAsync(&v, &fs->status, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         set_error("fused_step_status: copy failed");
+        return OSQ_ERR_HIP;
+    }
+    // After a time-out the arrival flags are not trustworthy: a streaming workgroup that became resident only after
+    // workgroup 2 had advanced the epoch stored the NEXT launch's tag.  Nothing is in flight after the synchronisation
+    // above, so the whole block goes back to its all-zero start.
+    if (v != 0u && (hipMemsetAsync(fs, 0, kWsFusedBytes, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        set_error("fused_step_status: reset failed");
         return OSQ_ERR_HIP;
     }
     *status_out = static_cast<int>(v);
@@ -1676,7 +1682,8 @@ extern "C" int osq_fused_step_status(void* workspace, int* status_out, osq_strea
 /* Sticky time-out flags of BOTH persistent launch families on this workspace (the fused observe + fake-quant step and
  * the resident MSEFast searches), read and cleared after everything enqueued on `stream` has finished.  With
  * reset_on_error != 0 a non-zero flag also puts the two state blocks back to their all-zero start (nothing is in
- * flight on this workspace after the synchronisation): the next launch starts clean. */
+ * flight on this workspace after the synchronisation): the next launch starts clean.  The fused step's block is wiped
+ * after a time-out of that family in either case. */
 extern "C" int osq_persistent_status(void* workspace, int* fused_status_out, int* resident_status_out, int reset_on_error,
                                      osq_stream stream) {
     OSQ_REQUIRE(workspace && fused_status_out && resident_status_out, "persistent_status: null pointer");
@@ -1695,8 +1702,10 @@ extern "C" int osq_persistent_status(void* workspace, int* fused_status_out, int
         hipError_t e = hipSuccess;
         if (reset_on_error) e = hipMemsetAsync(ws.fused(), 0, kWsFusedBytes + kWsResidentBytes, st);
         else {
-            e = hipMemsetAsync(&fs->status, 0, sizeof(f), st);
-            if (e == hipSuccess) e = hipMemsetAsync(rs_status, 0, sizeof(r), st);
+            // the fused step's block is wiped whenever ITS flag was raised (stale arrival flags, see osq_fused_step_status);
+            // the resident searches' granules are tag-protected with a gap after a time-out: their flag alone is cleared
+            if (f) e = hipMemsetAsync(ws.fused(), 0, kWsFusedBytes, st);
+            if (e == hipSuccess && r) e = hipMemsetAsync(rs_status, 0, sizeof(r), st);
         }
         if (e != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             set_error("persistent_status: reset failed");

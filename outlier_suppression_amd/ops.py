@@ -154,6 +154,14 @@ def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max
     ds = torch.empty(1, dtype=torch.float32, device=x.device) if need_scale else None
     dz = torch.empty(1, dtype=torch.float32, device=x.device) if need_zp else None
     ws = _hip.workspace(x.device)
+    if reference_sum_order("bwd") and x.numel() > 0:     # strict: autograd's four fp32 reductions in torch's one-thread order
+        scratch, nbytes = _ordered_scratch(x.device, x.numel(), 4)
+        _hip.check(lib.osq_lsq_backward_per_tensor_ordered(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
+                                                           _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                                                           int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz),
+                                                           _hip.ptr(scratch), nbytes, _hip.ptr(ws), _hip.stream_ptr(x.device)),
+                   "lsq_backward_per_tensor_ordered")
+        return dx, ds, dz
     _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
                                                _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
                                                int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
@@ -337,9 +345,26 @@ _token_scratch = {}
 _wide_min_slots = 32769
 
 
+_tuning = {}          # what set_tuning has been given (the summation-order switches decide which entry point a call takes)
+
+
 def set_tuning(key, value):
-    """Performance / path-selection knobs of the library (osq_set_tuning); results never change."""
+    """Performance / path-selection knobs of the library (osq_set_tuning).  Results never change -- except for the two
+    summation-order switches ("mse_sum_order", "bwd_sum_order": 8 / 16 = the reference's one-thread CPU order, see
+    outlier_suppression_amd.set_strict), which pick WHICH of two roundings of the same sum is returned."""
     _hip.check(_hip.load().osq_set_tuning(key.encode(), int(value)), f"set_tuning({key})")
+    _tuning[key] = int(value)
+
+
+def reference_sum_order(kind):
+    """SIMD width (8 / 16) of the reference host whose summation order the "mse" / "bwd" sums follow, or 0."""
+    v = _tuning.get("mse_sum_order" if kind == "mse" else "bwd_sum_order", 0)
+    return v if v in (8, 16) else 0
+
+
+def _ordered_scratch(device, n, n_sums):
+    nbytes = int(_hip.load().osq_ordered_sum_scratch_bytes(int(n), int(n_sums)))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 def set_wide_min_slots(slots):
@@ -619,6 +644,8 @@ def msefast_tensor_run(r, chunk=None, two_d=True):
     dev = r.x.device
     st = _hip.stream_ptr(dev)
     ws = _hip.workspace(dev)
+    if reference_sum_order("mse"):
+        return _msefast_tensor_run_ordered(r, chunk, two_d)
     rc = lib.osq_msefast_tensor_search(_hip.ptr(r.state), _hip.ptr(r.x), r.x.numel(), None if r.view is None else ctypes.byref(r.view),
                                        _hip.ptr(r.lengths), _hip.ptr(ws), st)
     if rc not in (0, _hip.ERR_UNSUPPORTED):
@@ -635,6 +662,35 @@ def msefast_tensor_run(r, chunk=None, two_d=True):
         else:
             _hip.check(lib.osq_msefast_tensor_evals_tokens(_hip.ptr(r.state), _hip.ptr(r.x), ctypes.byref(r.view),
                                                            _hip.ptr(r.lengths), chunk, _hip.ptr(ws), st), "msefast_evals_tokens")
+        launched += chunk
+        _hip.check(lib.osq_msefast_tensor_done(_hip.ptr(r.state), _hip.ptr(done), st), "msefast_done")
+        if int(done.item()) or launched > 500 * 500:
+            break
+
+
+def _msefast_tensor_run_ordered(r, chunk, two_d):
+    """The strict form of a per-tensor search ("mse_sum_order" 8 / 16): the site is laid out once the way the reference's
+    remove_padding / flatten does (observer.py:72-84) and every loss evaluation is one launch that adds the squared errors
+    in the order of torch.sum on a one-thread host (csrc/aten_order.h)."""
+    lib = _hip.load()
+    dev = r.x.device
+    st = _hip.stream_ptr(dev)
+    ws = _hip.workspace(dev)
+    if r.view is None:
+        flat, n, n_dev = r.x, r.x.numel(), None
+    else:
+        n = r.view.batch * r.view.tokens * r.view.feat_outer * r.view.feat_inner
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        _hip.check(lib.osq_gather_valid_tokens(_hip.ptr(r.x), ctypes.byref(r.view), _hip.ptr(r.lengths), _hip.ptr(flat),
+                                               _hip.ptr(n_dev), st), "gather_valid_tokens")
+    scratch, nbytes = _ordered_scratch(dev, n, 1)
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    chunk = chunk or (64 if two_d else 32)
+    launched = 0
+    while True:
+        _hip.check(lib.osq_msefast_tensor_evals_ordered(_hip.ptr(r.state), _hip.ptr(flat), n, _hip.ptr(n_dev), chunk,
+                                                        _hip.ptr(scratch), nbytes, _hip.ptr(ws), st), "msefast_evals_ordered")
         launched += chunk
         _hip.check(lib.osq_msefast_tensor_done(_hip.ptr(r.state), _hip.ptr(done), st), "msefast_done")
         if int(done.item()) or launched > 500 * 500:

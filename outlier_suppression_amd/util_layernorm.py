@@ -1,10 +1,16 @@
 """LayerNorm wrappers used by Gamma Migration, with the reference's class names.
 
 Reference: quant_transformer/model/util_layernorm.py.  Under autograd the normalisation stays stock
-PyTorch-ROCm followed by the HIP quantizer (the eager sequence of the reference).  Without autograd --
-every calibration / evaluation forward -- a LayerNorm site is ONE HIP launch: residual (GammaResidual),
-normalisation, affine pair or beta/gamma shift, and the output fake-quant (SURVEY.md 8f N4,
-``ops.residual_layernorm_fake_quant``); ``FUSE_LAYERNORM = False`` restores the eager sequence everywhere.
+PyTorch-ROCm followed by the HIP quantizer (the eager sequence of the reference).  Two fusions exist for forwards without
+autograd (every calibration / evaluation forward):
+
+  * ``FUSE_ACTIVATION`` (default ON): dense -> GELU -> fake-quant as ONE launch -- bit-identical to the two-step form;
+  * ``FUSE_LAYERNORM`` (default OFF, opt-in): a LayerNorm site -- residual (GammaResidual), normalisation, affine pair or
+    beta/gamma shift, output fake-quant -- as ONE launch (``ops.residual_layernorm_fake_quant``: 52 us
+    instead of 168 us on [256,128,768]).  Its row moments are two-pass sums in a wave, torch's LayerNorm kernel is
+    Welford: the normalised values agree to 2e-6, so an activation within 4e-6 of a rounding boundary may land on the
+    neighbouring integer.  This package's default configuration is the results-identical one, hence opt-in
+    (``outlier_suppression_amd.set_fast(True)`` or ``util_layernorm.FUSE_LAYERNORM = True``).
 """
 import torch
 import torch.nn.functional as F
@@ -14,7 +20,8 @@ from . import ops
 from .quantization import QuantizedModule, Quantizer
 from .quantization.fake_quant import _LearnableFakeQuantize
 
-FUSE_LAYERNORM = True
+FUSE_LAYERNORM = False
+FUSE_ACTIVATION = True
 
 
 def _fused_site(mod, x, hidden, gamma, weight, bias, eps, observation_mask):
@@ -139,7 +146,7 @@ def activation_fake_quant(act_fn, quantizer, hidden_states, observation_mask=Non
     quantising state this is ONE launch (``ops.gelu_fake_quant_per_tensor``: bit-identical to the two-step form,
     half the traffic on the largest activation of the block); otherwise the two steps."""
     q = quantizer
-    if (FUSE_LAYERNORM and q is not None and not torch.is_grad_enabled() and q.fake_quant_enabled == 1
+    if (FUSE_ACTIVATION and q is not None and not torch.is_grad_enabled() and q.fake_quant_enabled == 1
             and q.observer_enabled != 1 and q.ch_axis == -1 and hidden_states.is_cuda and hidden_states.dtype == torch.float32
             and hidden_states.is_contiguous() and hidden_states.numel() and hidden_states.data_ptr() % 16 == 0
             and q.scale.is_cuda and ops.is_exact_gelu(act_fn)):

@@ -517,7 +517,7 @@ def test_fused_residual_layernorm_fake_quant(dev):
                     y_q = UL.residual_layernorm(res, mod, xs, hs, L)
                     outs[fuse] = (y_obs.clone(), y_q.clone(), q.scale.item(), q.zero_point.item())
             finally:
-                UL.FUSE_LAYERNORM = True
+                UL.FUSE_LAYERNORM = False
         assert (outs[True][0] - outs[False][0]).abs().max().item() < 4e-6 * max(1.0, outs[False][0].abs().max().item())
         assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) < 1e-6 * outs[False][2]
         assert (outs[True][1] - outs[False][1]).abs().max().item() <= outs[False][2] * 1.001   # at most one step, at ties
@@ -586,14 +586,14 @@ def test_gelu_fake_quant_fused(dev):
     x = (torch.randn(4, 9, 64, generator=gen) * 2).to(dev)
     outs = []
     for fuse in (True, False):
-        UL.FUSE_LAYERNORM = fuse
+        UL.FUSE_ACTIVATION = fuse
         try:
             q.scale.data.fill_(-0.05)
             q.zero_point.data.fill_(80.0)
             with torch.no_grad():
                 outs.append((UL.activation_fake_quant(ACT2FN["gelu"], q, x, None).clone(), q.scale.item(), q.zero_point.item()))
         finally:
-            UL.FUSE_LAYERNORM = True
+            UL.FUSE_ACTIVATION = True
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:] and abs(outs[0][1] - 0.05) < 1e-9 and outs[0][2] == 63.0
     with torch.no_grad():
         r = UL.activation_fake_quant(torch.relu, q, x, None)

@@ -1,0 +1,175 @@
+"""The STRICT switch on the GPU: sums in the reference's own order at any length (csrc/aten_order.h).
+
+The reference's MSEFast loss (`.pow(2).mean()`, quantization/observer.py:420-432) and its LSQ / LSQ+ parameter gradients
+(autograd's `sum_to_size`, quantization/util_quant.py:29-67) are torch.sum on the CPU, whose order -- ATen's cascade_sum --
+is defined for every length once torch runs on one thread.  With `outlier_suppression_amd.set_strict(True)`
+(osq_set_tuning "mse_sum_order" / "bwd_sum_order" = 8) the kernels add in that order on the whole chip, and every number
+below is compared BIT FOR BIT:
+
+  * against the oracle (oracle/aten_sum.py::aten_sum_flat, pinned against torch.sum) at lengths round every boundary of
+    the cascade -- below one SIMD vector, one level-0 block, one level-1 chunk, one level-2 unit, the point where the
+    level step doubles (16.8 M fp32 elements), odd tails;
+  * against the REFERENCE's own one-thread run at the site sizes of BASELINE configs[3] (tests/golden/site_size.npz,
+    made by tests/golden/make_golden_site_size.py: [32,128,768] masked, [32,12,128,128] probabilities, [32,128,3072] GELU
+    outputs; three batches, so the float64 calls are covered; statistics after every call and the evaluation counts).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _site_size import BWD_CASES, MSE_CASES, bwd_case, checksum, site_input, site_lengths
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from outlier_suppression_amd import _hip
+    _hip.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def strict():
+    import outlier_suppression_amd as osq
+    osq.set_strict(True)
+    yield
+    osq.set_strict(False)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# lengths round the boundaries of the cascade: W = 8 lanes, 32 columns, level-0 block 512 elements, level-1 chunk 8192,
+# level-2 unit 131072, level 3 beyond; 2^24 + ... : the level step becomes 32
+LENGTHS = [1, 5, 7, 8, 9, 31, 32, 33, 100, 511, 512, 513, 8191, 8192, 8193, 8200 + 16 * 512 + 3, 65536, 100001,
+           131072, 131072 + 77, 2 * 131072 + 8192 + 512 + 33, 1 << 20, 3145728 + 13, (1 << 24) + 32 * 1024 + 37]
+
+
+@pytest.mark.parametrize("width", [8, 16])
+def test_ordered_backward_equals_oracle_at_any_length(dev, width):
+    """scale.grad / zero_point.grad of the LSQ+ backward in autograd's order (four fp32 reductions in ATen's one-thread
+    order) against the oracle's restatement, dx on the way, at lengths round every boundary of the cascade."""
+    from outlier_suppression_amd import ops
+    from oracle import fake_quant_oracle as FQ
+    rng = np.random.default_rng(11)
+    ops.set_tuning("bwd_sum_order", width)
+    try:
+        for n in LENGTHS:
+            x = (rng.standard_normal(n) * 1.5).astype(np.float32)
+            gy = rng.standard_normal(n).astype(np.float32)
+            scale, zp, gf = np.float32(0.07), np.float32(29.0), FQ.lsqplus_grad_factor(n, 63)
+            xd, gd = torch.from_numpy(x).to(dev), torch.from_numpy(gy).to(dev)
+            s = torch.tensor([scale], device=dev)
+            z = torch.tensor([zp], device=dev)
+            dx, ds, dz = ops.lsq_backward_per_tensor(xd, gd, s, z, 0, 63, ops.PARAM_LSQPLUS, gf)
+            rdx, rds, rdz = FQ.lsqplus_backward_per_tensor_reference_order(x, gy, scale, zp, 0, 63, gf, vec=width)
+            assert np.array_equal(N(dx), rdx), n
+            assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (n, width, ds.item(), rds, dz.item(), rdz)
+    finally:
+        ops.set_tuning("bwd_sum_order", 0)
+
+
+def _oracle_order_mean(width):
+    from oracle.aten_sum import aten_mean_flat
+
+    def mean(sq):
+        sq = np.asarray(sq)
+        if sq.dtype == np.float64:
+            return aten_mean_flat(sq.reshape(-1), width // 2, np.float64)
+        return aten_mean_flat(sq.reshape(-1), width, np.float32)
+    return mean
+
+
+@pytest.mark.parametrize("width", [8, 16])
+def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
+    """Per-tensor searches (symmetric 1-D: ~25 evaluations; two calls, the second in float64) on flat tensors whose
+    lengths sit round the boundaries of the cascade, and on masked 3-D / 4-D sites that are gathered first: ranges and
+    evaluation counts equal the oracle's with the loss summed in the same order."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization import observer as OBS
+    from oracle import observer_oracle as OB
+    rng = np.random.default_rng(5)
+    ops.set_tuning("mse_sum_order", width)
+    OB.MEAN_LIKE_TORCH = _oracle_order_mean(width)
+    try:
+        for n in [100, 8193, 3 * 8192 + 5, 70001, 131072 + 77, 262144 + 8192 + 33, (1 << 20) + 7]:
+            ob = OBS.MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
+            st = OB.ObserverState(bit=4, symmetric=True, ch_axis=-1)
+            counter = [0]
+            evals = 0
+            for r in range(2):
+                x = (rng.standard_normal(n) * (1.0 + r)).astype(np.float32)
+                ob(torch.from_numpy(x).to(dev))
+                evals += int(ob.last_nfev.sum().item())
+                OB.observe_msefast(st, x, average=False, counter=counter)
+                assert np.array_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
+                    np.array_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (n, r, N(ob.max_val), st.max_val)
+            assert evals == counter[0], (n, evals, counter[0])
+        for shape, seq_pos, sym in [((16, 96, 200), 1, False), ((4, 6, 50, 40), 2, False), ((5, 3, 24, 70), 3, True)]:
+            ob = OBS.AvgMSEFastObserver(bit=6, symmetric=sym, ch_axis=-1).to(dev)
+            st = OB.ObserverState(bit=6, symmetric=sym, ch_axis=-1)
+            counter = [0]
+            evals = 0
+            for r in range(2):
+                x = (rng.standard_normal(shape) * (1.0 + 0.5 * r)).astype(np.float32)
+                x[..., 3] *= 12
+                lengths = rng.integers(1, shape[seq_pos] + 1, size=shape[0])
+                ob(torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), seq_pos)
+                evals += int(ob.last_nfev.sum().item())
+                OB.observe_msefast(st, x, lengths, seq_pos, average=True, counter=counter)
+                assert np.array_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
+                    np.array_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (shape, r, N(ob.min_val), st.min_val)
+            assert evals == counter[0], (shape, evals, counter[0])
+    finally:
+        OB.MEAN_LIKE_TORCH = None
+        ops.set_tuning("mse_sum_order", 0)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in MSE_CASES])
+def test_msefast_site_size_equals_reference_in_its_summation_order(golden, dev, strict, case):
+    """BASELINE configs[3]'s per-tensor activation searches at their real site shapes against the REFERENCE's own run
+    (one thread): min_val / max_val after every call -- float64 arithmetic from the second call on where the reference
+    switches -- and the cumulative number of loss evaluations, bit for bit."""
+    from outlier_suppression_amd.quantization import observer as OBS
+    g = golden("site_size")
+    name, cls, shape, seq_pos, kind, bit, sym, batches, seed = next(c for c in MSE_CASES if c[0] == case)
+    gen = torch.Generator().manual_seed(seed)
+    ob = getattr(OBS, cls)(bit=bit, symmetric=sym, ch_axis=-1).to(dev)
+    evals = 0
+    for r in range(batches):
+        x = site_input(gen, shape, kind, r)
+        L = site_lengths(gen, shape, seq_pos)
+        assert checksum(x) == int(g[f"{name}_xsum"][r]), "the seeded input differs from the one the fixture was made with"
+        ob(x.to(dev), L.to(dev), seq_pos)
+        evals += int(ob.last_nfev.sum().item())
+        got = (float(N(ob.min_val).reshape(-1)[0]), float(N(ob.max_val).reshape(-1)[0]))
+        want = (float(g[f"{name}_min"][r]), float(g[f"{name}_max"][r]))
+        assert got == want, (name, r, got, want)
+        assert evals == int(g[f"{name}_nfev"][r]), (name, r, evals, int(g[f"{name}_nfev"][r]))
+    assert ob.one_side_dist == str(g[f"{name}_side"])
+
+
+@pytest.mark.parametrize("case", [c[0] for c in BWD_CASES])
+def test_lsqplus_site_size_gradients_equal_reference_in_its_summation_order(golden, dev, strict, case):
+    """LSQ+ forward + backward at BERT-base site sizes against the reference's own autograd run on one thread:
+    scale.grad and zero_point.grad bit for bit; y and x.grad through the sums of their bit patterns (they are bit-exact element-wise
+    in every mode: tests/test_gpu_parity.py)."""
+    from outlier_suppression_amd.quantization import util_quant as U
+    g = golden("site_size")
+    name, shape, kind, seed = next(c for c in BWD_CASES if c[0] == case)
+    x, gy, scale, zp, gf = bwd_case(shape, kind, seed)
+    assert [checksum(x), checksum(gy)] == [int(v) for v in g[f"{name}_xsum"]]
+    assert np.array_equal(scale.numpy(), g[f"{name}_scale"]) and np.array_equal(zp.numpy(), g[f"{name}_zp"])
+    xd = x.to(dev).requires_grad_(True)
+    s = scale.to(dev).requires_grad_(True)
+    z = zp.to(dev).requires_grad_(True)
+    y = U.fake_quantize_learnableplus_per_tensor_affine_training(xd, s, z, 0, 63, gf)
+    y.backward(gy.to(dev))
+    assert checksum(y) == int(g[f"{name}_ysum"][0])
+    assert checksum(xd.grad) == int(g[f"{name}_dxsum"][0])
+    assert np.array_equal(N(s.grad), g[f"{name}_dscale"]) and np.array_equal(N(z.grad), g[f"{name}_dzp"]), \
+        (name, N(s.grad), g[f"{name}_dscale"], N(z.grad), g[f"{name}_dzp"])

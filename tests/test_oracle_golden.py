@@ -153,10 +153,10 @@ def test_msefast(golden):
 
 def aten_order_mean(sq):
     """torch's CPU mean as the fixture machine computed it (one thread): fp32 in 8 SIMD lanes, float64 in 4."""
-    from oracle.aten_sum import aten_mean
+    from oracle.aten_sum import aten_mean_flat
     sq = np.asarray(sq)
     dt = np.float64 if sq.dtype == np.float64 else np.float32
-    return aten_mean(sq.reshape(-1), 4 if dt is np.float64 else 8, dt, serial_only=False)
+    return aten_mean_flat(sq.reshape(-1), 4 if dt is np.float64 else 8, dt)
 
 
 def test_msefast_equals_reference_in_its_summation_order(golden):

@@ -133,3 +133,47 @@ def test_aten_sum_order():
         torch.set_num_threads(threads)
     x = (rng.standard_normal((9, 3072)) ** 2).astype(np.float32)           # leading axes are independent rows
     assert np.array_equal(aten_sum_f32(x, 8), np.array([torch.from_numpy(r).sum().item() for r in x], dtype=np.float32))
+
+
+def test_aten_sum_flat_any_length():
+    """oracle/aten_sum.py::aten_sum_flat walks the cascade block-wise (what the strict kernels do, csrc/aten_order.h) and
+    holds for any length on a one-thread host: equal to the row-by-row restatement and to torch.sum itself, fp32 in 8 / 16
+    lanes and float64 in 4, at lengths round every boundary of the cascade -- including the one where the level step
+    doubles (beyond 2^19 rows per column: 16.8 M fp32 elements)."""
+    import torch
+    from oracle.aten_sum import aten_sum, aten_sum_flat
+    if torch.backends.cpu.get_cpu_capability() not in ("AVX2", "AVX512"):
+        pytest.skip("torch's sum kernel runs at another vector width on this host")
+    rng = np.random.default_rng(3)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for n in [1, 5, 7, 8, 9, 31, 32, 33, 100, 511, 512, 513, 8191, 8192, 8193, 16384 + 515, 65536, 100001, 131072 + 77,
+                  2 * 131072 + 8192 + 512 + 33, 1 << 20, 3145728 + 13, (1 << 24) + 32 * 1024 + 37]:
+            x = (rng.standard_normal(n) ** 2 * rng.choice([1e-3, 1.0, 1e3])).astype(np.float32)
+            got = aten_sum_flat(x, 8, np.float32)
+            assert got == np.float32(torch.from_numpy(x).sum().item()), n
+            xd = x.astype(np.float64) ** 1.5
+            assert aten_sum_flat(xd, 4, np.float64) == np.float64(torch.from_numpy(xd).sum().item()), n
+            if n <= 300000:
+                assert got == aten_sum(x, 8, np.float32, serial_only=False), n
+                assert aten_sum_flat(x, 16, np.float32) == aten_sum(x, 16, np.float32, serial_only=False), n
+                assert aten_sum_flat(xd, 8, np.float64) == aten_sum(xd, 8, np.float64, serial_only=False), n
+    finally:
+        torch.set_num_threads(threads)
+
+
+def test_exact_sum():
+    """oracle.observer_oracle.exact_sum beyond 200 000 elements (a pairwise tree of error-free two-sums) against
+    math.fsum, on squared-error-like data: non-negative, six decades of dynamic range, fp32-valued and full float64."""
+    import math
+    from oracle.observer_oracle import exact_sum
+    rng = np.random.default_rng(17)
+    for n in [200001, 262144, 300007, 1 << 20, 1700003]:
+        for kind in range(3):
+            a = rng.standard_normal(n) ** 2 * 10.0 ** rng.integers(-6, 1, size=n)
+            if kind == 1:
+                a = a.astype(np.float32).astype(np.float64)
+            if kind == 2:
+                a[rng.integers(0, n, size=n // 2)] = 0.0
+            assert exact_sum(a) == math.fsum(a.tolist()), (n, kind)

@@ -539,7 +539,8 @@ def calibration_extra(dev, rank, world, which):
         batches = masked_batches(8, 32, 384, 30522, 64)
         for b in batches:
             b["token_type_ids"] = torch.zeros_like(b["input_ids"])
-        task, mtype, grid = "squad", "bert", {"iters": 90, "step": 0.0033}
+        # OSQ_BENCH_SQUAD_CANDIDATES: test hook (tests/test_gpu_sharded.py runs eight ranks on one GPU); the measured config has 90
+        task, mtype, grid = "squad", "bert", {"iters": int(os.environ.get("OSQ_BENCH_SQUAD_CANDIDATES", "90")), "step": 0.0033}
         out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
     elif which in (4, 5):
         # 4: bart-base dimensions, what the reference's shipped config points at (exp/xsum/twc_fine_gamma/config.yaml:44);
@@ -569,8 +570,7 @@ def calibration_extra(dev, rank, world, which):
         w_q = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
         a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)
         from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
-        res = None
-        for rep in range(2):          # the second run is the steady state (code objects loaded, allocator grown, communicator built)
+        def run_once():
             model = quantize_model(fp, w_q, a_q).to(dev)
             phases = {}
             sync()
@@ -585,9 +585,28 @@ def calibration_extra(dev, rank, world, which):
             enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
             info_a = calibration.calibrate_owned_sites(model, batches, fwd)
             sync(); phases["activation_calibration_msefast_per_tensor"] = time.perf_counter() - t0
-            wall = time.perf_counter() - t_start
-            if rep == 0:
-                first_wall = wall
+            return time.perf_counter() - t_start, phases, info_w, info_a, model
+
+        first_wall = run_once()[0]    # the second run is the steady state (code objects loaded, allocator grown, communicator built)
+        wall, phases, info_w, info_a, model = run_once()
+        # the STRICT switch (outlier_suppression_amd.set_strict: every per-tensor loss added in the reference's one-thread
+        # order, one launch per loss evaluation instead of one resident launch per search): what it costs on this config
+        import outlier_suppression_amd as osq
+        osq.set_strict(True)
+        try:
+            strict_wall, strict_phases, _, _, strict_model = run_once()
+        finally:
+            osq.set_strict(False)
+        strict = {"wall_s": round(strict_wall, 3), "phases_s": {k: round(v, 3) for k, v in strict_phases.items()},
+                  "what": "set_strict(True): MSEFast losses in ATen's one-thread summation order (bit-equal to the reference run on a "
+                          "one-thread host, tests/test_gpu_strict_order.py); per-channel rows follow that order in either mode"}
+        # how far the two configurations' results are apart: relative difference of every activation quantizer's scale
+        d = [abs(a.scale.item() - b.scale.item()) / abs(b.scale.item())
+             for (_, a), (_, b) in zip([(n, m) for n, m in strict_model.named_modules() if isinstance(m, QuantizeBase) and "act" in n],
+                                       [(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n])]
+        d.sort()
+        strict["activation_scale_rel_diff_vs_default"] = {"median": d[len(d) // 2], "max": d[-1], "equal": sum(1 for v in d if v == 0.0), "sites": len(d)}
+        del strict_model
         mine_w = [q for (n, q), r in zip([(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "weight_fake_quant" in n],
                                          info_w["owner"] or [0] * 10 ** 6) if r == rank]
         rows = sum(int(q.observer.min_val.numel()) for q in mine_w)
@@ -597,7 +616,7 @@ def calibration_extra(dev, rank, world, which):
         act_evals = sum(int(q.observer.last_nfev.sum().item()) for q in mine_a if q.observer.last_nfev is not None)
         return {"config": "configs[3]: RoBERTa-base MNLI W4A6, per-channel weights + MSEFast, 256 samples (8 x [32,128])",
                 "wall_s": round(wall, 3), "first_run_wall_s": round(first_wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
-                "collective_s": round(info_w["collective_s"] + info_a["collective_s"], 4),
+                "collective_s": round(info_w["collective_s"] + info_a["collective_s"], 4), "strict": strict,
                 "weight_rows_searched_on_rank0": rows, "weight_loss_evaluations_on_rank0": evals,
                 "activation_sites": len(act_q), "activation_sites_on_rank0": len(mine_a),
                 "activation_loss_evaluations_last_batch_on_rank0": act_evals, "n_gpus": world,
@@ -803,7 +822,10 @@ def main():
     ap.add_argument("--settle", type=float, default=1.0, help="seconds of untimed steps before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--preroll", type=float, default=0.25, help="seconds of untimed graph replays directly before the timed one")
     ap.add_argument("--buffers", type=int, default=4, help="distinct input tensors cycled through (4 x 96 MiB > 256 MiB Infinity Cache)")
-    ap.add_argument("--eager", action="store_true", help="time the eager loop of module calls instead of the captured graph")
+    ap.add_argument("--eager", action="store_true", help="time the eager loop of module calls instead of the captured graph (= --launch eager)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="how the K timed module calls are issued: one hipGraph replay, the eager loop, or (auto) whichever of the two "
+                         "measures faster in untimed K-step regions directly before the timed one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
@@ -858,7 +880,15 @@ def main():
     valid_elem = int(lengths.sum().item()) * SHAPE[2]
     bytes_step = 4 * valid_elem + 8 * n_elem
 
+    # N > 1: every step also leaves ITS batch's (min, max) in row i of the table the ranks exchange after the timed steps
+    # (the one-launch step writes it on the way: osq_observe_tokens_fake_quant, cur_minmax)
+    table = torch.zeros(args.steps, 1, 2, device=dev)
+    rows = [table[i, 0] for i in range(args.steps)]
+    record = world > 1
+
     def step(i):
+        if record:
+            q.observer.__dict__["_record"] = rows[i % args.steps]
         return q(xs[i % len(xs)], lengths, 1)
 
     with torch.no_grad():
@@ -878,8 +908,6 @@ def main():
         torch.cuda.synchronize()
         for i in range(args.warmup):
             y = step(i)
-    # per-batch statistics table for the sharded-calibration exchange (N > 1)
-    table = torch.zeros(args.steps, 1, 2, device=dev)
     if world > 1:   # untimed: the first collective of a process group builds the RCCL communicator
         calibration.gather_batch_table(table, args.steps * world)
     import ctypes
@@ -893,13 +921,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the K timed steps are K module calls captured once into a hipGraph and replayed inside the timed region:
-    # the GPU executes exactly the launches the eager loop issues (same kernels, same arguments, same order), but
-    # the 1 ms timed region no longer depends on how fast a freshly started Python process gets through its first
-    # few calls (round 1: 22 % of a 20-step run).  Capture itself does not execute anything.  The eager loop is
-    # measured right after, untimed, and reported next to it (eager_ms_per_step, host_enqueue_ms_per_step).
-    graph, graph_ws, launch_mode = None, None, "eager loop"
-    if not args.eager:
+    # ---- the K timed steps are K module calls, issued either as ONE replay of a hipGraph captured after the warm-up (the
+    # GPU executes exactly the launches the eager loop issues: same kernels, same arguments, same order) or as the eager
+    # loop itself.  Which of the two gets a 0.8 ms region through faster is a property of the lease: round 3's driver
+    # box read 44.1 us per step for the replay and 39.5 for the eager loop in the same run, the builder's boxes 40.0 and
+    # 51.5 (an eager region that starts on an idle GPU).  So both are prepared, both are measured in UNTIMED K-step
+    # regions directly before the timed one, and the timed region -- one region, exactly K steps, bracketed as the
+    # contract says -- is issued the way that measured faster here (--launch graph / eager forces one).
+    if args.eager:
+        args.launch = "eager"
+    graph, graph_ws, graph_note = None, None, ""
+    if args.launch != "eager":
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -916,49 +948,111 @@ def main():
             torch.cuda.synchronize()
             graph.replay()                                   # untimed: the first replay of a graph also uploads it (+4 us/step at K = 20)
             torch.cuda.synchronize()
-            launch_mode = f"hipGraph replay of {args.steps} captured module calls (second replay; the first one is untimed warm-up)"
         except Exception as e:                               # capture unavailable: time the eager loop
-            graph, launch_mode = None, f"eager loop (graph capture failed: {type(e).__name__})"
+            graph, graph_note = None, f" (graph capture failed: {type(e).__name__})"
 
     import gc
     gc.collect()
     gc.disable()                               # no collector pauses inside the timed region
-    if graph is not None:
-        # untimed: capture and the collector pass above leave the GPU idle for tens of milliseconds and its clocks fall
-        # back (MI355X_MICROARCH.md, DVFS); a few replays do not bring them back (tools/region_probe.py: the same
-        # 20-step replay reads 41.5 us per step in the first milliseconds and 40.3 after ~50 ms of this work).  The
-        # timed region should measure the device in the state it runs this work in: replay for --preroll seconds
-        with torch.no_grad():
-            t_pre = time.perf_counter()
-            while time.perf_counter() - t_pre < args.preroll:
-                for _ in range(4):
-                    graph.replay()
-                torch.cuda.synchronize()
-            for _ in range(3):
-                graph.replay()
-    barrier()
-    t0 = time.perf_counter()
-    with torch.no_grad():                      # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
-        if graph is not None:
+
+    def issue(mode):
+        if mode == "graph":
             graph.replay()
-        else:
-            for i in range(args.steps):
-                y = step(i)                    # the module call itself, nothing else in the loop
-    host_dt = time.perf_counter() - t0
-    if world > 1:
-        # the path's one real exchange: per-batch statistics, gathered once and replayed in batch order
-        table[:, 0, 0] = q.observer.min_val
-        table[:, 0, 1] = q.observer.max_val
-        calibration.gather_batch_table(table, args.steps * world)
-    done = torch.cuda.Event()
-    done.record()
-    barrier(done)
-    dt = time.perf_counter() - t0
+            return None
+        out = None
+        for i in range(args.steps):
+            out = step(i)                      # the module call itself, nothing else in the loop
+        return out
+
+    def region(mode, exchange=False):
+        """One K-step region: barrier + synchronize, K module calls, (N > 1: the exchange), synchronize + barrier.  Seconds."""
+        barrier()
+        t0 = time.perf_counter()
+        with torch.no_grad():                  # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
+            out = issue(mode)
+        host = time.perf_counter() - t0
+        gathered = None
+        if exchange and world > 1:
+            # the path's one real exchange: the per-batch rows the K steps have just recorded, gathered once
+            gathered = calibration.gather_batch_table(table, args.steps * world)
+        done = torch.cuda.Event()
+        done.record()
+        barrier(done)
+        return time.perf_counter() - t0, host, gathered, out
+
+    modes = ["graph", "eager"] if (graph is not None and args.launch == "auto") else (["graph"] if graph is not None else ["eager"])
+    # untimed: capture and the collector pass above leave the GPU idle for tens of milliseconds and its clocks fall back
+    # (MI355X_MICROARCH.md, DVFS; tools/region_probe.py: the same 20-step replay reads 41.5 us per step in the first
+    # milliseconds and 40.3 after ~50 ms of this work).  The timed region should measure the device in the state it
+    # runs this work in: issue the steps for --preroll seconds, in every mode that may be timed
+    with torch.no_grad():
+        for mode in modes:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.preroll / len(modes):
+                for _ in range(4):
+                    y = issue(mode)
+                torch.cuda.synchronize()
+    probes = {m: [] for m in modes}
+    if len(modes) > 1:
+        for _ in range(5):                     # alternating, so that neither mode owns the warmer half
+            for m in modes:
+                probes[m].append(region(m)[0])
+        med = {m: sorted(v)[len(v) // 2] for m, v in probes.items()}
+        pick = min(modes, key=lambda m: med[m])
+        if world > 1:                          # one decision for the job: rank 0's
+            flag = torch.tensor([modes.index(pick)], dtype=torch.int64, device="cpu" if share else dev)
+            dist.broadcast(flag, src=0)
+            pick = modes[int(flag.item())]
+    else:
+        pick = modes[0]
+    with torch.no_grad():
+        for _ in range(3):                     # untimed: the chosen mode directly in front of the timed region
+            y = issue(pick)
+    dt, host_dt, gathered, y = region(pick, exchange=True)
     gc.enable()
+    launch_mode = ("hipGraph replay of %d captured module calls" % args.steps if pick == "graph" else "eager loop of %d module calls" % args.steps) + graph_note
+    if len(modes) > 1:
+        launch_mode += "; chosen by untimed probes of both (median of 5 regions, us per step: " + \
+                       ", ".join(f"{m} {med[m] / args.steps * 1e6:.2f}" for m in modes) + ")"
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    exchange_check = None
+    if world > 1:
+        # What the exchange is FOR: every rank replays the gathered rows in global batch order and must end up with the
+        # statistic a single process computes from the same table (observer.py:194-202: m <- (m * cnt + cur) / (cnt + 1),
+        # fp32, sequential).  Checked here on every rank: (a) the device replay (osq_replay_statistics, what
+        # calibrate_sharded runs) equals the host's fp32 restatement of that loop on the gathered table bit for bit,
+        # (b) all ranks hold the same bits, (c) the rows a rank contributed are the rows it recorded.
+        import numpy as np
+        rq = make_quantizer(dev)
+        calibration.replay(gathered, [("bench.act_fake_quant", rq)], fresh=True)
+        torch.cuda.synchronize()
+        g_host = gathered.detach().cpu().numpy().astype(np.float32)
+        mn = mx = None
+        for j in range(g_host.shape[0]):
+            cmin, cmax = g_host[j, 0]
+            if mn is None:
+                mn, mx = cmin, cmax
+            else:
+                c = np.float32(j)
+                mn = np.float32(np.float32(np.float32(mn * c) + cmin) / np.float32(j + 1))
+                mx = np.float32(np.float32(np.float32(mx * c) + cmax) / np.float32(j + 1))
+        got = (np.float32(rq.observer.min_val.item()), np.float32(rq.observer.max_val.item()))
+        mine = table.detach().cpu().numpy()
+        own_rows_ok = bool(np.array_equal(g_host[rank::world][:args.steps], mine)) and bool(np.isfinite(mine).all()) and bool((mine[:, 0, 0] < mine[:, 0, 1]).all())
+        vec = torch.tensor([float(got[0]), float(got[1]), float(rq.scale.item()), float(rq.zero_point.item())], dtype=torch.float64,
+                           device="cpu" if share else dev)
+        every = torch.empty(world * 4, dtype=torch.float64, device=vec.device)
+        dist.all_gather_into_tensor(every, vec)
+        same_on_all = bool((every.view(world, 4) == vec.view(1, 4)).all().item())
+        replay_ok = bool(got[0] == mn and got[1] == mx)
+        exchange_check = {"rows_gathered": int(g_host.shape[0]), "replay_equals_one_process_loop": replay_ok,
+                          "same_bits_on_every_rank": same_on_all, "own_rows_intact": own_rows_ok,
+                          "replayed_min_max": [float(got[0]), float(got[1])]}
+        if not (replay_ok and same_on_all and own_rows_ok):
+            raise SystemExit(f"bench.py: the exchanged statistics do not replay to the one-process result: {exchange_check}")
 
     def check_status():
         # every persistent launch of this process (timed replay, eager loop) marked its workspace: one call reads them all
@@ -1051,7 +1145,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "collective": collective,
+        "collective": dict(collective, exchange_check=exchange_check),
         "config": {"workload": "BERT-base activation [256,128,768] fp32, AvgPruneMinMaxObserver(p=0.95, lengths randint(8,129)) "
                                "-> running average -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]; configs[1] site shape",
                    "launches_per_step": 1 if fused_on else 3, "buffers_cycled": len(xs),
@@ -1098,6 +1192,11 @@ def main():
             except Exception as e:
                 out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+        # Metric 2 in one place: wall-clock and the collective's share of every measured config at the launched N
+        out["calibration_summary"] = {
+            "n_gpus": world,
+            "configs": {k: {"wall_s": v.get("wall_s"), "collective_s": v.get("collective_s")}
+                        for k, v in out.items() if k.startswith("calibration") and isinstance(v, dict) and "wall_s" in v}}
         if rank == 0:
             try:
                 out["quantized_forward"] = quantized_forward_times(dev)

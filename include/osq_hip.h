@@ -118,7 +118,8 @@ typedef enum osq_timed_kernel {
     OSQ_TIME_FAKE_QUANT_CHANNEL = 9,  /* row form of osq_fake_quant_per_channel (weights, ch_axis 0)          */
     OSQ_TIME_OBSERVE_CHANNELS = 10,   /* osq_observe_channels                                                */
     OSQ_TIME_TOKEN_MINMAX_MULTI = 11, /* osq_token_minmax_multi                                              */
-    OSQ_TIME_MSEFAST_ROWS = 12        /* osq_msefast_rows (the per-row search launch)                        */
+    OSQ_TIME_MSEFAST_ROWS = 12,       /* osq_msefast_rows (the per-row search launch)                        */
+    OSQ_TIME_OBSERVE_TOKENS = 13      /* one-launch form of osq_observe_tokens                               */
 } osq_timed_kernel;
 int osq_timing_events_create(void** start, void** stop);
 int osq_timing_events_destroy(void* start, void* stop);
@@ -297,12 +298,16 @@ int osq_observe_tokens(const float* x, const osq_token_view* view, const int64_t
  * with features a multiple of 256 (768, 1024, 3072, 4096), batch <= 1024 and 16-byte aligned buffers runs as ONE
  * persistent launch that keeps the tensor in registers between the reduction and the quantisation (x read from
  * HBM once, fused_step.h; token_min / token_max are scratch whose layout is then private to that launch); anything else, or
- * osq_set_tuning("fused_step", 0), is three launches.  osq_fused_step_status reads (and clears) the sticky
+ * osq_set_tuning("fused_step", 0), is three launches.  cur_minmax (nullable, 2 floats): also receives THIS batch's
+ * (min, max) -- the row a data-parallel calibration exchanges and replays in global batch order (calibration.py; the
+ * reference's running mean is sequential, observer.py:194-202) -- while the running statistic moves as usual.
+ * osq_fused_step_status reads (and clears) the sticky
  * time-out flags of the one-launch form: 0 = every launch on this workspace completed normally. */
 int osq_observe_tokens_fake_quant(const float* x, const osq_token_view* view, const int64_t* lengths,
                                   float* token_min, float* token_max,
                                   int prune, double percentile,
                                   int update_rule, int64_t cnt, float* min_val, float* max_val,
+                                  float* cur_minmax,
                                   int quant_min, int quant_max, int symmetric,
                                   float* scale, void* zero_point, int zp_type,
                                   float* y, int64_t n, int mode, float grad_factor,

@@ -20,6 +20,7 @@ PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
 TIME_LAYERNORM, TIME_FUSED_STEP = 6, 7
 TIME_FAKE_QUANT_STRIDED, TIME_FAKE_QUANT_CHANNEL, TIME_OBSERVE_CHANNELS, TIME_TOKEN_MINMAX_MULTI, TIME_MSEFAST_ROWS = 8, 9, 10, 11, 12
+TIME_OBSERVE_TOKENS = 13
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
 
@@ -77,7 +78,7 @@ SIGNATURES = {
     "osq_token_minmax_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_token_range_finalize": (_I, [_P, _P, _L, _L, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I,
+    "osq_observe_tokens_fake_quant": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _I, _D, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I,
                                            _P, _L, _I, _F, _P, _P, _P]),
     "osq_fused_step_status": (_I, [_P, ctypes.POINTER(_I), _P]),
     "osq_persistent_status": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I), _I, _P]),

@@ -46,7 +46,7 @@ extern "C" int osq_timing_events_destroy(void* start, void* stop) {
 }
 
 extern "C" int osq_time_next_launch(int which, void* start, void* stop) {
-    OSQ_REQUIRE(which >= OSQ_TIME_NONE && which <= OSQ_TIME_MSEFAST_ROWS, "time_next_launch: unknown kernel family");
+    OSQ_REQUIRE(which >= OSQ_TIME_NONE && which <= OSQ_TIME_OBSERVE_TOKENS, "time_next_launch: unknown kernel family");
     OSQ_REQUIRE((start == nullptr) == (stop == nullptr), "time_next_launch: give both events or neither");
     osq::g_time_which = start ? which : 0;
     osq::g_time_start = static_cast<hipEvent_t>(start);
@@ -68,4 +68,4 @@ extern "C" int osq_timing_elapsed_us(void* start, void* stop, float* us) {
 
 extern "C" const char* osq_last_error(void) { return osq::g_error; }
 extern "C" int osq_abi_version(void) { return 4; }
-extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes + osq::kWsFusedBytes + osq::kWsResidentBytes; }
+extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes + osq::kWsFusedBytes + osq::kWsResidentBytes + osq::kWsOneLaunchBytes; }

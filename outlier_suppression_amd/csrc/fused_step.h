@@ -624,6 +624,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             }
             qparams_from_range(mn, mx, fin.quant_min, fin.quant_max, fin.symmetric, &s, &z);
             if (blockIdx.x == 2u) {                        // ONE workgroup writes the module's buffers
+                if (fin.cur) { fin.cur[0] = cur_min; fin.cur[1] = cur_max; }     // this batch's own row (sharded calibration)
                 if (have_state) { fin.min_val[0] = mn; fin.max_val[0] = mx; }
                 fin.scale_out[0] = s;
                 store_zp(fin.zp_out, fin.zp_type, 0, z);

@@ -274,28 +274,12 @@ constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;      // consecutive t
 template <bool NT>
 __device__ __forceinline__ float4 tok_load(const float4* p) { return NT ? load_stream(p) : *p; }
 
+// The per-token reduction of one wave: the extrema of its (up to) 4 tokens starting at `base`, NaN-poisoned, every
+// lane holding every token's result.  Shared by the stand-alone kernel below and the one-launch observation
+// (observe_onelaunch.h).
 template <bool SINGLE_SEGMENT, bool NT>
-__global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float* __restrict__ x, osq_token_view v,
-                                                                    const int64_t* __restrict__ lengths,
-                                                                    float* __restrict__ tok_min,
-                                                                    float* __restrict__ tok_max, int lgG, int inner4) {
-    const int64_t b = blockIdx.y;
-    int64_t len = v.tokens;
-    if (lengths) {
-        const int64_t l = lengths[b];
-        len = l < len ? l : len;
-    }
-    const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
-    // Workgroups reach the XCDs round-robin in linear order (y * gridDim.x + x): with 8 chunks per sample
-    // chunk x would always land on XCD x, and since late chunks are mostly padding, XCD 0 would read 7x
-    // the bytes of XCD 7 (measured: the 54 %-valid tensor took as long as the full one).  Rotating the
-    // chunk index by the sample index spreads every chunk position over all XCDs.
-    const int64_t chunk = (static_cast<int64_t>(blockIdx.x) + blockIdx.y) % gridDim.x;
-    const int64_t t0 = chunk * kTokPerBlock + w * kTokPerWave;
-    if (t0 >= len) return;
-    const int ntok = (len - t0) < kTokPerWave ? static_cast<int>(len - t0) : kTokPerWave;
-    const float* base = x + b * v.stride_batch + t0 * v.stride_token;
-    MinMax acc[kTokPerWave];
+__device__ __forceinline__ void token_extrema(const float* __restrict__ base, const osq_token_view& v, const int ntok,
+                                              const int lgG, const int inner4, const int lane, MinMax (&acc)[kTokPerWave]) {
 #pragma unroll
     for (int k = 0; k < kTokPerWave; ++k) acc[k].init();
     if (SINGLE_SEGMENT) {
@@ -348,6 +332,31 @@ __global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float*
         acc[k].wave_reduce();
         acc[k].poison();
     }
+}
+
+template <bool SINGLE_SEGMENT, bool NT>
+__global__ __launch_bounds__(kThreads) void token_minmax_vec_kernel(const float* __restrict__ x, osq_token_view v,
+                                                                    const int64_t* __restrict__ lengths,
+                                                                    float* __restrict__ tok_min,
+                                                                    float* __restrict__ tok_max, int lgG, int inner4) {
+    const int64_t b = blockIdx.y;
+    int64_t len = v.tokens;
+    if (lengths) {
+        const int64_t l = lengths[b];
+        len = l < len ? l : len;
+    }
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), w = threadIdx.x / OSQ_WAVE;
+    // Workgroups reach the XCDs round-robin in linear order (y * gridDim.x + x): with 8 chunks per sample
+    // chunk x would always land on XCD x, and since late chunks are mostly padding, XCD 0 would read 7x
+    // the bytes of XCD 7 (measured: the 54 %-valid tensor took as long as the full one).  Rotating the
+    // chunk index by the sample index spreads every chunk position over all XCDs.
+    const int64_t chunk = (static_cast<int64_t>(blockIdx.x) + blockIdx.y) % gridDim.x;
+    const int64_t t0 = chunk * kTokPerBlock + w * kTokPerWave;
+    if (t0 >= len) return;
+    const int ntok = (len - t0) < kTokPerWave ? static_cast<int>(len - t0) : kTokPerWave;
+    const float* base = x + b * v.stride_batch + t0 * v.stride_token;
+    MinMax acc[kTokPerWave];
+    token_extrema<SINGLE_SEGMENT, NT>(base, v, ntok, lgG, inner4, lane, acc);
     if (lane < ntok) {
         float mn = acc[0].mn, mx = acc[0].mx;
 #pragma unroll
@@ -861,6 +870,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 
 #include "token_select.h"   // two-workgroup fast path (one per side), used whenever its layout rules hold
 #include "fused_step.h"     // one persistent launch for observe + fake-quant of a dense [B, T, H] activation
+#include "observe_onelaunch.h"   // a masked observation in one launch: the selectors work while the tokens stream
 
 namespace osq {
 
@@ -889,6 +899,8 @@ static int64_t g_wide_min_slots = 32769;
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
 static int g_obs_blocks = 768;
 static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
+static int g_onelaunch = 1;            // osq_set_tuning("observe_onelaunch", 0): masked observations as two launches (token_minmax, token_select)
+static int g_onelaunch_hint = 1;       // osq_set_tuning("observe_hint", 0): the one-launch observation without its pivot (every token a candidate; tests)
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
@@ -1307,6 +1319,8 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
+    if (k == "observe_onelaunch") { g_onelaunch = value != 0; return true; }
+    if (k == "observe_hint") { g_onelaunch_hint = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "select_hint") { g_select_hint = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
@@ -1529,6 +1543,42 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
                                   int quant_min, int quant_max, int symmetric,
                                   float* scale_out, void* zero_point_out, int zp_type,
                                   void* workspace, void* list_scratch, osq_stream stream) {
+    OSQ_REQUIRE(x && view && token_min && token_max, "observe_tokens: null pointer");
+    {
+        // ONE launch (observe_onelaunch.h) when the site has the vector kernel's layout, whole groups of 16 tokens and fits
+        // the selectors' tables; anything else is the two launches below
+        const osq_token_view v = *view;
+        const bool vec = v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0 && v.stride_inner == 1 && v.feat_inner % 4 == 0 &&
+                         aligned16(x) && v.stride_batch % 4 == 0 && v.stride_token % 4 == 0 && (v.feat_outer == 1 || v.stride_outer % 4 == 0) &&
+                         v.feat_inner / 4 < (1 << 30);
+        const int64_t chunks = v.tokens / kOlGroupTokens;
+        if (g_onelaunch && workspace && vec && v.tokens % kOlGroupTokens == 0 && chunks >= 2 && v.batch <= kOlMaxBatch &&
+            v.batch * chunks <= kOlMaxGroups && aligned16(token_min) && aligned16(token_max)) {
+            const char* why = "";
+            OSQ_REQUIRE(!prune || (percentile >= 0.0 && percentile <= 1.0), "observe_tokens: percentile outside [0, 1]");
+            OSQ_REQUIRE(check_finish_args(update_rule, min_val, max_val, &why), why);
+            const Finish fin{update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric, scale_out, zero_point_out, zp_type};
+            const int inner4 = static_cast<int>(v.feat_inner / 4);
+            int lgG = 6;
+            if (v.feat_outer > 1) {
+                lgG = 0;
+                while ((1 << lgG) < inner4 && lgG < 6) ++lgG;
+            }
+            Workspace wsp(workspace);
+            const OneLaunchArgs a{x, v, lengths, token_min, token_max, lgG, inner4, static_cast<int>(chunks), prune,
+                                  static_cast<float>(percentile), g_select_shortcut, g_onelaunch_hint,
+                                  static_cast<OneLaunchState*>(wsp.onelaunch()), wsp.meet(),
+                                  g_fused_spin_limit ? g_fused_spin_limit - 1u : kOlSpinLimit};
+            const dim3 grid(static_cast<unsigned>(chunks), static_cast<unsigned>(v.batch + 1));
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_TOKENS);
+#define OSQ_OL(SEG, NT) hipExtLaunchKernelGGL((observe_tokens_onelaunch_kernel<SEG, NT>), grid, dim3(kOlThreads), 0, st, th.start, th.stop, 0, a, fin)
+            if (v.feat_outer == 1) { if (g_tok_nt) OSQ_OL(true, true); else OSQ_OL(true, false); }
+            else { if (g_tok_nt) OSQ_OL(false, true); else OSQ_OL(false, false); }
+#undef OSQ_OL
+            return check_launch("observe_tokens(one launch)");
+        }
+    }
     const int rc = osq_token_minmax(x, view, lengths, token_min, token_max, stream);
     if (rc != OSQ_OK) return rc;
     return osq_token_range_finalize(token_min, token_max, view->batch, view->tokens, lengths, prune, percentile,
@@ -1598,6 +1648,7 @@ bool persistent_serialize(hipStream_t st) {
 }
 
 static_assert(sizeof(FusedState) <= kWsFusedBytes, "FusedState must fit its slice of the workspace");
+static_assert(sizeof(OneLaunchState) == kWsOneLaunchBytes, "OneLaunchState must fill its slice of the workspace");
 
 template <int NV>
 static bool launch_fused(hipStream_t st, const FusedArgs& a, const Finish& fin) {
@@ -1619,6 +1670,7 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
                                              float* token_min, float* token_max,
                                              int prune, double percentile,
                                              int update_rule, int64_t cnt, float* min_val, float* max_val,
+                                             float* cur_minmax,
                                              int quant_min, int quant_max, int symmetric,
                                              float* scale, void* zero_point, int zp_type,
                                              float* y, int64_t n, int mode, float grad_factor,
@@ -1636,7 +1688,7 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
         OSQ_REQUIRE(!prune || (percentile >= 0.0 && percentile <= 1.0), "observe_tokens_fake_quant: percentile outside [0, 1]");
         OSQ_REQUIRE(check_finish_args(update_rule, min_val, max_val, &why), why);
         OSQ_REQUIRE(quant_max > quant_min, "observe_tokens_fake_quant: quant_max must exceed quant_min");
-        const Finish fin{update_rule, cnt, min_val, max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
+        const Finish fin{update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric, scale, zero_point, zp_type};
         const FusedArgs a{x, y, v.batch, v.tokens, lengths, token_min, token_max, prune, static_cast<float>(percentile),
                           g_select_shortcut, static_cast<FusedState*>(Workspace(workspace).fused()), scale, zero_point,
                           zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), g_fused_gate, g_select_hint,
@@ -1652,7 +1704,7 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
         if (launched) return check_launch("observe_tokens_fake_quant(fused)");
     }
     const int rc = osq_observe_tokens(x, view, lengths, token_min, token_max, prune, percentile, update_rule, cnt, min_val,
-                                      max_val, nullptr, quant_min, quant_max, symmetric, scale, zero_point, zp_type, workspace,
+                                      max_val, cur_minmax, quant_min, quant_max, symmetric, scale, zero_point, zp_type, workspace,
                                       list_scratch, stream);
     if (rc != OSQ_OK) return rc;
     return osq_fake_quant_per_tensor(x, y, nullptr, n, scale, zero_point, zp_type, mode, grad_factor, quant_min, quant_max,
@@ -1691,12 +1743,20 @@ extern "C" int osq_persistent_status(void* workspace, int* fused_status_out, int
     FusedState* fs = static_cast<FusedState*>(ws.fused());
     unsigned int* rs_status = reinterpret_cast<unsigned int*>(static_cast<char*>(ws.resident()) + 64);   // ResidentState::status (msefast.hip)
     hipStream_t st = static_cast<hipStream_t>(stream);
-    unsigned int f = 0u, r = 0u;
+    OneLaunchState* ol = static_cast<OneLaunchState*>(ws.onelaunch());
+    unsigned int f = 0u, r = 0u, o = 0u;
     if (hipMemcpyAsync(&f, &fs->status, sizeof(f), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(&r, rs_status, sizeof(r), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&o, &ol->status, sizeof(o), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
         set_error("persistent_status: copy failed");
         return OSQ_ERR_HIP;
+    }
+    if (o) {          // a selector of the one-launch observation gave up waiting: reported with the fused family (bit 2), its slice wiped
+        if (hipMemsetAsync(ol, 0, kWsOneLaunchBytes, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            set_error("persistent_status: reset failed");
+            return OSQ_ERR_HIP;
+        }
     }
     if (f || r) {
         hipError_t e = hipSuccess;
@@ -1712,7 +1772,7 @@ extern "C" int osq_persistent_status(void* workspace, int* fused_status_out, int
             return OSQ_ERR_HIP;
         }
     }
-    *fused_status_out = static_cast<int>(f);
+    *fused_status_out = static_cast<int>(f | (o ? 4u : 0u));
     *resident_status_out = static_cast<int>(r);
     return OSQ_OK;
 }

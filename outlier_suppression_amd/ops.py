@@ -501,9 +501,10 @@ def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, m
 
 
 def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, max_val, quant_min, quant_max,
-                              symmetric, scale, zero_point, mode, grad_factor):
+                              symmetric, scale, zero_point, mode, grad_factor, cur=None):
     """A whole quantizer call (observe the masked activation, refresh scale / zero_point, fake-quantise) behind ONE
-    call of the binding.  x: dense fp32 on the device.  Returns (y, batch, tokens, lengths_int64)."""
+    call of the binding.  x: dense fp32 on the device.  cur: 2-float device slot that also receives this batch's own
+    (min, max) while the running statistic moves as usual.  Returns (y, batch, tokens, lengths_int64)."""
     lib = _hip._lib or _hip.load()
     if not (lengths.is_cuda and scale.is_cuda and zero_point.is_cuda and min_val.is_cuda):
         _hip.require_device(x, lengths, scale, zero_point, min_val, max_val)
@@ -518,7 +519,8 @@ def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt,
     y = torch.empty_like(x)
     rc = lib.osq_observe_tokens_fake_quant(x.data_ptr(), ctypes.byref(view), lengths.data_ptr(), tmin.data_ptr(), tmax.data_ptr(),
                                            1 if prune else 0, float(percentile) if prune else 1.0, rule, cnt,
-                                           min_val.data_ptr(), max_val.data_ptr(), quant_min, quant_max, 1 if symmetric else 0,
+                                           min_val.data_ptr(), max_val.data_ptr(), None if cur is None else cur.data_ptr(),
+                                           quant_min, quant_max, 1 if symmetric else 0,
                                            scale.data_ptr(), zero_point.data_ptr(), _zp_type(zero_point), y.data_ptr(), x.numel(),
                                            mode, grad_factor, _hip.workspace(dev).data_ptr(),
                                            lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))

@@ -117,7 +117,8 @@ class QuantizeBase(nn.Module):
         gf = self._grad_factor(X) if self.param_mode != PARAM_FIXED else 1.0
         y, batch, tokens, lengths = ops.observe_tokens_fake_quant(
             X, seq_pos, observation_mask, prune, getattr(obs, "percentile", 1.0), obs.update_rule, obs._counter(),
-            obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric, scale, zero_point, self.param_mode, gf)
+            obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric, scale, zero_point, self.param_mode, gf,
+            obs.__dict__.get("_record"))
         object.__setattr__(obs, "_last_site", ("tokens", batch, tokens, lengths))
         obs._bump()
         return y

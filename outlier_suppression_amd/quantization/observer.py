@@ -45,6 +45,7 @@ class ObserverBase(nn.Module):
         self.register_buffer("min_val", torch.tensor(float("inf")))
         self.register_buffer("max_val", torch.tensor(float("-inf")))
         self._capture = None   # sharded calibration: 2-float device slot that receives this batch's (min, max)
+        self._record = None    # one-call observe + quantize: slot that ALSO receives the batch's (min, max) (the running state still moves)
         self._token_cache = None   # cached grid search: (token_min, token_max) rows that receive the per-token extrema
         self._last_site = None     # ("tokens", batch, tokens, lengths) or ("flat",) of the most recent observation
 

@@ -352,8 +352,38 @@ def test_bench_self_launch_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
     assert out["collective"]["ranks_seen"] == 2 and out["collective"]["world_size"] == 2
+    # the exchange moved the rows the timed steps recorded, and they replay to the one-process statistic on every rank
+    chk = out["collective"]["exchange_check"]
+    assert chk["rows_gathered"] == 10 and chk["replay_equals_one_process_loop"] and chk["same_bits_on_every_rank"] and chk["own_rows_intact"], chk
     # without the hook and without a second device the command must refuse, loudly, instead of measuring something else
     if torch.cuda.device_count() < 2:
         env.pop("OSQ_BENCH_SHARE_GPU")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "visible HIP devices" in r.stderr
+
+
+def test_bench_self_launch_eight_ranks_with_sharded_calibration():
+    """The command the driver runs on an 8-GPU node, on this one-GPU box through the shared-GPU hook (gloo; eight processes
+    on one device): `bench.py --gpus 8` with BASELINE configs[2]'s calibration (BERT-base SQuAD, T = 384) sharded over the
+    eight ranks.  Inside the run every rank asserts that the rows exchanged after the timed steps replay to the
+    one-process running mean (bench.py raises otherwise); here: rc 0, one JSON line, eight distinct ranks seen, the
+    check's verdicts, and the calibration section carrying wall_s / collective_s at the launched N."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    env = dict(os.environ, OSQ_BENCH_SHARE_GPU="1", OSQ_BENCH_SQUAD_CANDIDATES="3")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--settle", "0.1",
+                        "--calib-configs", "2", "--no-kernel-table", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["collective"]["ranks_seen"] == 8
+    chk = out["collective"]["exchange_check"]
+    assert chk["rows_gathered"] == 32 and chk["replay_equals_one_process_loop"] and chk["same_bits_on_every_rank"] and chk["own_rows_intact"], chk
+    cal = out["calibration_config2"]
+    assert "error" not in cal, cal
+    assert cal["n_gpus"] == 8 and cal["wall_s"] > 0 and cal["collective_s"] >= 0, cal

@@ -1,7 +1,4 @@
-python -m pytest tests/test_gpu_strict_order.py tests/test_gpu_site_size.py -q --durations=12 2>&1 | tail -45
-for m in "" "--eager" "" "--eager"; do python bench.py --steps 20 --warmup 5 --no-calib --no-kernel-table --no-cpu-baseline $m 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('MODE [$m]', d['ms_per_step'], 'eager', d['config']['eager_ms_per_step'], 'host', d['config']['host_enqueue_ms_per_step'], 'kernel', d['roofline']['avg_launch_us'])
-"; done
+# scratch command file for gpurun calls (rewritten per call)
+mkdir -p gpurun_out/r04_parity
+OSQ_REPORT_BASE=1 OSQ_PARITY_REPORT_DIR=gpurun_out/r04_parity python -m pytest tests/test_gpu_model_base.py -q -x -s 2>&1 | grep -E "bert-base|passed|failed|Error|assert" | head -40
+python -m pytest tests -q -m gpu -x --deselect tests/test_gpu_model_base.py 2>&1 | tail -5

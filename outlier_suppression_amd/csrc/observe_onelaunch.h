@@ -88,7 +88,7 @@ struct alignas(16) OlSelShared {
 };
 struct OlStreamShared {
     float val[2][kOlGroupTokens];
-    unsigned int mask[2], nc[2], bad;
+    unsigned int mask[2][kOlWaves], nc[2][kOlWaves], bad[kOlWaves];
 };
 union OlShared {
     OlSelShared sel;
@@ -108,22 +108,16 @@ __device__ __forceinline__ void ol_stream(const OneLaunchArgs& a, const Finish& 
     // chunk index rotated by the sample index: see token_minmax_vec_kernel (XCD balance)
     const int64_t chunk = (static_cast<int64_t>(blockIdx.x) + b) % gridDim.x;
     if (chunk * kOlGroupTokens >= len) return;                   // nothing valid here: the selectors know it from the lengths
-    const unsigned int tag = uniform(__hip_atomic_load(&a.st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+#ifdef OSQ_FINAL_TIMING
+    const long long dbg_t0 = wall_clock64();
+#endif
+    // the launch's tag and the pivots are only needed behind the streaming: their loads travel with it
+    const unsigned int epoch = __hip_atomic_load(&a.st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool have_state = fin.rule != OSQ_UPDATE_NONE && fin.min_val && fin.max_val;
-    unsigned int pivot[2];
-    {
-        const float h0 = have_state ? fin.max_val[0] : 0.0f, h1 = have_state ? -fin.min_val[0] : 0.0f;
-        pivot[0] = uniform(ol_pivot_key(h0, a.prune, have_state && a.use_hint));
-        pivot[1] = uniform(ol_pivot_key(h1, a.prune, have_state && a.use_hint));
-    }
-    if (tid == 0) {
-        S.mask[0] = S.mask[1] = 0u;
-        S.nc[0] = S.nc[1] = ordered_bits(-__builtin_inff());
-        S.bad = 0u;
-    }
-    __syncthreads();
+    const float h0 = have_state ? fin.max_val[0] : 0.0f, h1 = have_state ? -fin.min_val[0] : 0.0f;
     const int64_t t0 = chunk * kOlGroupTokens + w * kTokPerWave;
     const int64_t group = b * a.chunks + chunk;
+    unsigned int m[2] = {0u, 0u}, nc[2] = {ordered_bits(-__builtin_inff()), ordered_bits(-__builtin_inff())}, wbad = 0u;
     if (t0 < len) {
         const int ntok = (len - t0) < kTokPerWave ? static_cast<int>(len - t0) : kTokPerWave;
         const float* base = a.x + b * a.v.stride_batch + t0 * a.v.stride_token;
@@ -139,27 +133,32 @@ __device__ __forceinline__ void ol_stream(const OneLaunchArgs& a, const Finish& 
             publish_f32(&a.tok_min[slot], mn);
             publish_f32(&a.tok_max[slot], mx);
         }
+        const unsigned int pivot[2] = {uniform(ol_pivot_key(h0, a.prune, have_state && a.use_hint)),
+                                       uniform(ol_pivot_key(h1, a.prune, have_state && a.use_hint))};
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const float xs = side ? -mn : mx;                    // a poisoned token is NaN on both sides
             const bool isnan = xs != xs;
             const bool cand = mine && !isnan && abs_key(xs) >= pivot[side];
             if (mine) S.val[side][w * kTokPerWave + lane] = xs;
-            const unsigned int m = static_cast<unsigned int>(__ballot(cand)) & 0xfu;
-            const float others = wave_max((mine && !isnan && !cand) ? xs : -__builtin_inff());
-            const bool any_nan = wave_any(mine && isnan);
-            if (lane == 0) {
-                if (m) atomicOr(&S.mask[side], m << (w * kTokPerWave));
-                atomicMax(&S.nc[side], ordered_bits(others));
-                if (any_nan) atomicOr(&S.bad, 1u << side);
-            }
+            m[side] = (static_cast<unsigned int>(__ballot(cand)) & 0xfu) << (w * kTokPerWave);
+            nc[side] = ordered_bits(wave_max((mine && !isnan && !cand) ? xs : -__builtin_inff()));
+            if (wave_any(mine && isnan)) wbad |= 1u << side;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the token arrays are in memory before the record says so
+    }
+    if (lane == 0) {                                             // every wave leaves its part: nothing to initialise, no atomics
+        S.mask[0][w] = m[0]; S.mask[1][w] = m[1];
+        S.nc[0][w] = nc[0]; S.nc[1][w] = nc[1];
+        S.bad[w] = wbad;
     }
     __syncthreads();
     if (tid < 2) {
         const int side = tid;
-        const unsigned int mask = S.mask[side];
+        const unsigned int tag = epoch + 1u;
+        const unsigned int mask = S.mask[side][0] | S.mask[side][1] | S.mask[side][2] | S.mask[side][3];
+        const unsigned int ncm = max(max(S.nc[side][0], S.nc[side][1]), max(S.nc[side][2], S.nc[side][3]));
+        const unsigned int badm = S.bad[0] | S.bad[1] | S.bad[2] | S.bad[3];
         float first[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned int rest = mask;
 #pragma unroll
@@ -172,12 +171,16 @@ __device__ __forceinline__ void ol_stream(const OneLaunchArgs& a, const Finish& 
         }
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(&a.st->rec[side][0][0], 0, static_cast<int>(sizeof(a.st->rec[side])), 0x00020000);
         osq_v4u32 ha, hb;
-        ha.x = tag; ha.y = mask | (((S.bad >> side) & 1u) << 16); ha.z = __float_as_uint(from_ordered_bits(S.nc[side])); ha.w = __float_as_uint(first[0]);
+        ha.x = tag; ha.y = mask | (((badm >> side) & 1u) << 16); ha.z = __float_as_uint(from_ordered_bits(ncm)); ha.w = __float_as_uint(first[0]);
         hb.x = tag; hb.y = __float_as_uint(first[1]); hb.z = __float_as_uint(first[2]); hb.w = __float_as_uint(first[3]);
         const unsigned int off = static_cast<unsigned int>(group) * 32u;
         __builtin_amdgcn_raw_buffer_store_b128(ha, rs, off, 0, 16 /* sc1 */);
         __builtin_amdgcn_raw_buffer_store_b128(hb, rs, off + 16u, 0, 16 /* sc1 */);
     }
+#ifdef OSQ_FINAL_TIMING
+    if (tid == 0 && (blockIdx.y == 1 || blockIdx.y == gridDim.y - 1 || blockIdx.y == gridDim.y / 2) && blockIdx.x < 2)
+        printf("[onelaunch] stream block (%u,%u) start %lld end %lld (%.2f us)\n", blockIdx.x, blockIdx.y, dbg_t0, wall_clock64(), (wall_clock64() - dbg_t0) / 100.0);
+#endif
 }
 
 // ---------------------------------------------------------------- selecting workgroup (blockIdx = (side, 0))
@@ -380,6 +383,14 @@ __device__ __forceinline__ void ol_reset_search(OlSelShared& S) {
 __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& fin, OlSelShared& S) {
     const int side = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
+#ifdef OSQ_FINAL_TIMING
+    long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int dbg_sweeps = 0u;
+#define OSQ_OLSTAMP(k) do { ts[k] = wall_clock64(); } while (0)
+#else
+#define OSQ_OLSTAMP(k) do { } while (0)
+#endif
+    OSQ_OLSTAMP(0);
     const unsigned int B = static_cast<unsigned int>(a.v.batch), T = static_cast<unsigned int>(a.v.tokens);
     const unsigned int chunks = static_cast<unsigned int>(a.chunks), groups = B * chunks;
     const unsigned int flip = side ? 0x80000000u : 0u;
@@ -407,12 +418,14 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
         if (side == 0 && tid == 0) __hip_atomic_store(&a.st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    // ---- gather: thread t owns groups t * per .. t * per + per - 1; bit j of `pending`: group j still has to arrive
-    const unsigned int per = (groups + kOlThreads - 1) / kOlThreads;           // <= 16
-    const unsigned int g0 = static_cast<unsigned int>(tid) * per;
+    // ---- gather.  Thread t owns groups j * 256 + t (j < per <= 16; bit j of `pending`: that group still has to arrive):
+    // a wave's 64 groups of one j are neighbours in dispatch order, so they tend to arrive together -- and the late
+    // sweeps only revisit the last j.  Everything below the uniform `wave_any` tests is per lane: LDS atomics on one
+    // address are serialised by the LDS itself at a lane per clock, cheaper than a ballot-and-prefix per value.
+    const unsigned int per = (groups + kOlThreads - 1) / kOlThreads;
     unsigned int pending = 0u;
     for (unsigned int j = 0; j < per; ++j) {
-        const unsigned int g = g0 + j;
+        const unsigned int g = j * kOlThreads + static_cast<unsigned int>(tid);
         if (g < groups) {
             const unsigned int bb = g / chunks, c = g - bb * chunks;
             if (static_cast<int>(c * kOlGroupTokens) < S.lens[bb]) pending |= 1u << j;
@@ -423,68 +436,66 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
     float plain = -__builtin_inff(), others = -__builtin_inff();
     unsigned int kmin = 0xffffffffu, kmax = 0u;
     bool bad = false, timed_out = false;
-    auto absorb = [&](const bool has, const float x) {            // wave-uniform call; `has`: this lane brings a candidate
-        const unsigned long long m = __ballot(has);
-        if (m == 0ull) return;
-        unsigned int basepos = 0u;
-        const int leader = __builtin_ctzll(m);
-        if (lane == leader) basepos = atomicAdd(&S.s_count, static_cast<unsigned int>(__builtin_popcountll(m)));
-        basepos = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(basepos), leader));
-        if (has) {
-            const unsigned int key = abs_key(x), pos = basepos + ol_lanes_below(m);
-            plain = fmaxf(plain, x);
-            kmin = min(kmin, key);
-            kmax = max(kmax, key);
-            if (pos < static_cast<unsigned int>(kOlListCap)) S.list[pos] = __float_as_uint(x);
-            if (window) {
-                const unsigned int d = key - pivot;
-                if (d < (1u << 23)) atomicAdd(&S.hist[d >> (23 - kOlBinBits)], 1u);
-            }
+    auto absorb = [&](const float x) {                             // one candidate of this lane
+        const unsigned int key = abs_key(x);
+        plain = fmaxf(plain, x);
+        kmin = min(kmin, key);
+        kmax = max(kmax, key);
+        const unsigned int pos = atomicAdd(&S.s_count, 1u);
+        if (pos < static_cast<unsigned int>(kOlListCap)) S.list[pos] = __float_as_uint(x);
+        if (window) {
+            const unsigned int d = key - pivot;
+            if (d < (1u << 23)) atomicAdd(&S.hist[d >> (23 - kOlBinBits)], 1u);
         }
     };
-    unsigned int spins = 0u;
-    while (wave_any(pending != 0u)) {
-        if (++spins > a.spin_limit) { timed_out = true; break; }
-        bool progress = false;
-        for (unsigned int j = 0; j < per; ++j) {
-            const bool want = (pending >> j) & 1u;
-            if (!wave_any(want)) continue;
-            osq_v4u32 ra = {0u, 0u, 0u, 0u}, rb = {0u, 0u, 0u, 0u};
-            if (want) {
-                ra = __builtin_amdgcn_raw_buffer_load_b128(recs, (g0 + j) * 32u, 0, 16 /* sc1 */);
-                rb = __builtin_amdgcn_raw_buffer_load_b128(recs, (g0 + j) * 32u + 16u, 0, 16 /* sc1 */);
-            }
-            const bool ready = want && ra.x == tag && rb.x == tag;
-            if (!wave_any(ready)) continue;
-            progress = true;
-            const unsigned int mask = ready ? (ra.y & 0xffffu) : 0u;
+    auto take = [&](const unsigned int j, const bool want, const osq_v4u32& ra, const osq_v4u32& rb) -> bool {
+        const bool ready = want && ra.x == tag && rb.x == tag;      // both halves carry this launch's tag
+        if (ready) {
+            pending &= ~(1u << j);
+            bad |= ((ra.y >> 16) & 1u) != 0u;
+            others = fmaxf(others, __uint_as_float(ra.z));
+            const unsigned int mask = ra.y & 0xffffu;
             const unsigned int cnt = static_cast<unsigned int>(__builtin_popcount(mask));
-            const bool more = cnt > 4u;
-            if (ready) {
-                bad |= ((ra.y >> 16) & 1u) != 0u;
-                others = fmaxf(others, __uint_as_float(ra.z));
-                pending &= ~(1u << j);
-            }
-            absorb(ready && !more && cnt > 0u, __uint_as_float(ra.w));
-            absorb(ready && !more && cnt > 1u, __uint_as_float(rb.y));
-            absorb(ready && !more && cnt > 2u, __uint_as_float(rb.z));
-            absorb(ready && !more && cnt > 3u, __uint_as_float(rb.w));
-            if (wave_any(more)) {                                  // more than four candidates: they are picked from the token array
+            if (cnt <= 4u) {
+                if (cnt > 0u) absorb(__uint_as_float(ra.w));
+                if (cnt > 1u) absorb(__uint_as_float(rb.y));
+                if (cnt > 2u) absorb(__uint_as_float(rb.z));
+                if (cnt > 3u) absorb(__uint_as_float(rb.w));
+            } else {                                               // more than four candidates: picked from the token array
+                const unsigned int g = j * kOlThreads + static_cast<unsigned int>(tid);
                 osq_v4u32 tk[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    tk[u] = osq_v4u32{0u, 0u, 0u, 0u};
-                    if (more) tk[u] = __builtin_amdgcn_raw_buffer_load_b128(toks, (g0 + j) * 64u + u * 16u, 0, 16 /* sc1 */);
-                }
+                for (int u = 0; u < 4; ++u) tk[u] = __builtin_amdgcn_raw_buffer_load_b128(toks, g * 64u + u * 16u, 0, 16 /* sc1 */);
 #pragma unroll
                 for (int k = 0; k < kOlGroupTokens; ++k) {
                     const unsigned int raw = (k & 3) == 0 ? tk[k >> 2].x : (k & 3) == 1 ? tk[k >> 2].y : (k & 3) == 2 ? tk[k >> 2].z : tk[k >> 2].w;
-                    absorb(more && ((mask >> k) & 1u), __uint_as_float(raw ^ flip));
+                    if ((mask >> k) & 1u) absorb(__uint_as_float(raw ^ flip));
                 }
             }
         }
+        return ready;
+    };
+    unsigned int spins = 0u;
+    OSQ_OLSTAMP(1);
+    while (wave_any(pending != 0u)) {
+        if (++spins > a.spin_limit) { timed_out = true; break; }
+        bool progress = false;
+#ifdef OSQ_FINAL_TIMING
+        ++dbg_sweeps;
+#endif
+        for (unsigned int j = 0; j < per; j += 2u) {                // two groups' records in flight per lane
+            const bool w0 = ((pending >> j) & 1u) != 0u, w1 = ((pending >> (j + 1u)) & 1u) != 0u;
+            if (!wave_any(w0 || w1)) continue;
+            osq_v4u32 a0 = {0u, 0u, 0u, 0u}, b0 = a0, a1 = a0, b1 = a0;
+            const unsigned int off0 = (j * kOlThreads + static_cast<unsigned int>(tid)) * 32u, off1 = off0 + kOlThreads * 32u;
+            if (w0) { a0 = __builtin_amdgcn_raw_buffer_load_b128(recs, off0, 0, 16 /* sc1 */); b0 = __builtin_amdgcn_raw_buffer_load_b128(recs, off0 + 16u, 0, 16); }
+            if (w1) { a1 = __builtin_amdgcn_raw_buffer_load_b128(recs, off1, 0, 16 /* sc1 */); b1 = __builtin_amdgcn_raw_buffer_load_b128(recs, off1 + 16u, 0, 16); }
+            const bool r0 = take(j, w0, a0, b0), r1 = take(j + 1u, w1, a1, b1);
+            progress |= wave_any(r0 || r1);
+        }
         if (!progress) __builtin_amdgcn_s_sleep(2);
     }
+    OSQ_OLSTAMP(2);
     // ---- fold the waves' partials
     plain = wave_max(plain);
     others = wave_max(others);
@@ -519,16 +530,26 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
     kmax = uniform(kmax);
     float result = fmaxf(from_ordered_bits(uniform(o_plain)), others_max);        // the plain maximum of the side
     if (gave_up && tid == 0) __hip_atomic_fetch_or(&a.st->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    OSQ_OLSTAMP(3);
+#ifdef OSQ_FINAL_TIMING
+    int dbg_mode = 0;
+#endif
     if (a.prune && !any_bad) {
         const bool list_ok = M <= static_cast<unsigned int>(kOlListCap);
         OlSource src{false, &S, M, toks, B * T, T, chunks, flip};
         bool missed = true;
         if (list_ok && window) result = ol_search(src, S, N, N - M, a.q, true, pivot, kmin, kmax, others_max, a.shortcut, &missed);
         if (missed && list_ok && M > 0u) {              // the rank lies above the window, or there is no window: full-range levels over the list
+#ifdef OSQ_FINAL_TIMING
+            dbg_mode = 1;
+#endif
             ol_reset_search(S);
             result = ol_search(src, S, N, N - M, a.q, false, 0u, kmin, kmax, others_max, a.shortcut, &missed);
         }
         if (missed) {                                   // the rank lies among the non-candidates, or the list overflowed: the token array
+#ifdef OSQ_FINAL_TIMING
+            dbg_mode = 2;
+#endif
             ol_reset_search(S);
             src.memory = true;
             unsigned int lo = 0xffffffffu, hi = 0u;
@@ -542,6 +563,7 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
             result = ol_search(src, S, N, 0u, a.q, false, 0u, uniform(lo), uniform(hi), others_max, a.shortcut, &missed);
         }
     }
+    OSQ_OLSTAMP(4);
     if (tid == 0) {
         const SideResult r{result, any_bad, false};
         float cur_min, cur_max;
@@ -550,6 +572,14 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
             __hip_atomic_store(&a.st->epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef OSQ_FINAL_TIMING
+    OSQ_OLSTAMP(5);
+    if (tid == 0)
+        printf("[onelaunch] side %d entry %lld: setup %.2f gather %.2f (%u sweeps, per %u) fold %.2f search %.2f (mode %d, N %u, M %u) meet %.2f total %.2f us\n",
+               side, ts[0], (ts[1] - ts[0]) / 100.0, (ts[2] - ts[1]) / 100.0, dbg_sweeps, per, (ts[3] - ts[2]) / 100.0, (ts[4] - ts[3]) / 100.0,
+               dbg_mode, N, M, (ts[5] - ts[4]) / 100.0, (ts[5] - ts[0]) / 100.0);
+#endif
+#undef OSQ_OLSTAMP
 }
 
 template <bool SINGLE_SEGMENT, bool NT>

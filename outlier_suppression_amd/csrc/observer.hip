@@ -899,7 +899,7 @@ static int64_t g_wide_min_slots = 32769;
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
 static int g_obs_blocks = 768;
 static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
-static int g_onelaunch = 1;            // osq_set_tuning("observe_onelaunch", 0): masked observations as two launches (token_minmax, token_select)
+static int g_onelaunch = 0;            // osq_set_tuning("observe_onelaunch", 1): masked observations as ONE launch (observe_onelaunch.h).  OFF by default: measured slower than the two launches at every size (profiles/r04_onelaunch_ab.txt)
 static int g_onelaunch_hint = 1;       // osq_set_tuning("observe_hint", 0): the one-launch observation without its pivot (every token a candidate; tests)
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)

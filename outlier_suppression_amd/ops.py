@@ -497,6 +497,7 @@ def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, m
                                 lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))
     if rc != 0:
         _hip.check(rc, "observe_tokens")
+    _persistent_dirty.add((dev.index, _hip.raw_stream(dev)))      # the one-launch form's selectors wait (bounded) for records
     return view.batch, view.tokens, lengths
 
 

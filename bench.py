@@ -328,6 +328,12 @@ def kernel_table(dev, xs, lengths, reps=20):
     return rows
 
 
+# OSQ_BENCH_SHORT=1: the calibration flows with 2 batches, 3 candidates and 1 learn-scale epoch, run once -- the same kernels
+# in the same states, a few thousand dispatches instead of a few hundred thousand: what the PMC passes of
+# tools/collect_calibration_profiles.sh profile (rocprofv3 --pmc costs milliseconds per dispatch).  Never a measured wall-clock.
+SHORT = os.environ.get("OSQ_BENCH_SHORT") == "1"
+
+
 def calibration_wall_clock(dev, rank, world, search="cached"):
     """BASELINE configs[1]: BERT-base (random init, HF default config), CoLA-shaped calibration set
     (256 samples = 8 batches of [32, 128], synthetic ids / lengths), twc_fine_gamma W6A6:
@@ -352,7 +358,7 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
     cfg = BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     fp = BertForSequenceClassification(cfg).eval().to(dev)
     g = torch.Generator().manual_seed(42)
-    n_batches, B, T = 8, 32, 128
+    n_batches, B, T = (2 if SHORT else 8), 32, 128
     batches = []
     for _ in range(n_batches):
         L = torch.randint(8, T + 1, (B,), generator=g)
@@ -396,7 +402,7 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         disable_all(m)
         set_observer_name(m)
         sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter()
-        grid = {"iters": 30, "step": 0.01}       # cac_step_iters(6 bit, bs 32, T 128), token_wise_clipping.py:118-129
+        grid = {"iters": 3 if SHORT else 30, "step": 0.01}       # cac_step_iters(6 bit, bs 32, T 128), token_wise_clipping.py:118-129
         if search == "cached":
             ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid,
                                           n_batches=n_batches)
@@ -404,9 +410,13 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
             ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
         sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
         # N > 1: every Adam step is split inside the batch (32/N samples per rank, averaged gradients)
-        (TWC.learn_scale if strict_learn else TWC.learn_scale_sharded)(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 3})
+        (TWC.learn_scale if strict_learn else TWC.learn_scale_sharded)(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
         sync(); phases["learn_scale"] = time.perf_counter() - t0
         return time.perf_counter() - t_start, phases, ratio
+
+    if SHORT:
+        wall, phases, ratio = run(search)
+        return {"config": "configs[1] SHORT (profiling only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
 
     # The whole calibration runs twice on fresh copies of the model: the first pass also pays the process's one-time
     # costs (rocBLAS / hipBLASLt kernel loading and heuristics for forward and backward shapes, allocator growth,
@@ -550,11 +560,11 @@ def calibration_extra(dev, rank, world, which):
     if which == 2:
         cfg = T.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
         fp = T.BertForQuestionAnswering(cfg).eval().to(dev)
-        batches = masked_batches(8, 32, 384, 30522, 64)
+        batches = masked_batches(2 if SHORT else 8, 32, 384, 30522, 64)
         for b in batches:
             b["token_type_ids"] = torch.zeros_like(b["input_ids"])
         # OSQ_BENCH_SQUAD_CANDIDATES: test hook (tests/test_gpu_sharded.py runs eight ranks on one GPU); the measured config has 90
-        task, mtype, grid = "squad", "bert", {"iters": int(os.environ.get("OSQ_BENCH_SQUAD_CANDIDATES", "90")), "step": 0.0033}
+        task, mtype, grid = "squad", "bert", {"iters": int(os.environ.get("OSQ_BENCH_SQUAD_CANDIDATES", "3" if SHORT else "90")), "step": 0.0033}
         out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
     elif which in (4, 5):
         # 4: bart-base dimensions, what the reference's shipped config points at (exp/xsum/twc_fine_gamma/config.yaml:44);
@@ -564,14 +574,14 @@ def calibration_extra(dev, rank, world, which):
                            decoder_attention_heads=heads, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, max_position_embeddings=1024,
                            dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
         fp = T.BartForConditionalGeneration(cfg).eval().to(dev)
-        batches = masked_batches(64, 4, 1024, 50265, 256)
+        batches = masked_batches(4 if SHORT else 64, 4, 1024, 50265, 256)
         for b in batches:
             DL = torch.randint(16, 63, (4,), generator=g)
             DL[0] = 62
             dm = (torch.arange(62)[None, :] < DL[:, None]).long()
             b["decoder_input_ids"] = (torch.randint(1000, 49000, (4, 62), generator=g) * dm + (1 - dm)).to(dev)
             b["decoder_attention_mask"] = dm.to(dev)
-        task, mtype, grid = "summ", "bart", {"iters": 30, "step": 0.01}
+        task, mtype, grid = "summ", "bart", {"iters": 3 if SHORT else 30, "step": 0.01}
         out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, " +
                          ("bart-base dimensions (the reference's shipped config)" if which == 4 else
                           "bart-LARGE dimensions (d 1024, 16 heads, 12 + 12 layers, ffn 4096: what BASELINE.json names)") +
@@ -580,7 +590,7 @@ def calibration_extra(dev, rank, world, which):
         cfg = T.RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, num_labels=3,
                               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
         fp = T.RobertaForSequenceClassification(cfg).eval().to(dev)
-        batches = masked_batches(8, 32, 128, 50265, 8)
+        batches = masked_batches(2 if SHORT else 8, 32, 128, 50265, 8)
         w_q = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
         a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)
         from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
@@ -601,6 +611,9 @@ def calibration_extra(dev, rank, world, which):
             sync(); phases["activation_calibration_msefast_per_tensor"] = time.perf_counter() - t0
             return time.perf_counter() - t_start, phases, info_w, info_a, model
 
+        if SHORT:
+            wall, phases, info_w, info_a, model = run_once()
+            return {"config": "configs[3] SHORT (profiling only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
         first_wall = run_once()[0]    # the second run is the steady state (code objects loaded, allocator grown, communicator built)
         wall, phases, info_w, info_a, model = run_once()
         # the STRICT switch (outlier_suppression_amd.set_strict: every per-tensor loss added in the reference's one-thread
@@ -679,7 +692,7 @@ def calibration_extra(dev, rank, world, which):
             learn_in, learn_out = small, targets(small)
         else:
             learn_in, learn_out = batches, fp_output
-        TWC.learn_scale_sharded(NS(model=m), learn_in, learn_out, {"lr": 1e-5, "epoch": 3})
+        TWC.learn_scale_sharded(NS(model=m), learn_in, learn_out, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
         sync(); phases["learn_scale"] = time.perf_counter() - t0
         out.update({"wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
                     "collective_s": round(gather_s[0], 4), "best_percentile": ratio, "twc_candidates": grid["iters"],
@@ -1119,16 +1132,28 @@ def main():
     k_avg_ms = sum(k_ms) / len(k_ms)
     probe_bytes = bytes_step if fused_on else 8 * n_elem
     achieved = probe_bytes / (k_avg_ms * 1e-3) / 1e9
+    # roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate
+    # rocprofv3 passes: tools/collect_profiles.sh).  Counters cannot be read from inside this process, so the figure comes
+    # from the committed profile -- but only while that profile was taken from the SAME kernel sources: the file carries the
+    # hash of the sources it measured, and a mismatch reports null with the reason instead of a number that went stale
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
-            table_j = json.load(open(tpath))      # PMC passes of tools/collect_profiles.sh, committed under profiles/
-            traffic = next((v.get("hbm_bytes_per_launch") for k, v in table_j.items()
-                            if k.startswith("observe_fq_fused_kernel" if fused_on else "fq_tensor_vec_kernel") and isinstance(v, dict)), None)
-            traffic_source = "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)"
-        except Exception:
-            traffic = None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from summarize_profiles import kernel_sources_sha256
+            table_j = json.load(open(tpath))
+            now, then = kernel_sources_sha256(), table_j.get("_kernel_sources_sha256")
+            if then == now:
+                traffic = next((v.get("hbm_bytes_per_launch") for k, v in table_j.items()
+                                if k.startswith("observe_fq_fused_kernel" if fused_on else "fq_tensor_vec_kernel") and isinstance(v, dict)), None)
+                traffic_source = (f"profiles/roofline_traffic.json ({table_j.get('_profile_tag', '?')}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
+                                  f"same command; kernel sources sha256 {now[:12]} = the ones built here)")
+            else:
+                traffic_source = (f"none: profiles/roofline_traffic.json was measured on other kernel sources (sha256 {str(then)[:12]} vs {now[:12]} here); "
+                                  "re-run tools/collect_profiles.sh")
+        except Exception as e:
+            traffic, traffic_source = None, f"none: {type(e).__name__}: {e}"[:200]
 
     # the same step as three launches (token_minmax, token_select, fake_quant), for reference
     from outlier_suppression_amd import ops

@@ -495,14 +495,21 @@ int osq_observe_quantile(const float* x, int64_t n, const osq_token_view* view, 
 
 /* MSEObserver / AvgMSEObserver (observer.py:285-409): brute-force grid of 100 clipping ranges
  * (1-D, symmetric or one-sided data) or 100 ranges x (quant_max-quant_min+1) zero-points (2-D);
- * 32 candidates are evaluated per pass over the data.  loss_scratch: osq_mse_grid_candidates() floats. */
+ * 32 candidates are evaluated per pass over the data.  loss_scratch: scratch_bytes bytes of device memory; with at least
+ * osq_mse_grid_scratch_bytes() (13 MB for the 6-bit asymmetric grid: the losses + 256 workgroups' partial sums of every
+ * candidate) the whole grid is ONE launch of 1024-thread workgroups + a reduction; with less (>= osq_mse_grid_candidates()
+ * floats) it is one launch per 32 candidates.  The first osq_mse_grid_candidates() floats hold the losses afterwards. */
 int osq_mse_grid_candidates(int quant_min, int quant_max, int two_d);
+size_t osq_mse_grid_scratch_bytes(int quant_min, int quant_max, int two_d);
 int osq_mse_grid_tensor(const float* x, int64_t n, const osq_token_view* view, const int64_t* lengths,
                         const float* cur_minmax, int quant_min, int quant_max, int symmetric,
-                        int one_side, int two_d, float* loss_scratch,
+                        int one_side, int two_d, float* loss_scratch, size_t scratch_bytes,
                         int update_rule, int64_t cnt, float* min_val, float* max_val,
                         float* scale_out, void* zero_point_out, int zp_type,
                         void* workspace, osq_stream stream);
+/* Test aid: the all-candidates launch replaces x / scale by a reciprocal sequence that is bit-equal to the IEEE division under
+ * two guards (csrc/observers_extra.hip, div_by_reciprocal); this counts the admitted pairs (x[i], s[i]) on which the two differ. */
+int osq_selftest_division(const float* x, const float* s, int64_t n, int32_t* mismatches, osq_stream stream);
 /* per-channel form (observer.py:297-301,316-323): one wave per row of w[rows, cols]. */
 int osq_mse_grid_rows(const float* w, int64_t rows, int64_t cols, int quant_min, int quant_max,
                       int symmetric, int one_side, int two_d,

@@ -104,7 +104,9 @@ SIGNATURES = {
     "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "osq_observe_quantile": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _D, _P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "osq_mse_grid_candidates": (_I, [_I, _I, _I]),
-    "osq_mse_grid_tensor": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _I, _I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "osq_mse_grid_scratch_bytes": (ctypes.c_size_t, [_I, _I, _I]),
+    "osq_mse_grid_tensor": (_I, [_P, _L, ctypes.POINTER(TokenView), _P, _P, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "osq_selftest_division": (_I, [_P, _P, _L, _P, _P]),
     "osq_mse_grid_rows": (_I, [_P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
     "osq_gamma_fold": (_I, [_P, _P, _L, _L, _P]),
     "osq_gamma_split_bias": (_I, [_P, _P, _P, _L, _P]),

@@ -870,6 +870,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     else if (osq::set_observer_tuning(key, value)) { }
     else if (osq::set_msefast_tuning(key, value)) { }
     else if (osq::set_layernorm_tuning(key, value)) { }
+    else if (osq::set_extra_tuning(key, value)) { }
     else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
     return OSQ_OK;
 }

@@ -4,6 +4,8 @@
 //   MSEObserver / Avg    observer.py:285-409   brute-force grid: 100 ranges (x zero-points) by MSE
 // All stream the observed tensor (padded tokens skipped); the grid search evaluates 32 candidates per
 // pass over the data instead of one.
+#include <algorithm>
+#include <string>
 #include "osq_device.h"
 #include "osq_host.h"
 
@@ -22,9 +24,10 @@ struct ElemSource {          // either a flat dense tensor or a token view with 
     int vec;
 };
 
-// calls f(value) for every observed element handled by this thread
-template <class F>
-__device__ __forceinline__ void for_each_element(const ElemSource& s, F f) {
+// calls f(value) for every observed element handled by this thread (workgroups of THREADS threads)
+template <int THREADS, class F>
+__device__ __forceinline__ void for_each_element_t(const ElemSource& s, F f) {
+    constexpr int kThreads = THREADS, kWaves = THREADS / OSQ_WAVE;      // shadow the file's 256-thread constants
     if (s.v.batch == 0) {
         const int64_t n4 = s.n / 4;
         const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
@@ -65,6 +68,9 @@ __device__ __forceinline__ void for_each_element(const ElemSource& s, F f) {
         }
     }
 }
+
+template <class F>
+__device__ __forceinline__ void for_each_element(const ElemSource& s, F f) { for_each_element_t<kThreads>(s, f); }
 
 __device__ __forceinline__ double observed_count(const ElemSource& s) {
     if (s.v.batch == 0) return static_cast<double>(s.n);
@@ -265,7 +271,48 @@ __global__ __launch_bounds__(kThreads) void quantile_finalize_kernel(unsigned in
 
 constexpr int kCandBatch = 32;
 
-struct Cand { float lo, hi, scale, zp; };
+struct Cand { float lo, hi, scale, zp, rcp; int fast; };
+
+// x / s for a divisor shared by many dividends, WITHOUT the division: y = RN(1 / s) once, q0 = x * y, then two rounds of
+// (r = x - q * s exactly, by fma; q += r * y).  The second round's result is the correctly rounded quotient -- the bits
+// of the IEEE division -- whenever nothing over- or underflows on the way and the significand of s is not all ones
+// (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, 2nd ed., Theorem 4.9 / section 4.7.2; the float64
+// search of msefast.hip uses the same sequence).  The guards: s in [2^-60, 2^60] with a significand that is not all ones
+// (div_fast_divisor, per candidate), |x| in [2^-60, 2^60] or x == 0 (div_fast_dividend, per element); everything else
+// takes the division.  Five full-rate fma-class instructions instead of v_rcp_f32 (quarter rate) + v_div_scale x 2 + four
+// fma + v_div_fmas + v_div_fixup, whose VCC hand-over also keeps the chains of neighbouring candidates from interleaving:
+// the grid search is VALU-bound on exactly this.  osq_selftest_division compares the two on caller-given operands.
+__device__ __forceinline__ bool div_fast_divisor(float s) {
+    return s >= 8.6736174e-19f && s <= 1.1529215e18f && (__float_as_uint(s) & 0x7fffffu) != 0x7fffffu;      // false for NaN
+}
+__device__ __forceinline__ bool div_fast_dividend(float x) {
+    const float a = fabsf(x);
+    return a <= 1.1529215e18f && (a >= 8.6736174e-19f || a == 0.0f);                                         // false for NaN / inf
+}
+__device__ __forceinline__ float div_by_reciprocal(float x, float s, float y) {
+    const float q0 = x * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s, x), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-q1, s, x), y, q1);
+}
+// the squared error of one element under one candidate (observer.py:292-312), the quotient by either route; `fast` is
+// wave-uniform (every lane's element passes its guard and the candidate passes its own): a real branch, not a select --
+// the division stays out of line so that the compiler cannot fold the two routes into "compute both"
+__device__ __attribute__((noinline)) float grid_true_division(float v, float s) { return v / s; }
+__device__ __forceinline__ float grid_sq_err(float v, bool fast, float scale, float rcp, float zp, float qmin, float qmax) {
+    float u;
+    if (fast) u = div_by_reciprocal(v, scale, rcp);
+    else u = grid_true_division(v, scale);
+    const float r = rintf(u);
+    const float x_int = ((r - u) + u) + zp;
+    float q = x_int;
+    q = (x_int < qmin) ? qmin : q;
+    q = (x_int > qmax) ? qmax : q;
+    const float d = fabsf(dequantize_value(q, scale, zp) - v);
+    return d * d;
+}
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __uint_as_float(static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(v)))));
+}
 
 // candidate k of perform_1D_search / perform_2D_search (observer.py:314-364), fp32 throughout
 __device__ __forceinline__ Cand make_candidate(int k, float x_min, float x_max, int qmin, int qmax, int sym, int side,
@@ -287,6 +334,8 @@ __device__ __forceinline__ Cand make_candidate(int k, float x_min, float x_max, 
     }
     qparams_from_range(c.lo, c.hi, qmin, qmax, sym, &c.scale, &c.zp);
     c.zp = static_cast<float>(static_cast<int>(c.zp));
+    c.rcp = 1.0f / c.scale;
+    c.fast = div_fast_divisor(c.scale) ? 1 : 0;
     return c;
 }
 
@@ -334,6 +383,91 @@ __global__ __launch_bounds__(kThreads) void mse_grid_loss_kernel(ElemSource src,
         __syncthreads();
         if (threadIdx.x == 0) grid_reset(tickets, gridDim.x);
     }
+}
+
+// ALL candidates in ONE launch (round 4).  The launch-per-batch form above runs 200 launches of 256 workgroups x 256
+// threads for the asymmetric grid -- one wave per SIMD, every division chain exposed -- and measured 30 ms on a
+// [32,128,768] site.  Here a workgroup has 1024 threads (16 waves per CU: the chains of four waves overlap on every SIMD),
+// keeps its share of the elements for the whole search and walks the candidates 16 at a time itself: per batch of
+// candidates one block reduction and 16 doubles to partials[workgroup][candidate]; mse_grid_reduce_kernel then adds the
+// workgroups' partials in workgroup order (deterministic) and leaves the losses the commit kernel reads.  Same
+// candidates, same fp32 squared errors, same 16-term fp32 runs inside a float64 sum as above.
+#ifndef OSQ_GRIDALL_THREADS
+#define OSQ_GRIDALL_THREADS 1024
+#endif
+#ifndef OSQ_GRIDALL_CANDS
+#define OSQ_GRIDALL_CANDS 16
+#endif
+#ifndef OSQ_GRIDALL_BARRIER
+#define OSQ_GRIDALL_BARRIER 1
+#endif
+constexpr int kGridAllThreads = OSQ_GRIDALL_THREADS;
+constexpr int kGridAllWaves = kGridAllThreads / OSQ_WAVE;
+constexpr int kGridAllMaxBlocks = 256;
+constexpr int kCandAll = OSQ_GRIDALL_CANDS;          // candidates per trip.  Measured on [32,128,768] / [32,128,3072] (tools/mse_grid_ab.py, ms): 1024 threads x 16: 21.8 / 40.2 (43 spilled VGPRs and still the fastest); 1024 x 8: 56 / 40; 256 x 32: 29 / 78; 512 x 16: 55 / 52; the launch-per-32-candidates form 30.2 / 76
+
+__global__ __launch_bounds__(kGridAllThreads) void mse_grid_all_kernel(ElemSource src, const float* __restrict__ cur_minmax,
+                                                                      GridArgs g, int n_pad, double* __restrict__ partials) {
+    __shared__ Cand cands[kCandAll];
+    __shared__ double sh[kGridAllWaves][kCandAll];
+    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
+    const float qmin = static_cast<float>(g.quant_min), qmax = static_cast<float>(g.quant_max);
+    for (int k0 = 0; k0 < g.n_cand; k0 += kCandAll) {
+        if (threadIdx.x < kCandAll) {
+            const int k = k0 + threadIdx.x < g.n_cand ? k0 + threadIdx.x : g.n_cand - 1;
+            cands[threadIdx.x] = make_candidate(k, cur_minmax[0], cur_minmax[1], g.quant_min, g.quant_max, g.symmetric, g.side,
+                                                g.two_d, g.num);
+        }
+        __syncthreads();
+        float part[kCandAll];
+        double acc[kCandAll];
+        float c_scale[kCandAll], c_rcp[kCandAll], c_zp[kCandAll];      // wave-uniform: scalar registers
+        unsigned int c_fast = 0u;
+#pragma unroll
+        for (int k = 0; k < kCandAll; ++k) {
+            part[k] = 0.0f; acc[k] = 0.0;
+            c_scale[k] = uniform_f32(cands[k].scale); c_rcp[k] = uniform_f32(cands[k].rcp); c_zp[k] = uniform_f32(cands[k].zp);
+            c_fast |= cands[k].fast ? (1u << k) : 0u;
+        }
+        c_fast = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c_fast)));
+        int run = 0;
+        for_each_element_t<kGridAllThreads>(src, [&](float v) {
+            const bool all_ok = !wave_any(!div_fast_dividend(v));          // uniform: one ballot per element, shared by the candidates
+#pragma unroll
+            for (int k = 0; k < kCandAll; ++k)
+                part[k] += grid_sq_err(v, all_ok && ((c_fast >> k) & 1u), c_scale[k], c_rcp[k], c_zp[k], qmin, qmax);
+            if (OSQ_GRIDALL_BARRIER) __builtin_amdgcn_sched_barrier(0);   // one value's chains at a time: interleaving several costs the registers
+            if (++run == 16) {
+#pragma unroll
+                for (int k = 0; k < kCandAll; ++k) { acc[k] += part[k]; part[k] = 0.0f; }
+                run = 0;
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < kCandAll; ++k) {
+            const double v = wave_sum(acc[k] + static_cast<double>(part[k]));
+            if (lane == 0) sh[wv][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < kCandAll) {
+            double a = 0.0;
+            for (int w = 0; w < kGridAllWaves; ++w) a += sh[w][threadIdx.x];
+            partials[static_cast<int64_t>(blockIdx.x) * n_pad + k0 + threadIdx.x] = a;
+        }
+        // the next batch's candidates / sh are written only after the barrier at its top
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mse_grid_reduce_kernel(const double* __restrict__ partials, int n_blocks, int n_pad,
+                                                                   ElemSource src, GridArgs g, float* __restrict__ losses) {
+    __shared__ double s_n;
+    if (threadIdx.x == 0) s_n = observed_count(src);
+    __syncthreads();
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= g.n_cand) return;
+    double a = 0.0;
+    for (int b = 0; b < n_blocks; ++b) a += partials[static_cast<int64_t>(b) * n_pad + k];
+    losses[k] = static_cast<float>(a / s_n);
 }
 
 // first strict minimum in candidate order (observer.py:339-341,359-361), then commit + qparams
@@ -475,9 +609,43 @@ extern "C" int osq_observe_quantile(const float* x, int64_t n, const osq_token_v
     return check_launch("observe_quantile");
 }
 
+namespace osq {
+__global__ void selftest_division_kernel(const float* __restrict__ x, const float* __restrict__ sc, int64_t n, int32_t* __restrict__ mismatches) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = sc[i];
+    if (!div_fast_divisor(b) || !div_fast_dividend(a)) return;      // operands the kernels send down the division anyway
+    const float want = a / b, got = div_by_reciprocal(a, b, 1.0f / b);
+    if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(mismatches, 1);
+}
+}  // namespace osq
+
+/* Test aid: counts the pairs (x[i], s[i]) -- among those both guards admit -- for which the reciprocal sequence of the MSE
+ * grid (div_by_reciprocal) and the IEEE division differ in any bit.  mismatches: device int32, added to. */
+extern "C" int osq_selftest_division(const float* x, const float* s, int64_t n, int32_t* mismatches, osq_stream stream) {
+    OSQ_REQUIRE(x && s && mismatches && n >= 0, "selftest_division: bad argument");
+    if (n == 0) return OSQ_OK;
+    hipLaunchKernelGGL(selftest_division_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, s, n, mismatches);
+    return check_launch("selftest_division");
+}
+
+static int g_mse_grid_all = 1;       // osq_set_tuning("mse_grid_all", 0): the per-tensor MSE grid as one launch per 32 candidates (A/B, tests)
+namespace osq {
+bool set_extra_tuning(const char* key, int value) {
+    if (std::string(key) == "mse_grid_all") { g_mse_grid_all = value != 0; return true; }
+    return false;
+}
+}  // namespace osq
+
+extern "C" size_t osq_mse_grid_scratch_bytes(int quant_min, int quant_max, int two_d) {
+    const int n_cand = two_d ? 100 * (quant_max - quant_min + 1) : 100;
+    const size_t n_pad = static_cast<size_t>((n_cand + kCandBatch - 1) / kCandBatch * kCandBatch);
+    return n_pad * sizeof(double) + static_cast<size_t>(kGridAllMaxBlocks) * n_pad * sizeof(double);
+}
+
 extern "C" int osq_mse_grid_tensor(const float* x, int64_t n, const osq_token_view* view, const int64_t* lengths,
                                    const float* cur_minmax, int quant_min, int quant_max, int symmetric,
-                                   int one_side, int two_d, float* loss_scratch,
+                                   int one_side, int two_d, float* loss_scratch, size_t scratch_bytes,
                                    int update_rule, int64_t cnt, float* min_val, float* max_val,
                                    float* scale_out, void* zero_point_out, int zp_type,
                                    void* workspace, osq_stream stream) {
@@ -490,9 +658,20 @@ extern "C" int osq_mse_grid_tensor(const float* x, int64_t n, const osq_token_vi
     const QOut q{quant_min, quant_max, symmetric, scale_out, zero_point_out, zp_type};
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
-    for (int k0 = 0; k0 < g.n_cand; k0 += kCandBatch)
-        hipLaunchKernelGGL(mse_grid_loss_kernel, dim3(grid), dim3(kThreads), 0, st, src, cur_minmax, g, k0, loss_scratch,
-                           ws.doubles(kFamHistogram), ws.counter(kFamHistogram));
+    const int n_pad = (g.n_cand + kCandBatch - 1) / kCandBatch * kCandBatch;
+    if (g_mse_grid_all && scratch_bytes >= osq_mse_grid_scratch_bytes(quant_min, quant_max, two_d)) {
+        // all candidates in ONE launch: [losses n_pad floats][partials 256 x n_pad doubles] in the caller's scratch
+        const int64_t items = view ? src.v.batch * src.v.tokens : (n + 4 * kGridAllThreads - 1) / (4 * kGridAllThreads);
+        const int blocks = static_cast<int>(std::min<int64_t>(kGridAllMaxBlocks, std::max<int64_t>(1, view ? (items + kGridAllWaves - 1) / kGridAllWaves : items)));
+        double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(loss_scratch) + static_cast<size_t>(n_pad) * sizeof(double));
+        hipLaunchKernelGGL(mse_grid_all_kernel, dim3(blocks), dim3(kGridAllThreads), 0, st, src, cur_minmax, g, n_pad, partials);
+        hipLaunchKernelGGL(mse_grid_reduce_kernel, dim3((g.n_cand + kThreads - 1) / kThreads), dim3(kThreads), 0, st, partials, blocks, n_pad, src, g,
+                           loss_scratch);
+    } else {
+        for (int k0 = 0; k0 < g.n_cand; k0 += kCandBatch)
+            hipLaunchKernelGGL(mse_grid_loss_kernel, dim3(grid), dim3(kThreads), 0, st, src, cur_minmax, g, k0, loss_scratch,
+                               ws.doubles(kFamHistogram), ws.counter(kFamHistogram));
+    }
     hipLaunchKernelGGL(mse_grid_commit_kernel, dim3(1), dim3(kThreads), 0, st, loss_scratch, cur_minmax, g, update_rule, cnt,
                        min_val, max_val, q);
     return check_launch("mse_grid_tensor");

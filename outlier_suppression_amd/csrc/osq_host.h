@@ -30,6 +30,7 @@ void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
 bool set_msefast_tuning(const char* key, int value);    // msefast.hip
 bool set_layernorm_tuning(const char* key, int value);  // layernorm.hip
+bool set_extra_tuning(const char* key, int value);      // observers_extra.hip
 bool stream_write_through();                            // fake_quant.hip: osq_set_tuning("stream_wt", 0|1)
 
 // Measurement aid (osq_time_next_launch): events that the next launch of kernel family `which` on this thread

@@ -807,11 +807,13 @@ def mse_grid_tensor(x, observation_mask, seq_pos, cur, quant_min, quant_max, sym
     _check_f32(x, min_val, max_val)
     x, n, view, lengths = _source(x, observation_mask, seq_pos)
     n_cand = int(lib.osq_mse_grid_candidates(int(quant_min), int(quant_max), int(bool(two_d))))
-    losses = torch.empty(n_cand, dtype=torch.float32, device=x.device)
+    nbytes = int(lib.osq_mse_grid_scratch_bytes(int(quant_min), int(quant_max), int(bool(two_d))))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)      # losses + every workgroup's partial sums: the grid is one launch
+    losses = scratch[:4 * n_cand].view(torch.float32)
     s_ptr, z_ptr, z_type = (sink or QParamSink()).args()
     _hip.check(lib.osq_mse_grid_tensor(_hip.ptr(x), n, ctypes.byref(view) if view is not None else None, _hip.ptr(lengths),
                                        _hip.ptr(cur), int(quant_min), int(quant_max), int(bool(symmetric)), SIDE[one_side],
-                                       int(bool(two_d)), _hip.ptr(losses), rule, int(cnt), _hip.ptr(min_val),
+                                       int(bool(two_d)), _hip.ptr(scratch), nbytes, rule, int(cnt), _hip.ptr(min_val),
                                        _hip.ptr(max_val), s_ptr, z_ptr, z_type, _hip.ptr(_hip.workspace(x.device)),
                                        _hip.stream_ptr(x.device)), "mse_grid_tensor")
     return losses

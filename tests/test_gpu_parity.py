@@ -1481,3 +1481,34 @@ def test_head_layout_fake_quant_helpers(dev):
                 out = merge_heads_fake_quant(q, ctx, lengths)
                 out.sum().backward()
                 assert q.scale.grad is not None
+
+
+def test_reciprocal_division_of_the_mse_grid_is_the_ieee_division(dev):
+    """The all-candidates launch of the MSE grid (csrc/observers_extra.hip) forms x / scale as y = RN(1 / s), q0 = x * y and
+    two fma corrections instead of dividing -- the correctly rounded quotient for every admitted operand pair (Markstein's
+    theorem; guards: significand of s not all ones, |x| and s within [2^-60, 2^60]).  osq_selftest_division counts the
+    pairs on which the two differ: 2^26 random pairs over the whole admitted exponent range, plus divisors with
+    awkward significands (all ones but the last bit, 1.0, 1 + ulp) against dividends round the rounding boundaries."""
+    import ctypes
+    from outlier_suppression_amd import _hip
+    lib = _hip.load()
+    gen = torch.Generator(device=dev).manual_seed(77)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    n = 1 << 24
+    for rep in range(4):
+        mant_x = torch.rand(n, device=dev, generator=gen) + 1.0
+        mant_s = torch.rand(n, device=dev, generator=gen) + 1.0
+        ex = torch.randint(-59, 60, (n,), device=dev, generator=gen).float()
+        es = torch.randint(-26, 60, (n,), device=dev, generator=gen).float()        # scales are floored at 1e-8 by calculate_qparams
+        sign = torch.where(torch.rand(n, device=dev, generator=gen) < 0.5, -1.0, 1.0)
+        x = sign * mant_x * torch.exp2(ex)
+        s = mant_s * torch.exp2(es)
+        if rep == 3:          # awkward divisors, dividends built as k * s (+- an ulp): quotients on rounding boundaries
+            bits = torch.randint(0, 3, (n,), device=dev, generator=gen)
+            pat = torch.tensor([0x3fffffe0 | 0x1e, 0x3f800000, 0x3f800001], dtype=torch.int32, device=dev)[bits]
+            s = pat.view(torch.float32) * torch.exp2(torch.randint(-20, 10, (n,), device=dev, generator=gen).float())
+            k = torch.randint(-64, 64, (n,), device=dev, generator=gen).float() + 0.5
+            x = (k * s)
+            x = (x.view(torch.int32) + torch.randint(-2, 3, (n,), device=dev, generator=gen).int()).view(torch.float32)
+        _hip.check(lib.osq_selftest_division(_hip.ptr(x), _hip.ptr(s), n, _hip.ptr(bad), _hip.stream_ptr(dev)), "selftest_division")
+    assert int(bad.item()) == 0

@@ -13,6 +13,17 @@ import sqlite3
 import sys
 
 N_ELEM = 256 * 128 * 768
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# what the dominant kernels are compiled from: bench.py refuses a roofline_traffic.json taken from other sources
+KERNEL_SOURCES = ("fused_step.h", "token_select.h", "observer.hip", "osq_device.h", "fake_quant.hip", "Makefile")
+
+
+def kernel_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "outlier_suppression_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
 
 
 def find_db(d):
@@ -69,6 +80,8 @@ def main(out, tag):
     open(os.path.join(out, f"{tag}_bench_pmc.md"), "w").write("\n".join(lines) + "\n")
     traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 50 "
                         "--warmup 10 --no-cpu-baseline --no-calib`; KB per dispatch; reads doubled per MI355X_MICROARCH.md")
+    traffic["_kernel_sources_sha256"] = kernel_sources_sha256()
+    traffic["_profile_tag"] = tag
     json.dump(traffic, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1)
     print(stats)
     print("\n".join(lines))

@@ -618,6 +618,8 @@ def calibration_extra(dev, rank, world, which):
         wall, phases, info_w, info_a, model = run_once()
         # the STRICT switch (outlier_suppression_amd.set_strict: every per-tensor loss added in the reference's one-thread
         # order, one launch per loss evaluation instead of one resident launch per search): what it costs on this config
+        if os.environ.get("OSQ_BENCH_NO_STRICT") == "1":      # profiling runs of the DEFAULT flow (tools/collect_calibration_profiles.sh)
+            return {"config": "configs[3] (default flow only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
         import outlier_suppression_amd as osq
         osq.set_strict(True)
         try:
@@ -1007,6 +1009,11 @@ def main():
         barrier(done)
         return time.perf_counter() - t0, host, gathered, out
 
+    if world > 1:                              # the ranks issue the same way: a rank whose capture failed takes every rank to the eager loop
+        ok = torch.tensor([1 if graph is not None else 0], dtype=torch.int64, device="cpu" if share else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            graph = None
     modes = ["graph", "eager"] if (graph is not None and args.launch == "auto") else (["graph"] if graph is not None else ["eager"])
     # untimed: capture and the collector pass above leave the GPU idle for tens of milliseconds and its clocks fall back
     # (MI355X_MICROARCH.md, DVFS; tools/region_probe.py: the same 20-step replay reads 41.5 us per step in the first
@@ -1236,7 +1243,7 @@ def main():
             "n_gpus": world,
             "configs": {k: {"wall_s": v.get("wall_s"), "collective_s": v.get("collective_s")}
                         for k, v in out.items() if k.startswith("calibration") and isinstance(v, dict) and "wall_s" in v}}
-        if rank == 0:
+        if rank == 0 and not SHORT:
             try:
                 out["quantized_forward"] = quantized_forward_times(dev)
             except Exception as e:

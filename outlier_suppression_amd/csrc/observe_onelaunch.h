@@ -59,6 +59,7 @@ struct OneLaunchArgs {
     OneLaunchState* st;
     unsigned long long* meet;
     unsigned int spin_limit;
+    int phase;                        // 0: streaming and selecting workgroups in one launch; 1: the streaming ones only; 2: the selectors only (after a phase-1 launch)
 };
 
 __device__ __forceinline__ unsigned int ol_pivot_key(const float hint, const int prune, const bool usable) {
@@ -585,8 +586,12 @@ __device__ __forceinline__ void ol_select(const OneLaunchArgs& a, const Finish& 
 template <bool SINGLE_SEGMENT, bool NT>
 __global__ __launch_bounds__(kOlThreads) void observe_tokens_onelaunch_kernel(OneLaunchArgs a, Finish fin) {
     __shared__ OlShared S;
+    if (a.phase == 2) {                       // grid (2, 1): the selectors of a two-launch run find every record in place
+        ol_select(a, fin, S.sel);
+        return;
+    }
     if (blockIdx.y == 0) {
-        if (blockIdx.x < 2) ol_select(a, fin, S.sel);
+        if (blockIdx.x < 2 && a.phase == 0) ol_select(a, fin, S.sel);
         return;
     }
     ol_stream<SINGLE_SEGMENT, NT>(a, fin, S.str);

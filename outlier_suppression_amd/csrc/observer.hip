@@ -1319,7 +1319,7 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
-    if (k == "observe_onelaunch") { g_onelaunch = value != 0; return true; }
+    if (k == "observe_onelaunch") { if (value < 0 || value > 2) return false; g_onelaunch = value; return true; }
     if (k == "observe_hint") { g_onelaunch_hint = value != 0; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "select_hint") { g_select_hint = value != 0; return true; }
@@ -1565,10 +1565,10 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
                 while ((1 << lgG) < inner4 && lgG < 6) ++lgG;
             }
             Workspace wsp(workspace);
-            const OneLaunchArgs a{x, v, lengths, token_min, token_max, lgG, inner4, static_cast<int>(chunks), prune,
-                                  static_cast<float>(percentile), g_select_shortcut, g_onelaunch_hint,
-                                  static_cast<OneLaunchState*>(wsp.onelaunch()), wsp.meet(),
-                                  g_fused_spin_limit ? g_fused_spin_limit - 1u : kOlSpinLimit};
+            OneLaunchArgs a{x, v, lengths, token_min, token_max, lgG, inner4, static_cast<int>(chunks), prune,
+                            static_cast<float>(percentile), g_select_shortcut, g_onelaunch_hint,
+                            static_cast<OneLaunchState*>(wsp.onelaunch()), wsp.meet(),
+                            g_fused_spin_limit ? g_fused_spin_limit - 1u : kOlSpinLimit, g_onelaunch == 2 ? 1 : 0};
             const dim3 grid(static_cast<unsigned>(chunks), static_cast<unsigned>(v.batch + 1));
             hipStream_t st = static_cast<hipStream_t>(stream);
             const TimingHook th = take_timing_hook(OSQ_TIME_OBSERVE_TOKENS);
@@ -1576,6 +1576,11 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
             if (v.feat_outer == 1) { if (g_tok_nt) OSQ_OL(true, true); else OSQ_OL(true, false); }
             else { if (g_tok_nt) OSQ_OL(false, true); else OSQ_OL(false, false); }
 #undef OSQ_OL
+            if (g_onelaunch == 2) {           // the same selectors as a second launch: every record is in place when they start
+                a.phase = 2;
+                const TimingHook th2 = take_timing_hook(OSQ_TIME_TOKEN_SELECT);
+                hipExtLaunchKernelGGL((observe_tokens_onelaunch_kernel<true, true>), dim3(2, 1), dim3(kOlThreads), 0, st, th2.start, th2.stop, 0, a, fin);
+            }
             return check_launch("observe_tokens(one launch)");
         }
     }

@@ -13,7 +13,7 @@ for c in $cfgs; do
   out=/tmp/osq_prof_${tag}_c$c          # raw databases never enter gpurun_out/ (64 MiB limit on what travels back)
   rm -rf "$out"; mkdir -p "$out"
   cmd="python bench.py --steps 5 --warmup 2 --settle 0 --preroll 0.05 --no-cpu-baseline --no-kernel-table --calib-configs $c"
-  rocprofv3 --kernel-trace --stats -d "$out/trace" -o r -- $cmd > "$out/trace.log" 2>&1 || tail -5 "$out/trace.log"
+  OSQ_BENCH_NO_STRICT=1 timeout 600 rocprofv3 --kernel-trace --stats -d "$out/trace" -o r -- $cmd > "$out/trace.log" 2>&1 || tail -5 "$out/trace.log"
   if [ "${PMC:-1}" = "1" ]; then
     OSQ_BENCH_SHORT=1 timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $cmd > "$out/pmc_fetch.log" 2>&1 || tail -5 "$out/pmc_fetch.log"
     OSQ_BENCH_SHORT=1 timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $cmd > "$out/pmc_write.log" 2>&1 || tail -5 "$out/pmc_write.log"

@@ -1,2 +1,2 @@
-python tools/mse_grid_ab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_mse_grid_ab.txt
-python -m pytest tests -q -m gpu -x -k "mse_grid or other_observers or reciprocal_division or golden" 2>&1 | tail -4
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+PMC=1 timeout 1200 tools/collect_calibration_profiles.sh r04 1 2>&1 | tail -12

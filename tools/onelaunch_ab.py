@@ -33,7 +33,7 @@ for shape, seq_pos in (((32, 128, 768), 1), ((32, 12, 128, 128), 2), ((32, 128, 
     B, T = shape[0], shape[seq_pos]
     for name, L in (("lengths 8..T", torch.randint(8, T + 1, (B,), generator=g).to(dev)), ("all valid", torch.full((B,), T, dtype=torch.int64, device=dev))):
         res = {}
-        for mode in (1, 0):
+        for mode in (2, 1, 0):
             ops.set_tuning("observe_onelaunch", mode)
             mn, mx = torch.tensor(float("inf"), device=dev), torch.tensor(float("-inf"), device=dev)
             st = {"c": 0}
@@ -41,10 +41,13 @@ for shape, seq_pos in (((32, 128, 768), 1), ((32, 12, 128, 128), 2), ((32, 128, 
             def call(i):
                 ops.observe_tokens(xs[i % 3], seq_pos, L, True, 0.95, ops.UPDATE_AVERAGE, st["c"], mn, mx, 0, 63, False)
                 st["c"] += 1
-            if mode:
+            if mode == 2:
+                res["split_a"] = timed(_hip.TIME_OBSERVE_TOKENS, call)
+                res["split_b"] = timed(_hip.TIME_TOKEN_SELECT, call)
+            elif mode:
                 res["one"] = timed(_hip.TIME_OBSERVE_TOKENS, call)
             else:
                 res["minmax"] = timed(_hip.TIME_TOKEN_MINMAX, call)
                 res["select"] = timed(_hip.TIME_TOKEN_SELECT, call)
         ops.set_tuning("observe_onelaunch", 0)
-        print(f"{str(shape):>20s} {name:13s}: one launch {res['one']:6.2f} us | two launches {res['minmax']:6.2f} + {res['select']:6.2f} = {res['minmax'] + res['select']:6.2f} us", flush=True)
+        print(f"{str(shape):>20s} {name:13s}: one launch {res['one']:6.2f} us | two launches {res['minmax']:6.2f} + {res['select']:6.2f} = {res['minmax'] + res['select']:6.2f} us | records + small selectors {res['split_a']:6.2f} + {res['split_b']:6.2f} = {res['split_a'] + res['split_b']:6.2f} us", flush=True)

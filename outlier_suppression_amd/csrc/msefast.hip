@@ -274,6 +274,9 @@ __device__ __forceinline__ bool rcp_division_exact(double s, double x_min, doubl
     const bool finite = fabs(x_min) <= 3.5e38 && fabs(x_max) <= 3.5e38;        // false for NaN / inf extrema
     return finite && (b & 0xfffffffffffffull) != 0xfffffffffffffull && s >= 1e-9 && s <= 1e38;
 }
+__device__ __attribute__((noinline)) double sq_err_f64_outofline(float xf, double s, double z, double qmin, double qmax) {
+    return sq_err_f64(xf, s, z, qmin, qmax);
+}
 __device__ __forceinline__ double sq_err4_f64(const float4& a, double s, double z, double qmin, double qmax) {
     return (sq_err_f64(a.x, s, z, qmin, qmax) + sq_err_f64(a.y, s, z, qmin, qmax)) +
            (sq_err_f64(a.z, s, z, qmin, qmax) + sq_err_f64(a.w, s, z, qmin, qmax));
@@ -631,7 +634,14 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
     const int64_t n = n_dev ? n_dev[0] : n_host;
     if (f64) {
         const CascadeGeom g = cascade_geom(n, W / 2);
-        auto term = [=](int64_t e, double (&t)[1]) { t[0] = sq_err_f64(x[e], sd, z, qmin, qmax); };
+        // the float64 chain is VALU-bound on its division: the exact reciprocal sequence of the resident search (same bits,
+        // sq_err_f64_rcp) whenever its two conditions hold -- a uniform branch, the division out of line
+        const double rcp = 1.0 / sd;
+        const bool fast = rcp_division_exact(sd, ts->S.x_min, ts->S.x_max);
+        auto term = [=](int64_t e, double (&t)[1]) {
+            if (fast) t[0] = sq_err_f64_rcp(x[e], sd, rcp, z, qmin, qmax);
+            else t[0] = sq_err_f64_outofline(x[e], sd, z, qmin, qmax);
+        };
         double* part = static_cast<double*>(scratch);
         double* lds = lds_raw;
         cascade_units<double, 1, kOrdThreads>(g, part, lds, term);

@@ -178,3 +178,72 @@ def test_deal_sites_is_balanced_and_deterministic():
         load = [sum(c for c, r in zip(costs, owner) if r == k) for k in range(world)]
         assert max(load) <= 1.08 * (sum(costs) / world), (world, load)
     assert deal_sites([], 4) == [] and deal_sites([5.0, 1.0], 1) == [0, 0]
+
+
+def _timeout_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from outlier_suppression_amd import calibration, ops
+
+    def fake_check(where=""):                      # rank 1's persistent launch "timed out"; rank 0's did not
+        if rank == 1:
+            raise ops.PersistentLaunchTimeout("rank 1 timed out")
+    real = ops.check_persistent
+    ops.check_persistent = fake_check
+    try:
+        try:
+            calibration.check_persistent_collectively("test")
+            verdict = "no error"
+        except ops.PersistentLaunchTimeout as e:
+            verdict = "raised: " + str(e)[:40]
+        # nobody is left behind in a collective: both ranks reach this gather
+        t = torch.tensor([float(rank)])
+        out = torch.empty(world)
+        dist.all_gather_into_tensor(out, t)
+    finally:
+        ops.check_persistent = real
+    open(os.path.join(out_dir, f"verdict_{rank}.txt"), "w").write(verdict + f" | gathered {out.tolist()}")
+    dist.destroy_process_group()
+
+
+def test_persistent_time_out_is_raised_on_every_rank(tmp_path):
+    """calibration.check_persistent_collectively: a time-out on ONE rank raises on every rank before the
+    table exchange, so no rank waits in the gather alone and none carries on with the other's NaN-poisoned rows."""
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_timeout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    v0, v1 = (open(tmp_path / f"verdict_{r}.txt").read() for r in (0, 1))
+    assert v0.startswith("raised"), v0                                   # rank 0 had no time-out of its own: it raises for rank 1's
+    assert v1.startswith("raised: rank 1 timed out"), v1
+    assert v0.endswith("gathered [0.0, 1.0]") and v1.endswith("gathered [0.0, 1.0]")
+
+
+def test_probe_sites_switches_every_quantizer_off():
+    """calibration.probe_sites: the geometry probe must not let ANY observer see its batch -- not the
+    selected ones, not the others -- and must restore every flag."""
+    from outlier_suppression_amd import calibration
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+
+    class Spy(QuantizeBase):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.observer_enabled, self.fake_quant_enabled, self.ch_axis, self.calls = 1, 1, -1, []
+
+        def forward(self, X, observation_mask=None, seq_pos=-1):
+            self.calls.append((self.observer_enabled, self.fake_quant_enabled))
+            return X
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a_act_fake_quant, self.w_weight_fake_quant = Spy(), Spy()
+
+        def forward(self, x):
+            return self.w_weight_fake_quant(self.a_act_fake_quant(x))
+    net = Net()
+    selected = [("a_act_fake_quant", net.a_act_fake_quant)]
+    geo = calibration.probe_sites(net, torch.zeros(3, 5), lambda m, b: m(b), selected)
+    assert geo == [(15, 1)]
+    assert net.a_act_fake_quant.calls == [(0, 0)] and net.w_weight_fake_quant.calls == [(0, 0)]      # nobody observed, nobody quantised
+    assert (net.a_act_fake_quant.observer_enabled, net.a_act_fake_quant.fake_quant_enabled) == (1, 1)
+    assert (net.w_weight_fake_quant.observer_enabled, net.w_weight_fake_quant.fake_quant_enabled) == (1, 1)

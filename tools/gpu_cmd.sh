@@ -1,2 +1,2 @@
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-PMC=1 timeout 1200 tools/collect_calibration_profiles.sh r04 1 2>&1 | tail -12
+python -m pytest tests/test_gpu_strict_order.py -q -x 2>&1 | tail -3
+python tools/strict_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_strict_bench.txt

@@ -250,3 +250,19 @@ def test_resident_kernels_do_not_spill():
             assert r.get("vgpr_spill_count", 0) == 0, r
         if "observe_fq_fused_kernel" in r["name"]:
             assert r.get("vgpr_spill_count", 0) <= 1, r
+
+
+def test_strict_and_fast_switches_from_the_environment():
+    """OSQ_STRICT=1 / OSQ_FAST=1 are applied when the library is first loaded (outlier_suppression_amd._apply_environment):
+    the strict switch sets both summation orders, the fast switch opts into the one-launch LayerNorm site; without them
+    the defaults are the results-identical configuration (order-free sums, eager LayerNorm sites)."""
+    import subprocess
+    import sys
+    code = ("from outlier_suppression_amd import _hip, ops, util_layernorm as UL; _hip.load(); "
+            "print(ops.reference_sum_order('mse'), ops.reference_sum_order('bwd'), UL.FUSE_LAYERNORM, UL.FUSE_ACTIVATION)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("OSQ_STRICT", "OSQ_FAST", "OSQ_STRICT_SIMD")}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["0", "0", "False", "True"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, OSQ_STRICT="1", OSQ_FAST="1"), capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["8", "8", "True", "True"], out.stdout + out.stderr

@@ -195,19 +195,27 @@ def kernel_table(dev, xs, lengths, reps=20):
             tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
             8 * SHAPE[0] * SHAPE[1])
         # BASELINE.md section 2's "observer forward" row: the north-star observer ALONE (AvgPruneMinMaxObserver, fake-quant off
-        # -- the state of every observer pass of token-wise clipping) as ONE launch (csrc/observe_onelaunch.h); the two
-        # rows above are the two launches it replaces
+        # -- the state of every observer pass of token-wise clipping) = the two launches above, back to back
+        for tag_, mm, nb in (("bench lengths", "token_minmax, bench lengths", 4 * valid), ("all tokens", "token_minmax, all tokens", 4 * n)):
+            us = rows[mm]["avg_us"] + rows["token_select p=0.95 (32768 slots)"]["avg_us"]
+            rows[f"observer alone (AvgPruneMinMax p=0.95: token_minmax + token_select), {tag_}"] = {
+                "avg_us": round(us, 2), "bound": "hbm + one CU per side for the selection", "algorithmic_MB": round(nb / 1e6, 1),
+                "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBS, 3),
+                "note": "sum of the two launches' own durations; the kernel boundary between them (~1.7 us) is not in it"}
+        # ... and the variant that was built to replace them and measured slower (csrc/observe_onelaunch.h, opt-in;
+        # profiles/r04_onelaunch_ab.txt): kept in the table so that the A/B stays visible
         obs_mn, obs_mx = torch.tensor(float("inf"), device=dev), torch.tensor(float("-inf"), device=dev)
         state = {"cnt": 0}
 
         def observe_alone(i, lens):
             ops.observe_tokens(xs[i % len(xs)], 1, lens, True, PERCENTILE, ops.UPDATE_AVERAGE, state["cnt"], obs_mn, obs_mx, 0, 63, False)
             state["cnt"] += 1
-        add("observer alone, one launch (token-wise clipping p=0.95 + running mean), bench lengths",
-            timed(_hip.TIME_OBSERVE_TOKENS, lambda i: observe_alone(i, lengths)), 4 * valid)
-        obs_mn.fill_(float("inf")); obs_mx.fill_(float("-inf")); state["cnt"] = 0
-        add("observer alone, one launch, all tokens",
-            timed(_hip.TIME_OBSERVE_TOKENS, lambda i: observe_alone(i, full)), 4 * n)
+        ops.set_tuning("observe_onelaunch", 1)
+        try:
+            add("observer alone as ONE launch (opt-in variant, dropped: slower), bench lengths",
+                timed(_hip.TIME_OBSERVE_TOKENS, lambda i: observe_alone(i, lengths)), 4 * valid)
+        finally:
+            ops.set_tuning("observe_onelaunch", 0)
         add("lsq_plus_backward", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
             xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
         # LayerNorm site of a quantized block: GammaResidual -> split LayerNorm -> + beta/gamma -> fake-quant, one launch

@@ -9,7 +9,7 @@
 set -e
 tag=${1:-r02}
 out=$PWD/gpurun_out/$tag
-rm -rf "$out"; mkdir -p "$out"
+mkdir -p "$out"; rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 export TMPDIR=/tmp
 cmd="python bench.py --steps 50 --warmup 10 --settle 0 --no-cpu-baseline --no-calib --no-kernel-table"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o r -- $cmd > "$out/bench_trace.log" 2>&1

@@ -1,10 +1,20 @@
-set -x
+# Round-end run on ONE box: GPU tests, the bench profiles (kernel trace + PMC passes + the default bench line), the driver's flags.
+# usage: bash tools/final_run.sh <tag>     (raw databases stay in /tmp on the box; summaries go to gpurun_out/<tag>/)
+tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -2 gpurun_out/gpu_tests.log
-bash tools/collect_profiles.sh r02 > gpurun_out/collect.log 2>&1; tail -3 gpurun_out/collect.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02/bench_steps20.json 2> gpurun_out/r02/bench_steps20.err
-bash tools/prof.sh calib1 python bench.py --steps 20 --warmup 5 --settle 0 --no-cpu-baseline --no-kernel-table --calib-configs 1 > gpurun_out/calib1_table.txt 2>&1
-bash tools/prof.sh calib3 python bench.py --steps 20 --warmup 5 --settle 0 --no-cpu-baseline --no-kernel-table --calib-configs 3 > gpurun_out/calib3_table.txt 2>&1
-python tools/fused_timing.py > gpurun_out/fused_timing_r02_final.log 2>&1 || true
-ls gpurun_out/r02
+mkdir -p gpurun_out/$tag
+python -m pytest tests -m gpu -x -q > gpurun_out/$tag/gpu_tests.log 2>&1; tail -2 gpurun_out/$tag/gpu_tests.log
+bash tools/collect_profiles.sh $tag > gpurun_out/$tag/collect.log 2>&1; tail -3 gpurun_out/$tag/collect.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench_steps20.json 2> gpurun_out/$tag/bench_steps20.err
+rm -rf gpurun_out/$tag/trace gpurun_out/$tag/pmc_fetch gpurun_out/$tag/pmc_write
+ls gpurun_out/$tag
+python - <<PY
+import json
+for f in ("bench.json", "bench_steps20.json"):
+    try:
+        d = json.loads([l for l in open("gpurun_out/$tag/" + f) if l.startswith("{")][0])
+        print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["config"]["launch"][:90])
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY

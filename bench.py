@@ -1003,7 +1003,9 @@ def main():
 
     def region(mode, exchange=False):
         """One K-step region: barrier + synchronize, K module calls, (N > 1: the exchange), synchronize + barrier.  Seconds."""
-        barrier()
+        before = torch.cuda.Event()            # poll, do not block: a host thread that slept in hipStreamSynchronize for the
+        before.record()                        # 60 ms of the pre-roll wakes up cold and issues the region ~30 us late
+        barrier(before)                        # (measured: +1.5 us per step at K = 20 against regions that follow a short wait)
         t0 = time.perf_counter()
         with torch.no_grad():                  # the reference calibrates under no_grad (token_wise_clipping.py:29-47)
             out = issue(mode)
@@ -1048,7 +1050,11 @@ def main():
     else:
         pick = modes[0]
     with torch.no_grad():
-        for _ in range(3):                     # untimed: the chosen mode directly in front of the timed region
+        # untimed: ~12 ms of the chosen mode back to back (no synchronisation in between) directly in front of the timed
+        # region.  Measured (tools/region_probe2.py, 20-step regions, us per step): after an idle gap of 5 ms 40.9, after 3-20
+        # replays 39.2-39.8, after 75 replays (60 ms) 39.8-40.9, after 300 replays 40.6-41.0 -- the clocks sag when the GPU
+        # idles AND when it has been busy for tens of milliseconds; a short run-up is the state the path's launches meet
+        for _ in range(max(3, int(0.012 / (args.steps * 40e-6)))):
             y = issue(pick)
     dt, host_dt, gathered, y = region(pick, exchange=True)
     gc.enable()

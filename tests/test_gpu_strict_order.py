@@ -96,7 +96,8 @@ def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
     ops.set_tuning("mse_sum_order", width)
     OB.MEAN_LIKE_TORCH = _oracle_order_mean(width)
     try:
-        for n in [100, 8193, 3 * 8192 + 5, 70001, 131072 + 77, 262144 + 8192 + 33, (1 << 20) + 7]:
+        # the last length (width 8 only: 20 s of NumPy) puts the float64 call beyond 2^19 rows per column: level step 32
+        for n in [100, 8193, 3 * 8192 + 5, 70001, 131072 + 77, 262144 + 8192 + 33, (1 << 20) + 7] + ([(1 << 23) + 4096 * 3 + 21] if width == 8 else []):
             ob = OBS.MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
             st = OB.ObserverState(bit=4, symmetric=True, ch_axis=-1)
             counter = [0]

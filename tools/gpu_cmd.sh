@@ -1,2 +1,6 @@
-python -m pytest tests/test_gpu_strict_order.py -q -x 2>&1 | tail -3
-python tools/strict_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_strict_bench.txt
+for i in 1 2 3 4; do python bench.py --steps 20 --warmup 5 --no-calib --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['ms_per_step'], d['config']['launch'][-70:], d['config']['eager_ms_per_step'], d['roofline']['avg_launch_us'])
+"; done

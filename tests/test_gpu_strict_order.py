@@ -110,15 +110,21 @@ def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
                 assert np.array_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
                     np.array_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (n, r, N(ob.max_val), st.max_val)
             assert evals == counter[0], (n, evals, counter[0])
-        for shape, seq_pos, sym in [((16, 96, 200), 1, False), ((4, 6, 50, 40), 2, False), ((5, 3, 24, 70), 3, True)]:
+        # (shape, seq_pos, symmetric, view): "split" = [B,h,T,d] seen through [B,T,h,d] memory (quant_bert.py:128-150);
+        # "zip" = BART's 3-D probabilities [B*h, T, S] masked with B lengths: remove_padding's zip keeps the first B rows (observer.py:82)
+        for shape, seq_pos, sym, view in [((16, 96, 200), 1, False, None), ((4, 6, 50, 40), 2, False, None), ((5, 3, 24, 70), 3, True, None),
+                                          ((6, 4, 40, 32), 2, False, "split"), ((12, 20, 36), 1, False, "zip")]:
             ob = OBS.AvgMSEFastObserver(bit=6, symmetric=sym, ch_axis=-1).to(dev)
             st = OB.ObserverState(bit=6, symmetric=sym, ch_axis=-1)
             counter = [0]
             evals = 0
             for r in range(2):
-                x = (rng.standard_normal(shape) * (1.0 + 0.5 * r)).astype(np.float32)
+                if view == "split":
+                    x = np.transpose((rng.standard_normal((shape[0], shape[2], shape[1], shape[3])) * (1.0 + 0.5 * r)).astype(np.float32), (0, 2, 1, 3))
+                else:
+                    x = (rng.standard_normal(shape) * (1.0 + 0.5 * r)).astype(np.float32)
                 x[..., 3] *= 12
-                lengths = rng.integers(1, shape[seq_pos] + 1, size=shape[0])
+                lengths = rng.integers(1, shape[seq_pos] + 1, size=3 if view == "zip" else shape[0])
                 ob(torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), seq_pos)
                 evals += int(ob.last_nfev.sum().item())
                 OB.observe_msefast(st, x, lengths, seq_pos, average=True, counter=counter)

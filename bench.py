@@ -1234,7 +1234,10 @@ def main():
                      "launches_timed": len(k_ms), "algorithmic_bytes_per_launch": probe_bytes},
     }
     if rank == 0 and not args.no_kernel_table:
-        out["kernels"] = kernel_table(dev, xs, lengths)
+        try:          # a failure in the per-kernel table must not cost the headline line
+            out["kernels"] = kernel_table(dev, xs, lengths)
+        except Exception as e:
+            out["kernels"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_calib:
         wanted = {int(c) for c in args.calib_configs.split(",") if c.strip()}
         if 0 in wanted:
@@ -1243,7 +1246,10 @@ def main():
             except Exception as e:
                 out["calibration_config0"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if 1 in wanted:
-            out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
+            try:
+                out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
+            except Exception as e:
+                out["calibration"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         for which in (2, 3, 4, 5):
             if which not in wanted:
                 continue
@@ -1263,7 +1269,10 @@ def main():
             except Exception as e:
                 out["quantized_forward"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
+        try:
+            out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

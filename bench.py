@@ -1249,6 +1249,8 @@ def main():
             try:
                 out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
             except Exception as e:
+                if world > 1:
+                    raise          # the other ranks are inside its collectives: fail the job rather than hang it
                 out["calibration"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         for which in (2, 3, 4, 5):
             if which not in wanted:
@@ -1256,6 +1258,8 @@ def main():
             try:          # a failure here must not cost the headline line
                 out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
             except Exception as e:
+                if world > 1:
+                    raise          # see above: never leave the other ranks waiting in a collective
                 out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         # Metric 2 in one place: wall-clock and the collective's share of every measured config at the launched N

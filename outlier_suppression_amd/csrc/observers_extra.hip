@@ -404,14 +404,38 @@ __global__ __launch_bounds__(kThreads) void mse_grid_loss_kernel(ElemSource src,
 constexpr int kGridAllThreads = OSQ_GRIDALL_THREADS;
 constexpr int kGridAllWaves = kGridAllThreads / OSQ_WAVE;
 constexpr int kGridAllMaxBlocks = 256;
+constexpr int kGridAllMaxBatch = 1024;       // prefix sums of the lengths in LDS (the dealing of a dense masked site by pieces)
 constexpr int kCandAll = OSQ_GRIDALL_CANDS;          // candidates per trip.  Measured on [32,128,768] / [32,128,3072] (tools/mse_grid_ab.py, ms): 1024 threads x 16: 21.8 / 40.2 (43 spilled VGPRs and still the fastest); 1024 x 8: 56 / 40; 256 x 32: 29 / 78; 512 x 16: 55 / 52; the launch-per-32-candidates form 30.2 / 76
 
 __global__ __launch_bounds__(kGridAllThreads) void mse_grid_all_kernel(ElemSource src, const float* __restrict__ cur_minmax,
                                                                       GridArgs g, int n_pad, double* __restrict__ partials) {
     __shared__ Cand cands[kCandAll];
     __shared__ double sh[kGridAllWaves][kCandAll];
+    __shared__ unsigned int pre[kGridAllMaxBatch + 1];
     const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
     const float qmin = static_cast<float>(g.quant_min), qmax = static_cast<float>(g.quant_max);
+    // A masked dense site whose rows are whole 1 KiB pieces (768 / 1024 / 3072 / 4096 features): the VALID tokens' pieces
+    // (one float4 per lane) are dealt round the waves of the grid -- piece u to wave u mod waves -- instead of one token
+    // per wave: with 54 % of the tokens valid every wave is busy (token dealing left the waves of padded tokens idle),
+    // and a piece is a finer unit than a token.  Only the dealing differs; the values and the candidates are the same.
+    const bool pieces = src.v.batch > 0 && src.vec && src.v.feat_outer == 1 && src.v.feat_inner % 256 == 0 && src.v.batch <= kGridAllMaxBatch;
+    unsigned int n_units = 0u, segs = 1u;
+    if (pieces) {
+        const unsigned int Bu = static_cast<unsigned int>(src.v.batch);
+        for (unsigned int b = threadIdx.x; b < Bu; b += kGridAllThreads) {
+            int64_t l = src.lengths ? src.lengths[b] : src.v.tokens;
+            l = l < 0 ? 0 : (l > src.v.tokens ? src.v.tokens : l);
+            pre[b + 1] = static_cast<unsigned int>(l);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pre[0] = 0u;
+            for (unsigned int b = 0; b < Bu; ++b) pre[b + 1] += pre[b];
+        }
+        __syncthreads();
+        segs = static_cast<unsigned int>(src.v.feat_inner / 256);
+        n_units = pre[Bu] * segs;
+    }
     for (int k0 = 0; k0 < g.n_cand; k0 += kCandAll) {
         if (threadIdx.x < kCandAll) {
             const int k = k0 + threadIdx.x < g.n_cand ? k0 + threadIdx.x : g.n_cand - 1;
@@ -431,7 +455,7 @@ __global__ __launch_bounds__(kGridAllThreads) void mse_grid_all_kernel(ElemSourc
         }
         c_fast = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(c_fast)));
         int run = 0;
-        for_each_element_t<kGridAllThreads>(src, [&](float v) {
+        auto one = [&](float v) {
             const bool all_ok = !wave_any(!div_fast_dividend(v));          // uniform: one ballot per element, shared by the candidates
 #pragma unroll
             for (int k = 0; k < kCandAll; ++k)
@@ -442,7 +466,23 @@ __global__ __launch_bounds__(kGridAllThreads) void mse_grid_all_kernel(ElemSourc
                 for (int k = 0; k < kCandAll; ++k) { acc[k] += part[k]; part[k] = 0.0f; }
                 run = 0;
             }
-        });
+        };
+        if (pieces) {
+            const unsigned int Bu = static_cast<unsigned int>(src.v.batch), nwaves = gridDim.x * kGridAllWaves;
+            for (unsigned int u = blockIdx.x * kGridAllWaves + wv; u < n_units; u += nwaves) {
+                const unsigned int j = u / segs, seg = u - j * segs;           // valid token j (sample-major), its piece
+                unsigned int lo = 0u, hi = Bu;                                  // pre[lo] <= j < pre[hi]
+                while (lo + 1u < hi) {
+                    const unsigned int mid = (lo + hi) >> 1;
+                    if (pre[mid] <= j) lo = mid; else hi = mid;
+                }
+                const float4 a = reinterpret_cast<const float4*>(src.x + static_cast<int64_t>(lo) * src.v.stride_batch +
+                                                                 static_cast<int64_t>(j - pre[lo]) * src.v.stride_token + seg * 256u)[lane];
+                one(a.x); one(a.y); one(a.z); one(a.w);
+            }
+        } else {
+            for_each_element_t<kGridAllThreads>(src, one);
+        }
 #pragma unroll
         for (int k = 0; k < kCandAll; ++k) {
             const double v = wave_sum(acc[k] + static_cast<double>(part[k]));

@@ -187,7 +187,8 @@ int osq_lsq_backward_per_tensor_ordered(const float* x, const float* grad_out, f
                                         float* grad_scale, float* grad_zero_point,
                                         void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream);
 
-/* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner]. */
+/* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner].  With "bwd_sum_order" set, weights
+ * (outer == 1, inner <= 3072) take every row's four reductions in torch's order (bit-equal to the reference's autograd run). */
 int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,
                                  int64_t outer, int64_t channels, int64_t inner,
                                  const float* scale, const void* zero_point, int zp_type,

@@ -22,10 +22,11 @@ def set_strict(on=True, simd_width=8):
 
     ``set_strict(True)`` makes both sums follow torch's order on a ONE-thread host with ``simd_width`` fp32 lanes per
     vector (8: x86 torch, AVX2 and AVX-512 builds alike; float64 sums use half as many), at any length: min_val /
-    max_val / scale / zero_point of every MSEFast observer and scale.grad / zero_point.grad of every PER-TENSOR learnable
-    quantizer (LSQ / LSQ+ activations: what every shipped configuration learns) then equal that reference run bit for bit
-    (tests/test_gpu_strict_order.py, fixtures made by running the reference at BERT-base site sizes).  Per-channel
-    learnable quantizers keep their float64 sums (2e-5 from autograd's fp32 ones; no shipped configuration has them).  Price: per-tensor MSEFast searches take one launch per loss evaluation instead of one
+    max_val / scale / zero_point of every MSEFast observer and scale.grad / zero_point.grad of every learnable quantizer
+    -- per-tensor (LSQ / LSQ+ activations: what every shipped configuration learns; any size) and per-channel weights
+    (ch_axis = 0, rows of up to 3072 columns) -- then equal that reference run bit for bit (tests/test_gpu_strict_order.py,
+    fixtures made by running the reference at BERT-base site sizes; tests/test_gpu_parity.py for the per-channel case).
+    Other per-channel layouts (an inner channel axis, longer rows) keep their float64 sums (2e-5 from autograd's fp32 ones).  Price: per-tensor MSEFast searches take one launch per loss evaluation instead of one
     persistent launch per search (BASELINE configs[3]'s activation pass: see DESIGN.md), the LSQ+ backward runs at
     ~60 % of its default rate.  Per-channel (row) searches follow the reference's order in either mode.
     Also settable from the environment: OSQ_STRICT=1."""

@@ -516,6 +516,49 @@ __global__ __launch_bounds__(kBwdOrdThreads) void lsq_bwd_tensor_ordered_kernel(
     }
 }
 
+// The per-channel backward with "bwd_sum_order" set (strict switch), weights [channels, inner] (outer == 1, the ch_axis = 0
+// case of every weight quantizer): autograd's sum_to_size reduces each of the four term tensors over the contiguous inner
+// axis with torch's fp32 `sum` -- one row of fewer than 32768 elements: ATen's serial cascade whatever the host's thread
+// count (aten_sum_wave, osq_device.h).  One workgroup per channel: the terms go to LDS, waves 0..3 add one term each in
+// that order.  Equal to tests/golden/lsqplus.npz's pc_ds / pc_dzp bit for bit (tests/test_gpu_parity.py).
+__global__ __launch_bounds__(kThreads) void lsq_bwd_channel_ordered_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx, int64_t channels, int inner,
+    const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
+    float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp, int W) {
+    extern __shared__ float terms[];                 // [4][inner]
+    const int64_t c = blockIdx.x;
+    const QParams p = effective_params(scale_p[c], load_zp(zp_p, zp_type, c), mode, g);
+    const float s = p.scale, z = p.zp;
+    const int64_t base = c * inner;
+    for (int j = threadIdx.x; j < inner; j += kThreads) {
+        float x_int;
+        const float xv = x[base + j], gv = gy[base + j];
+        const float q = quantize_value(xv, s, z, qmin, qmax, &x_int);
+        const bool inside = (x_int >= qmin) && (x_int <= qmax);
+        const float g_mul = gv * s;
+        const float g_in = inside ? g_mul : 0.0f;
+        dx[base + j] = g_in / s;
+        terms[j] = gv * (q - z);
+        terms[inner + j] = (-g_in) * ((xv / s) / s);
+        terms[2 * inner + j] = g_in;
+        terms[3 * inner + j] = -g_mul;
+    }
+    __syncthreads();
+    __shared__ float sums[4];
+    const int w = threadIdx.x / OSQ_WAVE;
+    {
+        const float* t = terms + static_cast<int64_t>(w) * inner;
+        const float v = inner >= W ? aten_sum_wave<float>(t, inner, W) : aten_sum_short<float>(t, inner);
+        if ((threadIdx.x & (OSQ_WAVE - 1)) == 0) sums[w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ds = sums[0] + sums[1], dz = sums[2] + sums[3];
+        if (dscale) dscale[c] = (mode == OSQ_PARAM_FIXED) ? ds : ds * g;
+        if (dzp) dzp[c] = (mode == OSQ_PARAM_LSQPLUS) ? dz * g : dz;
+    }
+}
+
 // per-channel backward on [rows = outer*channels, inner]: one workgroup per channel,
 // no cross-workgroup reduction needed.
 __global__ __launch_bounds__(kThreads) void lsq_bwd_channel_kernel(
@@ -830,6 +873,14 @@ extern "C" int osq_lsq_backward_per_channel(const float* x, const float* grad_ou
     OSQ_REQUIRE(x && grad_out && grad_x, "lsq_backward_per_channel: null tensor");
     OSQ_REQUIRE(channels < (1ll << 31), "lsq_backward_per_channel: too many channels");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_bwd_sum_order && outer == 1 && inner <= 3072) {      // strict switch: weight rows in the reference's order (4 x inner floats of LDS)
+        static_assert(kThreads / OSQ_WAVE == 4, "one wave per term");
+        hipLaunchKernelGGL(lsq_bwd_channel_ordered_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads),
+                           static_cast<size_t>(inner) * 16, st, x, grad_out, grad_x, channels, static_cast<int>(inner), scale, zero_point,
+                           zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), grad_scale,
+                           grad_zero_point, g_bwd_sum_order);
+        return check_launch("lsq_backward_per_channel(reference order)");
+    }
     hipLaunchKernelGGL(lsq_bwd_channel_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads), 0, st, x, grad_out,
                        grad_x, outer, channels, inner, scale, zero_point, zp_type, mode, grad_factor,
                        static_cast<float>(quant_min), static_cast<float>(quant_max), grad_scale, grad_zero_point);

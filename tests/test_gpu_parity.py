@@ -164,6 +164,26 @@ def test_lsqplus_gradients_equal_reference_in_its_summation_order(golden, eq32, 
         ops.set_tuning("bwd_sum_order", 0)
 
 
+def test_lsqplus_per_channel_gradients_equal_reference_in_its_summation_order(golden, eq32, dev):
+    """The per-channel learnable quantizer (weights, ch_axis = 0) under the strict switch: every row's four reductions in
+    torch's order -- scale.grad and zero_point.grad of tests/golden/lsqplus.npz's per-channel case bit for bit."""
+    import outlier_suppression_amd as osq
+    from outlier_suppression_amd.quantization import util_quant as U
+    g = golden("lsqplus")
+    qmin, qmax, gf = int(g["pc_meta"][1]), int(g["pc_meta"][2]), g["pc_meta"][3]
+    osq.set_strict(True)
+    try:
+        x = T(g["pc_x"], dev).requires_grad_(True)
+        s = T(g["pc_scale"], dev).requires_grad_(True)
+        z = T(g["pc_zp"], dev).requires_grad_(True)
+        y = U.fake_quantize_learnableplus_per_channel_affine_training(x, s, z, 0, qmin, qmax, gf)
+        y.backward(T(g["pc_gy"], dev))
+        assert eq32(N(y), g["pc_y"]) and eq32(N(x.grad), g["pc_dx"])
+        assert eq32(N(s.grad), g["pc_ds"]) and eq32(N(z.grad), g["pc_dzp"]), (N(s.grad), g["pc_ds"], N(z.grad), g["pc_dzp"])
+    finally:
+        osq.set_strict(False)
+
+
 def test_lsq_backward_determinism_and_size(dev):
     """Grid-wide reduction: same bits run to run, and correct at a size with many workgroups."""
     from outlier_suppression_amd import ops

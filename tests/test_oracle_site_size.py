@@ -1,7 +1,7 @@
 """The oracle against the REFERENCE's own one-thread run at the site sizes of BASELINE configs[3]
 (tests/golden/site_size.npz, made by tests/golden/make_golden_site_size.py; the inputs are re-drawn from the same seeded
 generators): per-tensor MSEFast searches on [32,128,768] masked hidden states (nested 2-D, float64 from the second call
-on), [32,12,128,128] attention probabilities (1-D, fp32 for ever) and -- OSQ_SLOW_TESTS=1 only, ~4 minutes of NumPy --
+on), [32,12,128,128] attention probabilities (1-D, fp32 for ever) and -- OSQ_SLOW_TESTS=1 only: 1.5 minutes of NumPy here, green at the round's last commit --
 [32,128,3072] GELU outputs; LSQ+ gradients on [32,128,768] and [32,128,3072].  With the sums in ATen's one-thread order
 (oracle/aten_sum.py::aten_sum_flat) every statistic after every call, every evaluation count and both gradients are
 EQUAL.  The GPU counterpart (the kernels' strict switch) is tests/test_gpu_strict_order.py."""

@@ -140,6 +140,10 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
             for (int b = 0; b < nblk; ++b) acc = acc + lds[(((s << g.P) + b) << nc_shift) + c];
             cascade_publish<T>(&part[s * sstride + (m << nc_shift) + c], acc);
         }
+        // Every wave drains ITS published values before the barrier: the workgroup's ticket (grid_last_block, thread 0)
+        // only waits for thread 0's own wave, and a workgroup-scope barrier is no promise about stores still in flight
+        // to memory (MI355X_MICROARCH.md, "valid forms": sc1 payload -> vmcnt(0) -> flag).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }

@@ -910,6 +910,9 @@ def main():
                       "devices_visible": torch.cuda.device_count(), "shared_gpu": share}
     from outlier_suppression_amd import _hip, calibration
     _hip.load()
+    for kv in filter(None, os.environ.get("OSQ_BENCH_TUNING", "").split(",")):      # A/B runs: "key=value,key=value" through osq_set_tuning
+        from outlier_suppression_amd import ops as _ops
+        _ops.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     q = make_quantizer(dev)
     xs, lengths = make_inputs(dev, args.buffers, seed=1234 + rank)
     lengths = lengths.to(dev)

@@ -431,6 +431,21 @@ int osq_gather_valid_tokens(const float* x, const osq_token_view* view, const in
                             int64_t* count_out, osq_stream stream);
 int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat, int64_t n, const int64_t* n_device, int n_evals,
                                      void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream);
+/* The strict evaluations of SEVERAL searches (the MSEFast observers of one forward: independent while fake-quant is off) as
+ * ROUNDS: one launch = one loss evaluation of every unfinished search, each in the reference's order as above.  A launch
+ * per evaluation of one site costs ~15 us whatever its size; a round pays that once for up to 128 sites.
+ *   table: osq_msefast_ordered_multi_bytes(n_sites) bytes of device memory, ZERO before _prepare (site table + the ticket
+ *          counters of every site); _prepare fills the site table (synchronous on `stream`) and returns the grid of a round;
+ *   per site: state (between osq_msefast_tensor_begin and _commit), the flat tensor (osq_gather_valid_tokens for a masked
+ *          site) with its host-side element bound n[i] and nullable device count n_device[i], and scratch of
+ *          osq_ordered_sum_scratch_bytes(n[i], 1) bytes;
+ *   _evals: n_evals rounds, then done_out[0] = 1 if every search has converged (nullable). */
+size_t osq_msefast_ordered_multi_bytes(int n_sites);
+int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
+                                      const int64_t* n, const int64_t* const* n_device, void* const* scratch,
+                                      const size_t* scratch_bytes, int n_sites, int* total_blocks_out, osq_stream stream);
+int osq_msefast_ordered_multi_evals(const void* table, int n_sites, int total_blocks, int n_evals, int32_t* done_out,
+                                    osq_stream stream);
 /* The whole per-tensor search in ONE persistent launch (between _begin and _commit; replaces the _evals_* / _done loop):
  * the valid part of the tensor is loaded once into the registers of a one-workgroup-per-CU grid, every loss
  * evaluation is one exchange of per-workgroup partial sums through the workspace.  view == NULL: x is flat, n

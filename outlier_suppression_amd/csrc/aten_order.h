@@ -89,12 +89,14 @@ template <> __device__ __forceinline__ float CascadeReader::get<float>(int64_t i
 template <> __device__ __forceinline__ double CascadeReader::get<double>(int64_t idx) const { return get_f64(idx); }
 
 // ---- stage 1: every workgroup; `lds` holds NS * S * NC values of T
+// bid / nblk: this workgroup's index among the workgroups that add THIS vector (the whole grid unless a launch serves several)
 template <typename T, int NS, int THREADS, typename Term>
-__device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restrict__ part, T* lds, Term term) {
+__device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restrict__ part, T* lds, Term term, const unsigned int bid,
+                                              const unsigned int nblk_grid, const int64_t first_unit = 0) {
     const int64_t units = g.chunks + 1;                     // the last one is what the levels still hold at the end
     const int64_t sstride = (g.chunks + 2) * g.NC;          // part[s][m][c]; m == chunks: open level 1, chunks + 1: open level 0
     const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
-    for (int64_t m = blockIdx.x; m < units; m += gridDim.x) {
+    for (int64_t m = first_unit + bid; m < units; m += nblk_grid) {
         const bool full = m < g.chunks;
         const int nblk = full ? g.S : g.tail_blocks;
         const int ntask = (nblk + ((!full && g.tail_rows) ? 1 : 0)) << nc_shift;
@@ -146,6 +148,81 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+}
+
+template <typename T, int NS, int THREADS, typename Term>
+__device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restrict__ part, T* lds, Term term) {
+    cascade_units<T, NS, THREADS, Term>(g, part, lds, term, blockIdx.x, gridDim.x);
+}
+
+// Stage 1 of ONE sum over the FULL level-1 chunks with the memory latency hidden.  The generic form above is a chain per
+// chunk -- loads, terms, barrier, the S block sums, publish -- of ~3 us with two workgroups per CU to overlap it: 1.7 us per
+// million elements, the whole cost of a strict MSEFast round.  Here a thread's S raw inputs of its NEXT chunk (`load(e)`,
+// Raw = what `eval` needs of element e) are in flight while the current chunk's terms are computed (`eval(raw)` -> T) and
+// added in order; the block sums go through a double-buffered LDS tile (one barrier per chunk), and a workgroup whose
+// threads outnumber a chunk's S * NC (block, column) pairs takes G = THREADS / (S * NC) chunks at a time (float64: NC is
+// half as wide).  Same additions in the same order.  Requires S * NC <= THREADS; `lds` holds 2 * THREADS values of T.
+// The open unit (m == chunks) stays with cascade_units(..., first_unit = chunks).
+template <typename T, int P, int THREADS, typename Raw, typename Load, typename Eval>
+__device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T* __restrict__ part, T* lds, Load load, Eval eval,
+                                                         const unsigned int bid, const unsigned int nblk_grid) {
+    constexpr int S = 1 << P;
+    constexpr int KB = 16;                                  // terms computed side by side (S = 16 or 32)
+    const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
+    const int tpc = S << nc_shift;                          // (block, column) pairs of a chunk
+    const int G = THREADS / tpc;
+    const int64_t ngroups = (g.chunks + G - 1) / G;
+    const int tid = threadIdx.x;
+    const int j = tid / tpc, rem = tid - j * tpc, blk = rem >> nc_shift, c = rem & (g.NC - 1);
+    const bool lane_ok = tid < G * tpc;
+    Raw cur[S], nxt[S];
+    auto fetch = [&](const int64_t grp, Raw (&r)[S]) {
+        const int64_t m = grp * G + j;
+        if (lane_ok && m < g.chunks) {
+            const int64_t row0 = ((m << P) + blk) << P;
+#pragma unroll
+            for (int k = 0; k < S; ++k) r[k] = load(((row0 + k) << nc_shift) + c);
+        }
+    };
+    int64_t grp = bid;
+    if (grp < ngroups) fetch(grp, cur);
+    int buf = 0;
+    for (; grp < ngroups; grp += nblk_grid) {
+        if (grp + nblk_grid < ngroups) fetch(grp + nblk_grid, nxt);
+        const int64_t m = grp * G + j;
+        T* const tile = lds + buf * THREADS;
+        if (lane_ok && m < g.chunks) {
+            T acc = T(0);
+#pragma unroll
+            for (int k0 = 0; k0 < S; k0 += KB) {
+                T t[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) t[k] = eval(cur[k0 + k]);
+#pragma unroll
+                for (int k = 0; k < KB; ++k) acc = acc + t[k];
+            }
+            tile[(((j << P) + blk) << nc_shift) + c] = acc;
+        }
+        __syncthreads();
+        if (tid < (G << nc_shift)) {
+            const int jj = tid >> nc_shift, cc = tid & (g.NC - 1);
+            const int64_t mm = grp * G + jj;
+            if (mm < g.chunks) {
+                T v[S];
+#pragma unroll
+                for (int b = 0; b < S; ++b) v[b] = tile[(((jj << P) + b) << nc_shift) + cc];
+                T a = T(0);
+#pragma unroll
+                for (int b = 0; b < S; ++b) a = a + v[b];
+                cascade_publish<T>(&part[(mm << nc_shift) + cc], a);
+            }
+        }
+        buf ^= 1;                                           // the next chunk's block sums go to the other tile: one barrier per chunk
+#pragma unroll
+        for (int k = 0; k < S; ++k) cur[k] = nxt[k];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's published sums have left before the workgroup's ticket
+    __syncthreads();
 }
 
 // ---- stage 2: the last workgroup; `lds` holds lds_values values of T (>= NS * NC + NC); the sums arrive in out[] of thread 0

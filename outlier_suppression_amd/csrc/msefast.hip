@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <string>
+#include <vector>
 #include <hip/hip_ext.h>
 #include "osq_device.h"
 #include "aten_order.h"
@@ -621,17 +622,14 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
 // the flat layout the reference's remove_padding builds (gather_valid_tokens_kernel: once per search, not per evaluation).
 constexpr int kOrdThreads = 512;
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
-__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
-                                                                            const int64_t* __restrict__ n_dev,
-                                                                            TensorSearch* __restrict__ ts, void* __restrict__ scratch,
-                                                                            unsigned int* __restrict__ counters, int W) {
-    if (ts->S.done) return;
-    __shared__ double lds_raw[kOrdLdsBytes / 8];
+// one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
+__device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, const int64_t n, TensorSearch* __restrict__ ts,
+                                                   void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W,
+                                                   const unsigned int bid, const unsigned int nblk, double* lds_raw) {
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
     const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
-    const int64_t n = n_dev ? n_dev[0] : n_host;
     if (f64) {
         const CascadeGeom g = cascade_geom(n, W / 2);
         // the float64 chain is VALU-bound on its division: the exact reciprocal sequence of the resident search (same bits,
@@ -644,8 +642,17 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
         };
         double* part = static_cast<double*>(scratch);
         double* lds = lds_raw;
-        cascade_units<double, 1, kOrdThreads>(g, part, lds, term);
-        if (grid_last_block(counters, gridDim.x)) {
+        if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
+            // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
+            auto load = [=](int64_t e) { return x[e]; };
+            auto eval = [=](float xf) { return fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax); };
+            if (g.P == 4) cascade_chunks_pipelined<double, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            else cascade_chunks_pipelined<double, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
+        } else {
+            cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
+        }
+        if (grid_last_block(counters, nblk, bid)) {
             double sum[1];
             cascade_finish<double, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 8, term, sum);
             if (threadIdx.x == 0) {
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
                 if (!ts->S.done)
                     loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
                                  &ts->scale_d);
-                grid_reset(counters, gridDim.x);
+                grid_reset(counters, nblk);
             }
         }
     } else {
@@ -661,8 +668,16 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
         auto term = [=](int64_t e, float (&t)[1]) { t[0] = sq_err(x[e], s, z, qmin, qmax); };
         float* part = static_cast<float*>(scratch);
         float* lds = reinterpret_cast<float*>(lds_raw);
-        cascade_units<float, 1, kOrdThreads>(g, part, lds, term);
-        if (grid_last_block(counters, gridDim.x)) {
+        if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
+            auto load = [=](int64_t e) { return x[e]; };
+            auto eval = [=](float xf) { return sq_err(xf, s, z, qmin, qmax); };
+            if (g.P == 4) cascade_chunks_pipelined<float, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            else cascade_chunks_pipelined<float, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
+        } else {
+            cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
+        }
+        if (grid_last_block(counters, nblk, bid)) {
             float sum[1];
             cascade_finish<float, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 4, term, sum);
             if (threadIdx.x == 0) {
@@ -670,10 +685,57 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
                 if (!ts->S.done)
                     loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
                                  &ts->scale_d);
-                grid_reset(counters, gridDim.x);
+                grid_reset(counters, nblk);
             }
         }
     }
+}
+
+__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
+                                                                            const int64_t* __restrict__ n_dev,
+                                                                            TensorSearch* __restrict__ ts, void* __restrict__ scratch,
+                                                                            unsigned int* __restrict__ counters, int W) {
+    if (ts->S.done) return;
+    __shared__ double lds_raw[kOrdLdsBytes / 8];
+    ordered_evaluation(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
+}
+
+// The strict form of the searches of a whole forward (the observers of an observer pass are independent): ONE launch per
+// ROUND = one loss evaluation of every unfinished search.  A launch-per-evaluation of one site costs ~15 us whatever its
+// size (dispatch, the ticket, the serial upper levels of the cascade, scipy's step) on top of ~1.7 us per million
+// elements; here that fixed part is paid once per round of up to 128 searches.  Site s owns the workgroups
+// block_begin .. block_begin + blocks - 1 of the 1-D grid, its own scratch and its own ticket counters.
+struct OrderedSite {
+    const float* x;
+    const int64_t* n_dev;
+    TensorSearch* ts;
+    void* scratch;
+    unsigned int* counters;
+    int64_t n_host;
+    unsigned int block_begin, blocks;
+    unsigned int pad[2];
+};
+static_assert(sizeof(OrderedSite) == 64, "OrderedSite is a 64-byte table entry");
+constexpr int kOrderedMaxSites = 128;
+constexpr size_t kOrderedCounterBytes = (1 + kTicketShards) * kTicketStride * sizeof(unsigned int);
+
+__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int W) {
+    __shared__ double lds_raw[kOrdLdsBytes / 8];
+    int lo = 0, hi = n_sites - 1;                                  // uniform: the site whose range holds this workgroup
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (sites[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const OrderedSite s = sites[lo];
+    if (s.ts->S.done) return;
+    ordered_evaluation(s.x, s.n_dev ? s.n_dev[0] : s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
+}
+
+__global__ void msefast_done_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int* __restrict__ done_out) {
+    int all = 1;
+    for (int i = threadIdx.x; i < n_sites; i += OSQ_WAVE) all &= sites[i].ts->S.done ? 1 : 0;
+    all = __all(all) ? 1 : 0;
+    if (threadIdx.x == 0) done_out[0] = all;
 }
 
 // remove_padding (observer.py:72-84) as a copy: out[(valid token j) * F + f] for the tokens t < lengths[b], sample by
@@ -1508,6 +1570,66 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     return check_launch("msefast_tensor_evals_ordered");
 }
 
+static int g_ord_groups = 8;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
+extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
+    if (n_sites <= 0) return 0;
+    return static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
+}
+
+extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
+                                                 const int64_t* n, const int64_t* const* n_device, void* const* scratch,
+                                                 const size_t* scratch_bytes, int n_sites, int* total_blocks_out, osq_stream stream) {
+    OSQ_REQUIRE(table && states && x_flat && n && scratch && scratch_bytes && total_blocks_out, "msefast_ordered_multi_prepare: null pointer");
+    OSQ_REQUIRE(n_sites > 0 && n_sites <= kOrderedMaxSites, "msefast_ordered_multi_prepare: 1 .. 128 searches per table");
+    OSQ_REQUIRE(table_bytes >= osq_msefast_ordered_multi_bytes(n_sites), "msefast_ordered_multi_prepare: table smaller than osq_msefast_ordered_multi_bytes(n_sites)");
+    OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
+                "msefast_ordered_multi_prepare: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
+    std::vector<OrderedSite> host(static_cast<size_t>(n_sites));
+    char* const counters0 = static_cast<char*>(table) + static_cast<size_t>(n_sites) * sizeof(OrderedSite);
+    int64_t total = 0;
+    for (int i = 0; i < n_sites; ++i) {
+        OSQ_REQUIRE(states[i] && x_flat[i] && n[i] > 0 && scratch[i], "msefast_ordered_multi_prepare: bad site");
+        OSQ_REQUIRE(scratch_bytes[i] >= osq_ordered_sum_scratch_bytes(n[i], 1), "msefast_ordered_multi_prepare: scratch smaller than osq_ordered_sum_scratch_bytes(n, 1)");
+        const CascadeGeom g = cascade_geom(n[i], g_mse_sum_order / 2);
+        OSQ_REQUIRE(g.P <= kCascadeMaxP, "msefast_ordered_multi_prepare: tensor too large");
+        OrderedSite& s = host[static_cast<size_t>(i)];
+        s.x = x_flat[i];
+        s.n_dev = n_device ? n_device[i] : nullptr;
+        s.ts = static_cast<TensorSearch*>(states[i]);
+        s.scratch = scratch[i];
+        s.counters = reinterpret_cast<unsigned int*>(counters0 + static_cast<size_t>(i) * kOrderedCounterBytes);
+        s.n_host = n[i];
+        s.block_begin = static_cast<unsigned int>(total);
+        // a workgroup of a round takes g_ord_groups chunk groups (8192 elements each, fp32 and float64 alike) so that the loads of
+        // its next group travel under the arithmetic of the current one (aten_order.h, cascade_chunks_pipelined)
+        const int64_t groups = (g.chunks + 1) / 2 + 1;
+        s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>((groups + g_ord_groups - 1) / g_ord_groups, 1), kMaxBlocks));
+        s.pad[0] = s.pad[1] = 0u;
+        total += s.blocks;
+    }
+    OSQ_REQUIRE(total < (1ll << 31), "msefast_ordered_multi_prepare: too many workgroups");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the counters behind the table stay as the caller zeroed them; the table is in place when this returns
+    OSQ_REQUIRE(hipMemcpyAsync(table, host.data(), host.size() * sizeof(OrderedSite), hipMemcpyHostToDevice, st) == hipSuccess &&
+                hipStreamSynchronize(st) == hipSuccess, "msefast_ordered_multi_prepare: copying the table failed");
+    *total_blocks_out = static_cast<int>(total);
+    return OSQ_OK;
+}
+
+extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, int total_blocks, int n_evals, int32_t* done_out,
+                                               osq_stream stream) {
+    OSQ_REQUIRE(table && n_sites > 0 && n_sites <= kOrderedMaxSites && total_blocks > 0 && n_evals >= 0, "msefast_ordered_multi_evals: bad argument");
+    OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
+                "msefast_ordered_multi_evals: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const OrderedSite* sites = static_cast<const OrderedSite*>(table);
+    for (int e = 0; e < n_evals; ++e)
+        hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, n_sites,
+                           g_mse_sum_order);
+    if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
+    return check_launch("msefast_ordered_multi_evals");
+}
+
 // osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 in the environment (the switch for processes that SHARE a GPU:
 // persistent grids of two processes cannot be ordered against each other): per-tensor searches run one launch per evaluation
 static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -1515,6 +1637,7 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
+    if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }

@@ -390,12 +390,14 @@ constexpr unsigned int kTicketShards = 32;
 constexpr unsigned int kTicketStride = 16;   // one 64-byte line per counter
 
 // Call from thread 0 AFTER it has published the workgroup's partial; every thread gets the answer.
-__device__ __forceinline__ bool grid_last_block(unsigned int* counters, unsigned int nblocks) {
+// bid / nblocks: this workgroup's index among the workgroups that share `counters` (a launch that serves several
+// independent reductions gives each its own range of workgroups and its own counters).
+__device__ __forceinline__ bool grid_last_block(unsigned int* counters, unsigned int nblocks, unsigned int bid) {
     __shared__ unsigned int s_last;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the published partial has left this CU
         const unsigned int shards = nblocks < kTicketShards ? nblocks : kTicketShards;
-        const unsigned int shard = blockIdx.x % shards;
+        const unsigned int shard = bid % shards;
         const unsigned int members = (nblocks - shard + shards - 1) / shards;
         unsigned int last = 0u;
         const unsigned int t = __hip_atomic_fetch_add(&counters[(1 + shard) * kTicketStride], 1u, __ATOMIC_RELAXED,
@@ -408,6 +410,9 @@ __device__ __forceinline__ bool grid_last_block(unsigned int* counters, unsigned
     }
     __syncthreads();
     return s_last != 0u;
+}
+__device__ __forceinline__ bool grid_last_block(unsigned int* counters, unsigned int nblocks) {
+    return grid_last_block(counters, nblocks, blockIdx.x);
 }
 // thread 0 of the last workgroup
 __device__ __forceinline__ void grid_reset(unsigned int* counters, unsigned int nblocks) {

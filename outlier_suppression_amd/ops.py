@@ -700,6 +700,63 @@ def _msefast_tensor_run_ordered(r, chunk, two_d):
             break
 
 
+ORDERED_GROUP_SITES = 128     # searches one table of osq_msefast_ordered_multi_* holds
+
+
+def msefast_tensor_run_ordered_group(group, chunk=64):
+    """The strict form of several searches (MseSearch records of one device, e.g. the MSEFast observers of one forward):
+    rounds of ONE launch = one loss evaluation of every unfinished search, each sum in the order of torch.sum on a
+    one-thread host (csrc/aten_order.h, osq_msefast_ordered_multi_*).  Same numbers as _msefast_tensor_run_ordered
+    search by search (tests/test_gpu_strict_order.py)."""
+    lib = _hip.load()
+    n_sites = len(group)
+    assert 0 < n_sites <= ORDERED_GROUP_SITES
+    dev = group[0].x.device
+    st = _hip.stream_ptr(dev)
+    flats, ns, n_devs, keep = [], [], [], []
+    for r in group:
+        if r.view is None:
+            flats.append(r.x)
+            ns.append(r.x.numel())
+            n_devs.append(None)
+        else:
+            n = r.view.batch * r.view.tokens * r.view.feat_outer * r.view.feat_inner
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            _hip.check(lib.osq_gather_valid_tokens(_hip.ptr(r.x), ctypes.byref(r.view), _hip.ptr(r.lengths), _hip.ptr(flat),
+                                                   _hip.ptr(n_dev), st), "gather_valid_tokens")
+            flats.append(flat)
+            ns.append(n)
+            n_devs.append(n_dev)
+    sizes = [int(lib.osq_ordered_sum_scratch_bytes(int(n), 1)) for n in ns]
+    offs, total = [], 0
+    for b in sizes:
+        offs.append(total)
+        total += (b + 255) // 256 * 256
+    scratch = torch.empty(total, dtype=torch.uint8, device=dev)
+    table_bytes = int(lib.osq_msefast_ordered_multi_bytes(n_sites))
+    table = torch.zeros(table_bytes, dtype=torch.uint8, device=dev)
+    vp = ctypes.c_void_p
+    states = (vp * n_sites)(*[_hip.ptr(r.state) for r in group])
+    xs = (vp * n_sites)(*[_hip.ptr(f) for f in flats])
+    n_arr = (ctypes.c_int64 * n_sites)(*ns)
+    nd_arr = (vp * n_sites)(*[_hip.ptr(t) for t in n_devs])
+    sc_arr = (vp * n_sites)(*[scratch.data_ptr() + o for o in offs])
+    sb_arr = (ctypes.c_size_t * n_sites)(*sizes)
+    blocks = ctypes.c_int(0)
+    _hip.check(lib.osq_msefast_ordered_multi_prepare(_hip.ptr(table), table_bytes, states, xs, n_arr, nd_arr, sc_arr, sb_arr, n_sites,
+                                                     ctypes.byref(blocks), st), "msefast_ordered_multi_prepare")
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    launched = 0
+    while True:
+        _hip.check(lib.osq_msefast_ordered_multi_evals(_hip.ptr(table), n_sites, blocks.value, chunk, _hip.ptr(done), st),
+                   "msefast_ordered_multi_evals")
+        launched += chunk
+        if int(done.item()) or launched > 500 * 500:
+            break
+    return launched
+
+
 def msefast_tensor_run_group(group):
     """Several searches (MseSearch records of one device) in ONE persistent launch; False = the group does not fit (nothing
     launched).  The caller sizes groups with msefast_resident_slots."""

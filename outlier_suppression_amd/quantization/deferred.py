@@ -43,6 +43,12 @@ class DeferredSites:
         pending, self.mse = self.mse, []
         if not pending:
             return 0
+        if ops.reference_sum_order("mse"):
+            # strict sums: one launch per ROUND of loss evaluations of all the forward's searches (128 per table)
+            for i in range(0, len(pending), ops.ORDERED_GROUP_SITES):
+                ops.msefast_tensor_run_ordered_group([it[1] for it in pending[i:i + ops.ORDERED_GROUP_SITES]])
+                self.launches += 1
+            return self._commit_mse(pending)
         # greedy groups: at most max_sites searches and max_slots float4 slots per lane in a launch (16 and 32); what cannot
         # be resident runs alone
         max_slots, max_sites = ops.msefast_resident_limits()
@@ -64,6 +70,9 @@ class DeferredSites:
                 for it in g:
                     ops.msefast_tensor_run(it[1], None, it[2])
             self.launches += 1
+        return self._commit_mse(pending)
+
+    def _commit_mse(self, pending):
         for obs, search, two_d, sink, cnt, rule in pending:
             obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink,
                                                       obs._ref_flags(obs.min_val.device))

@@ -39,3 +39,38 @@ def same_f32(a, b):
 @pytest.fixture(scope="session")
 def eq32():
     return same_f32
+
+
+@pytest.fixture()
+def order_free():
+    """The ORDER-FREE tier for one test (outlier_suppression_amd.set_strict(False)): exact / float64 sums, the resident
+    per-tensor MSEFast searches; the package default (the reference's one-thread summation order) is restored afterwards."""
+    import outlier_suppression_amd as osq
+    osq.set_strict(False)
+    yield
+    osq.set_strict(True)
+
+
+def aten_order_mean(sq):
+    """torch's CPU mean on a one-thread host with 8 fp32 SIMD lanes (float64: 4) -- the order the package's default sums follow."""
+    from oracle.aten_sum import aten_mean_flat
+    sq = np.asarray(sq)
+    dt = np.float64 if sq.dtype == np.float64 else np.float32
+    return aten_mean_flat(sq.reshape(-1), 4 if dt is np.float64 else 8, dt)
+
+
+@pytest.fixture(params=["reference-order", "order-free"])
+def sum_tier(request):
+    """Both tiers of the two whole-tensor sums for one test: the package default (the reference's one-thread order;
+    the oracle's MSE loss is then summed by oracle/aten_sum.py in that order) and set_strict(False) (exact sums on the
+    device, the oracle's plain float64 mean)."""
+    import outlier_suppression_amd as osq
+    from oracle import observer_oracle as OB
+    old = OB.MEAN_LIKE_TORCH
+    if request.param == "order-free":
+        osq.set_strict(False)
+    else:
+        OB.MEAN_LIKE_TORCH = aten_order_mean
+    yield request.param
+    OB.MEAN_LIKE_TORCH = old
+    osq.set_strict(True)

@@ -253,9 +253,9 @@ def test_resident_kernels_do_not_spill():
 
 
 def test_strict_and_fast_switches_from_the_environment():
-    """OSQ_STRICT=1 / OSQ_FAST=1 are applied when the library is first loaded (outlier_suppression_amd._apply_environment):
-    the strict switch sets both summation orders, the fast switch opts into the one-launch LayerNorm site; without them
-    the defaults are the results-identical configuration (order-free sums, eager LayerNorm sites)."""
+    """The switches applied when the library is first loaded (outlier_suppression_amd._apply_environment): by default
+    both sums of the path follow the reference's one-thread order (8-lane host) and the LayerNorm sites stay eager -- the
+    results-identical configuration; OSQ_STRICT=0 opts into order-free sums, OSQ_FAST=1 into the one-launch LayerNorm site."""
     import subprocess
     import sys
     code = ("from outlier_suppression_amd import _hip, ops, util_layernorm as UL; _hip.load(); "
@@ -263,6 +263,8 @@ def test_strict_and_fast_switches_from_the_environment():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("OSQ_STRICT", "OSQ_FAST", "OSQ_STRICT_SIMD")}
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["0", "0", "False", "True"], out.stdout + out.stderr
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, OSQ_STRICT="1", OSQ_FAST="1"), capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["8", "8", "True", "True"], out.stdout + out.stderr
+    assert out.stdout.split() == ["8", "8", "False", "True"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, OSQ_STRICT="0", OSQ_FAST="1"), capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["0", "0", "True", "True"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, OSQ_STRICT_SIMD="16"), capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["16", "16", "False", "True"], out.stdout + out.stderr

@@ -322,7 +322,7 @@ def test_fused_step_vs_three_launches_random(dev):
         ops.set_tuning("fused_step", 1)
 
 
-def test_other_observers_vs_oracle(eq32, dev):
+def test_other_observers_vs_oracle(eq32, dev, sum_tier):
     """The remaining observers of ObserverDict on random small activations (masked and not, odd shapes, one-sided data,
     several batches): AvgQuantileObserver (torch.histc-exact histogram + clip), MSEObserver / AvgMSEObserver (grid argmin),
     MSEFastObserver / AvgMSEFastObserver per tensor (bounded Brent, float64 statistics from the second batch on)."""
@@ -394,7 +394,7 @@ def test_other_observers_vs_oracle(eq32, dev):
                     (tag, got_min, want_min, got_max, want_max)
 
 
-def test_deferred_forwards_vs_oracle(eq32, dev):
+def test_deferred_forwards_vs_oracle(eq32, dev, sum_tier):
     """Observer passes as calibrate() runs them: the sites of a forward recorded and reduced together
     (quantization/deferred.py) -- random groups of sites (layouts, masks, observers, MSEFast searches among them), several
     forwards, every statistic and parameter against the oracle."""
@@ -784,7 +784,7 @@ def test_quantized_operator_arguments(eq32, dev):
         assert torch.equal(qm.weight.cpu(), mod.weight.detach()) and (b is None) == (getattr(mod, "bias", None) is None), (case, kind)
 
 
-def test_msefast_float32_statistics_corner(dev):
+def test_msefast_float32_statistics_corner(dev, sum_tier):
     """Per-tensor AvgMSEFast on data with a populated lower bound (GELU-like: the optimal range keeps the data's own minimum):
     the reference's min_val is then the float32 extremum, batch after batch -- its running mean is fp32 arithmetic, the next
     batch is searched on fp32 input, and while max_val is float32 too the parameters are derived in fp32.  Statistics,

@@ -10,9 +10,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_last_block_reductions_under_load():
+def test_last_block_reductions_under_load(sum_tier):
+    """Both tiers of the LSQ+ backward's sums: the order-free kernel (float64 partials, one ticket) at 1e-5 of the float64
+    torch sum, and the default reference-order kernel (aten_order.h: published chunk sums, ticket, serial upper levels) --
+    autograd's TWO fp32 sums (sum g_in, sum -g_mul) cancel, so its bound is relative to their magnitudes, which a stale
+    chunk sum or a lost ticket still exceeds by orders of magnitude."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    strict = sum_tier == "reference-order"
     from outlier_suppression_amd import ops
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(123)
@@ -23,7 +28,7 @@ def test_last_block_reductions_under_load():
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     lens = [torch.randint(1, 65, (16,), generator=gen).to(dev) for _ in range(8)]
     torch.cuda.synchronize()
-    rounds = 450                       # x 2 streams x 69 sizes x (1 + 1/3 + 2/5) launches of this library: 1.08e5, each beside its stock reductions
+    rounds = 150 if strict else 450    # x 2 streams x 69 sizes x (1 + 1/3 + 2/5) launches of this library: 1.08e5, each beside its stock reductions
     bad = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in streams]
     s1 = torch.tensor([0.731], device=dev)
     z1 = torch.tensor([29.0], device=dev)
@@ -50,7 +55,8 @@ def test_last_block_reductions_under_load():
                         g_mul = gy * s1
                         ref_dz = (torch.where(inside, g_mul, torch.zeros_like(gy)) - g_mul).double().sum()
                         bad[si][1] += (dx != torch.where(inside, g_mul, torch.zeros_like(gy)) / s1).long().sum()
-                        bad[si][1] += ((dz.double().sum() - ref_dz).abs() > 1e-5 * ref_dz.abs() + 1e-6).long()
+                        bound = 1e-5 * (g_mul.abs().double().sum() if strict else ref_dz.abs()) + 1e-6
+                        bad[si][1] += ((dz.double().sum() - ref_dz).abs() > bound).long()
                         launches += 1
                     if (r + k) % 5 == 0:
                         # 3. masked token observer: per-token extrema + two-workgroup selection with its rendezvous word
@@ -67,5 +73,5 @@ def test_last_block_reductions_under_load():
                         launches += 2
     torch.cuda.synchronize()
     total = (bad[0] + bad[1]).cpu().tolist()
-    assert launches >= 100000
+    assert launches >= (30000 if strict else 100000)
     assert total == [0, 0, 0], total

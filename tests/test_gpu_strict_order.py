@@ -36,7 +36,7 @@ def strict():
     import outlier_suppression_amd as osq
     osq.set_strict(True)
     yield
-    osq.set_strict(False)
+    osq.set_strict(True)
 
 
 def N(t):
@@ -70,7 +70,7 @@ def test_ordered_backward_equals_oracle_at_any_length(dev, width):
             assert np.array_equal(N(dx), rdx), n
             assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (n, width, ds.item(), rds, dz.item(), rdz)
     finally:
-        ops.set_tuning("bwd_sum_order", 0)
+        ops.set_tuning("bwd_sum_order", 8)      # the default
 
 
 def _oracle_order_mean(width):
@@ -133,7 +133,7 @@ def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
             assert evals == counter[0], (shape, evals, counter[0])
     finally:
         OB.MEAN_LIKE_TORCH = None
-        ops.set_tuning("mse_sum_order", 0)
+        ops.set_tuning("mse_sum_order", 8)      # the default
 
 
 @pytest.mark.parametrize("case", [c[0] for c in MSE_CASES])
@@ -182,3 +182,46 @@ def test_lsqplus_site_size_gradients_equal_reference_in_its_summation_order(gold
     assert checksum(xd.grad) == int(g[f"{name}_dxsum"][0])
     assert np.array_equal(N(s.grad), g[f"{name}_dscale"]) and np.array_equal(N(z.grad), g[f"{name}_dzp"]), \
         (name, N(s.grad), g[f"{name}_dscale"], N(z.grad), g[f"{name}_dzp"])
+
+
+def test_ordered_rounds_equal_search_by_search(dev, strict):
+    """osq_msefast_ordered_multi_*: the strict evaluations of several searches as rounds (one launch = one evaluation of
+    every unfinished search) against the same searches run one by one (one launch per evaluation): converged ranges,
+    evaluation counts and the running statistics after two batches (fp32 call, then the float64 one) equal bit for bit."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for shape, seq_pos, masked in (((8, 64, 96), 1, True), ((4, 6, 32, 32), 2, True), ((16, 128, 768), 1, True),
+                                   ((3, 50, 37), 1, False), ((32, 128, 768), 1, True), ((2, 16, 8), 1, True)):
+        xs = []
+        for _ in range(2):
+            x = torch.randn(*shape, generator=g)
+            if len(shape) == 4:
+                x = torch.softmax(x * 2, -1)
+            else:
+                x[..., 3] *= 12
+            xs.append(x.to(dev))
+        L = (torch.randint(1, shape[seq_pos] + 1, (shape[0],), generator=g) if masked else torch.full((shape[0],), shape[seq_pos])).to(dev)
+        cases.append((xs, L, seq_pos))
+
+    def observers():
+        return [(AvgMSEFastObserver if i % 2 == 0 else MSEFastObserver)(bit=6 if i % 3 else 4, symmetric=False).to(dev) for i in range(len(cases))]
+
+    one_by_one = observers()
+    for b in range(2):
+        for ob, (xs, L, sp) in zip(one_by_one, cases):
+            ob(xs[b], L, sp)
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    rounds = observers()
+    for ob in rounds:
+        object.__setattr__(ob, "_defer_ok", True)                  # what the quantizer of an observer pass grants
+    with deferred_observation() as sites:
+        for b in range(2):
+            for ob, (xs, L, sp) in zip(rounds, cases):
+                ob(xs[b], L, sp)
+            assert len(sites.mse) == len(cases)
+            sites.flush()
+    for a, b in zip(one_by_one, rounds):
+        assert np.array_equal(N(a.min_val), N(b.min_val)) and np.array_equal(N(a.max_val), N(b.max_val))
+        assert np.array_equal(N(a.last_nfev), N(b.last_nfev))

@@ -161,65 +161,82 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
 // Raw = what `eval` needs of element e) are in flight while the current chunk's terms are computed (`eval(raw)` -> T) and
 // added in order; the block sums go through a double-buffered LDS tile (one barrier per chunk), and a workgroup whose
 // threads outnumber a chunk's S * NC (block, column) pairs takes G = THREADS / (S * NC) chunks at a time (float64: NC is
-// half as wide).  Same additions in the same order.  Requires S * NC <= THREADS; `lds` holds 2 * THREADS values of T.
+// half as wide).  NS sums share the pass (`eval(raw, e, t[NS])`; it may write per-element results on the way).  Same
+// additions in the same order.  Requires S * NC <= THREADS; `lds` holds 2 * NS * THREADS values of T.
 // The open unit (m == chunks) stays with cascade_units(..., first_unit = chunks).
-template <typename T, int P, int THREADS, typename Raw, typename Load, typename Eval>
+template <typename T, int NS, int P, int THREADS, typename Raw, typename Load, typename Eval>
 __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T* __restrict__ part, T* lds, Load load, Eval eval,
                                                          const unsigned int bid, const unsigned int nblk_grid) {
     constexpr int S = 1 << P;
-    constexpr int KB = 16;                                  // terms computed side by side (S = 16 or 32)
+    constexpr int R = 16;                                   // rows in flight per thread: a block of S = 32 rows is two steps
+    constexpr int H = S / R;
+    constexpr int KB = NS == 1 ? 16 : 8;                    // terms computed side by side
     const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
+    const int64_t sstride = (g.chunks + 2) * g.NC;          // part[s][m][c], as in cascade_units
     const int tpc = S << nc_shift;                          // (block, column) pairs of a chunk
     const int G = THREADS / tpc;
     const int64_t ngroups = (g.chunks + G - 1) / G;
     const int tid = threadIdx.x;
     const int j = tid / tpc, rem = tid - j * tpc, blk = rem >> nc_shift, c = rem & (g.NC - 1);
     const bool lane_ok = tid < G * tpc;
-    Raw cur[S], nxt[S];
-    auto fetch = [&](const int64_t grp, Raw (&r)[S]) {
+    Raw cur[R], nxt[R];
+    auto fetch = [&](const int64_t grp, const int h, Raw (&r)[R]) {
         const int64_t m = grp * G + j;
         if (lane_ok && m < g.chunks) {
-            const int64_t row0 = ((m << P) + blk) << P;
+            const int64_t row0 = (((m << P) + blk) << P) + h * R;
 #pragma unroll
-            for (int k = 0; k < S; ++k) r[k] = load(((row0 + k) << nc_shift) + c);
+            for (int k = 0; k < R; ++k) r[k] = load(((row0 + k) << nc_shift) + c);
         }
     };
     int64_t grp = bid;
-    if (grp < ngroups) fetch(grp, cur);
+    if (grp < ngroups) fetch(grp, 0, cur);
     int buf = 0;
     for (; grp < ngroups; grp += nblk_grid) {
-        if (grp + nblk_grid < ngroups) fetch(grp + nblk_grid, nxt);
         const int64_t m = grp * G + j;
-        T* const tile = lds + buf * THREADS;
-        if (lane_ok && m < g.chunks) {
-            T acc = T(0);
+        T* const tile = lds + buf * (NS * THREADS);
+        T acc[NS];
 #pragma unroll
-            for (int k0 = 0; k0 < S; k0 += KB) {
-                T t[KB];
+        for (int s = 0; s < NS; ++s) acc[s] = T(0);
 #pragma unroll
-                for (int k = 0; k < KB; ++k) t[k] = eval(cur[k0 + k]);
+        for (int h = 0; h < H; ++h) {
+            if (h + 1 < H) fetch(grp, h + 1, nxt);
+            else if (grp + nblk_grid < ngroups) fetch(grp + nblk_grid, 0, nxt);
+            if (lane_ok && m < g.chunks) {
+                const int64_t row0 = (((m << P) + blk) << P) + h * R;
 #pragma unroll
-                for (int k = 0; k < KB; ++k) acc = acc + t[k];
+                for (int k0 = 0; k0 < R; k0 += KB) {
+                    T t[KB][NS];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) eval(cur[k0 + k], ((row0 + k0 + k) << nc_shift) + c, t[k]);
+#pragma unroll
+                    for (int k = 0; k < KB; ++k)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) acc[s] = acc[s] + t[k][s];
+                }
             }
-            tile[(((j << P) + blk) << nc_shift) + c] = acc;
+#pragma unroll
+            for (int k = 0; k < R; ++k) cur[k] = nxt[k];
+        }
+        if (lane_ok && m < g.chunks) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) tile[s * THREADS + (((j << P) + blk) << nc_shift) + c] = acc[s];
         }
         __syncthreads();
-        if (tid < (G << nc_shift)) {
-            const int jj = tid >> nc_shift, cc = tid & (g.NC - 1);
+        for (int t = tid; t < NS * (G << nc_shift); t += THREADS) {
+            const int s = t / (G << nc_shift), r = t - s * (G << nc_shift);
+            const int jj = r >> nc_shift, cc = r & (g.NC - 1);
             const int64_t mm = grp * G + jj;
             if (mm < g.chunks) {
                 T v[S];
 #pragma unroll
-                for (int b = 0; b < S; ++b) v[b] = tile[(((jj << P) + b) << nc_shift) + cc];
+                for (int b = 0; b < S; ++b) v[b] = tile[s * THREADS + (((jj << P) + b) << nc_shift) + cc];
                 T a = T(0);
 #pragma unroll
                 for (int b = 0; b < S; ++b) a = a + v[b];
-                cascade_publish<T>(&part[(mm << nc_shift) + cc], a);
+                cascade_publish<T>(&part[s * sstride + (mm << nc_shift) + cc], a);
             }
         }
         buf ^= 1;                                           // the next chunk's block sums go to the other tile: one barrier per chunk
-#pragma unroll
-        for (int k = 0; k < S; ++k) cur[k] = nxt[k];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's published sums have left before the workgroup's ticket
     __syncthreads();
@@ -260,42 +277,44 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
     const int64_t units2 = g.chunks >> g.P;                 // full level-2 units
     const CascadeReader rd(part, static_cast<size_t>(NS) * static_cast<size_t>(sstride) * sizeof(T));
     T* const col = lds;                                     // [NS][NC]
-    T* const tile = lds + (NS << nc_shift);                 // [QT][NC]
-    const int QT = (lds_values - (NS << nc_shift)) >> nc_shift;
-    for (int s = 0; s < NS; ++s) {
-        const int64_t base = s * sstride;
-        T acc3 = T(0);
-        for (int64_t q0 = 0; q0 < units2; q0 += QT) {
-            const int nq = static_cast<int>(units2 - q0 < QT ? units2 - q0 : QT);
-            for (int task = threadIdx.x; task < (nq << nc_shift); task += THREADS) {
-                const int q = task >> nc_shift, c = task & (g.NC - 1);
-                const int64_t first = base + ((((q0 + q) << g.P)) << nc_shift) + c;
-                T a = T(0);
-                for (int j0 = 0; j0 < g.S; j0 += 16) {
-                    T v[16];
+    T* const tile = lds + (NS << nc_shift);                 // [NS][QT][NC]: the NS sums advance together
+    const int QT = ((lds_values - (NS << nc_shift)) / NS) >> nc_shift;
+    const int tid = threadIdx.x;
+    const bool owner = tid < (NS << nc_shift);              // thread (s, c): level 3 and the open levels of column c of sum s
+    const int my_s = tid >> nc_shift, my_c = tid & (g.NC - 1);
+    T acc3 = T(0);
+    for (int64_t q0 = 0; q0 < units2; q0 += QT) {
+        const int nq = static_cast<int>(units2 - q0 < QT ? units2 - q0 : QT);
+        const int per_sum = nq << nc_shift;
+        for (int task = tid; task < NS * per_sum; task += THREADS) {
+            const int s = task / per_sum, r = task - s * per_sum;
+            const int q = r >> nc_shift, c = r & (g.NC - 1);
+            const int64_t first = s * sstride + ((((q0 + q) << g.P)) << nc_shift) + c;
+            T a = T(0);
+            for (int j0 = 0; j0 < g.S; j0 += 16) {
+                T v[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = rd.get<T>(first + (static_cast<int64_t>(j0 + j) << nc_shift));
+                for (int j = 0; j < 16; ++j) v[j] = rd.get<T>(first + (static_cast<int64_t>(j0 + j) << nc_shift));
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) a = a + v[j];
-                }
-                tile[(q << nc_shift) + c] = a;
+                for (int j = 0; j < 16; ++j) a = a + v[j];
             }
-            __syncthreads();
-            if (static_cast<int>(threadIdx.x) < g.NC)
-                for (int q = 0; q < nq; ++q) acc3 = acc3 + tile[(q << nc_shift) + threadIdx.x];
-            __syncthreads();
+            tile[((s * QT + q) << nc_shift) + c] = a;
         }
-        if (static_cast<int>(threadIdx.x) < g.NC) {
-            const int c = threadIdx.x;
-            T acc2 = T(0);
-            for (int64_t m = units2 << g.P; m < g.chunks; ++m) acc2 = acc2 + rd.get<T>(base + (m << nc_shift) + c);
-            const T acc1 = rd.get<T>(base + (g.chunks << nc_shift) + c);
-            T acc0 = g.tail_rows ? rd.get<T>(base + ((g.chunks + 1) << nc_shift) + c) : T(0);
-            acc0 = acc0 + acc1;
-            acc0 = acc0 + acc2;
-            acc0 = acc0 + acc3;
-            col[(s << nc_shift) + c] = acc0;
-        }
+        __syncthreads();
+        if (owner)
+            for (int q = 0; q < nq; ++q) acc3 = acc3 + tile[((my_s * QT + q) << nc_shift) + my_c];
+        __syncthreads();
+    }
+    if (owner) {
+        const int64_t base = my_s * sstride;
+        T acc2 = T(0);
+        for (int64_t m = units2 << g.P; m < g.chunks; ++m) acc2 = acc2 + rd.get<T>(base + (m << nc_shift) + my_c);
+        const T acc1 = rd.get<T>(base + (g.chunks << nc_shift) + my_c);
+        T acc0 = g.tail_rows ? rd.get<T>(base + ((g.chunks + 1) << nc_shift) + my_c) : T(0);
+        acc0 = acc0 + acc1;
+        acc0 = acc0 + acc2;
+        acc0 = acc0 + acc3;
+        col[(my_s << nc_shift) + my_c] = acc0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -20,6 +20,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // tuning knobs of the dense per-tensor kernel (osq_set_tuning): loads in flight per lane, grid cap, and
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
+static int g_bwd_ord_chunks = 4;     // osq_set_tuning("bwd_order_chunks", n): level-1 chunks per workgroup of the reference-order backward
 static int g_bwd_sum_order = 0;      // osq_set_tuning("bwd_sum_order", 0 | 8 | 16): the LSQ / LSQ+ gradients summed in ATen's one-thread CPU order on 8- / 16-lane vectors (strict switch, lsq_bwd_tensor_ordered_kernel)
 static int g_fq_max_blocks = 8192;
 static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void lsq_bwd_tensor_kernel(
 // equal_reference_in_its_summation_order) and torch's own autograd run on one thread at site size; the default sums in float64.
 constexpr int kBwdOrdThreads = 512;
 constexpr int kBwdOrdLdsBytes = 32 * 1024;                    // stage 1: 4 sums x S x NC fp32 values (<= 4 x 32 x 64 x 4 B)
-__global__ __launch_bounds__(kBwdOrdThreads) void lsq_bwd_tensor_ordered_kernel(
+__global__ __launch_bounds__(kBwdOrdThreads, 4) void lsq_bwd_tensor_ordered_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ dx, int64_t n,
     const float* __restrict__ scale_p, const void* __restrict__ zp_p, int zp_type, int mode, float g,
     float qmin, float qmax, float* __restrict__ dscale, float* __restrict__ dzp, float* __restrict__ part,
@@ -503,7 +504,29 @@ __global__ __launch_bounds__(kBwdOrdThreads) void lsq_bwd_tensor_ordered_kernel(
         t[2] = g_in;
         t[3] = -g_mul;
     };
-    cascade_units<float, 4, kBwdOrdThreads>(geom, part, lds, term);
+    if (geom.S * geom.NC <= kBwdOrdThreads && geom.chunks > 0) {
+        // full chunks: the (x, gy) pairs of a workgroup's next chunk travel under the arithmetic of the current one
+        // (aten_order.h, cascade_chunks_pipelined); the open unit keeps the generic form
+        struct Pair { float x, gy; };
+        auto load = [=](int64_t i) { return Pair{x[i], gy[i]}; };
+        auto eval = [=](const Pair r, int64_t i, float (&t)[4]) {
+            float x_int;
+            const float q = quantize_value(r.x, s, z, qmin, qmax, &x_int);
+            const bool inside = (x_int >= qmin) && (x_int <= qmax);
+            const float g_mul = r.gy * s;
+            const float g_in = inside ? g_mul : 0.0f;
+            dx[i] = g_in / s;
+            t[0] = r.gy * (q - z);
+            t[1] = (-g_in) * ((r.x / s) / s);
+            t[2] = g_in;
+            t[3] = -g_mul;
+        };
+        if (geom.P == 4) cascade_chunks_pipelined<float, 4, 4, kBwdOrdThreads, Pair>(geom, part, lds, load, eval, blockIdx.x, gridDim.x);
+        else cascade_chunks_pipelined<float, 4, 5, kBwdOrdThreads, Pair>(geom, part, lds, load, eval, blockIdx.x, gridDim.x);
+        cascade_units<float, 4, kBwdOrdThreads>(geom, part, lds, term, blockIdx.x, gridDim.x, geom.chunks);
+    } else {
+        cascade_units<float, 4, kBwdOrdThreads>(geom, part, lds, term);
+    }
     if (grid_last_block(counters, gridDim.x)) {
         float sums[4];
         cascade_finish<float, 4, kBwdOrdThreads>(geom, part, lds, kBwdOrdLdsBytes / 4, term, sums);
@@ -854,7 +877,10 @@ extern "C" int osq_lsq_backward_per_tensor_ordered(const float* x, const float* 
     const CascadeGeom geom = cascade_geom(n, g_bwd_sum_order);
     OSQ_REQUIRE(geom.P <= kCascadeMaxP, "lsq_backward_per_tensor_ordered: tensor too large");
     Workspace ws(workspace);
-    const int grid = static_cast<int>(std::min<int64_t>(geom.chunks + 1, kMaxBlocks));
+    // a workgroup takes g_bwd_ord_chunks level-1 chunks so that its next chunk's loads travel under the current one's arithmetic
+    // (at least 1024 workgroups while there are that many chunks: below ~12 M elements one chunk per workgroup measured best)
+    const int64_t units = geom.chunks + 1;
+    const int grid = static_cast<int>(std::min<int64_t>(std::max<int64_t>((units + g_bwd_ord_chunks - 1) / g_bwd_ord_chunks, std::min<int64_t>(units, 1024)), kMaxBlocks));
     hipLaunchKernelGGL(lsq_bwd_tensor_ordered_kernel, dim3(grid), dim3(kBwdOrdThreads), 0, static_cast<hipStream_t>(stream), x, grad_out,
                        grad_x, n, scale, zero_point, zp_type, mode, grad_factor, static_cast<float>(quant_min),
                        static_cast<float>(quant_max), grad_scale, grad_zero_point, static_cast<float*>(scratch),
@@ -913,6 +939,7 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
     else if (k == "bwd_sum_order") { OSQ_REQUIRE(value == 0 || value == 8 || value == 16, "bwd_sum_order must be 0, 8 or 16"); osq::g_bwd_sum_order = value; }
+    else if (k == "bwd_order_chunks") { OSQ_REQUIRE(value >= 1 && value <= 64, "bwd_order_chunks must be 1..64"); osq::g_bwd_ord_chunks = value; }
     else if (k == "fq_headsplit") { osq::g_fq_headsplit = value != 0; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }

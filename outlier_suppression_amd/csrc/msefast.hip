@@ -645,9 +645,9 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
             // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
             auto load = [=](int64_t e) { return x[e]; };
-            auto eval = [=](float xf) { return fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax); };
-            if (g.P == 4) cascade_chunks_pipelined<double, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            else cascade_chunks_pipelined<double, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            auto eval = [=](float xf, int64_t, double (&t)[1]) { t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax); };
+            if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
         } else {
             cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
@@ -670,9 +670,9 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         float* lds = reinterpret_cast<float*>(lds_raw);
         if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
             auto load = [=](int64_t e) { return x[e]; };
-            auto eval = [=](float xf) { return sq_err(xf, s, z, qmin, qmax); };
-            if (g.P == 4) cascade_chunks_pipelined<float, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            else cascade_chunks_pipelined<float, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
+            if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
         } else {
             cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
@@ -719,7 +719,7 @@ static_assert(sizeof(OrderedSite) == 64, "OrderedSite is a 64-byte table entry")
 constexpr int kOrderedMaxSites = 128;
 constexpr size_t kOrderedCounterBytes = (1 + kTicketShards) * kTicketStride * sizeof(unsigned int);
 
-__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int W) {
+__global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
     int lo = 0, hi = n_sites - 1;                                  // uniform: the site whose range holds this workgroup
     while (lo < hi) {
@@ -1570,7 +1570,7 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     return check_launch("msefast_tensor_evals_ordered");
 }
 
-static int g_ord_groups = 8;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
+static int g_ord_groups = 4;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
     return static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);

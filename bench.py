@@ -216,8 +216,17 @@ def kernel_table(dev, xs, lengths, reps=20):
                 timed(_hip.TIME_OBSERVE_TOKENS, lambda i: observe_alone(i, lengths)), 4 * valid)
         finally:
             ops.set_tuning("observe_onelaunch", 0)
-        add("lsq_plus_backward", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
+        # the default adds the two parameter gradients in autograd's order (four fp32 sums in ATen's one-thread order); the
+        # order-free tier (set_strict(False)) in float64
+        add("lsq_plus_backward (default: gradients summed in the reference's order)", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
             xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
+        prev_order = ops.reference_sum_order("bwd")
+        ops.set_tuning("bwd_sum_order", 0)
+        try:
+            add("lsq_plus_backward (order-free tier, set_strict(False))", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
+                xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
+        finally:
+            ops.set_tuning("bwd_sum_order", prev_order)
         # LayerNorm site of a quantized block: GammaResidual -> split LayerNorm -> + beta/gamma -> fake-quant, one launch
         gamma = torch.rand(SHAPE[2], device=dev) + 0.5
         shift = torch.randn(SHAPE[2], device=dev)

@@ -93,8 +93,11 @@ size_t      osq_workspace_bytes(void);
  *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "bwd_sum_order" 8 | 16 = the per-tensor LSQ / LSQ+ backward
  *   adds the parameter gradients in autograd's decomposition and ATen's one-thread CPU order, fp32, any length (osq_lsq_backward_per_tensor_ordered);
  *   "mse_sum_order" 8 | 16 = the MSEFast losses (rows and per-tensor searches of any length, osq_msefast_tensor_evals_ordered) are added in ATen's one-thread CPU
- *   order for 8- / 16-lane SIMD (oracle/aten_sum.py) -- these two are the STRICT switch of the package: results equal to the reference run on a one-thread host bit for
- *   bit, at the price of one launch per loss evaluation; "mse_sum_order" 64 = per-tensor sums as double-doubles, i.e. order-independent (test mode; one launch per evaluation); 0 = off;
+ *   order for 8- / 16-lane SIMD (oracle/aten_sum.py) -- these two are the summation-order switch of the package: results equal to the reference run on a one-thread host bit for
+ *   bit.  The C library starts with both at 0; the Python host sets them to 8 when it loads the library (outlier_suppression_amd.set_strict, its DEFAULT tier; OSQ_STRICT=0
+ *   keeps 0).  With the order set, per-tensor searches go through osq_msefast_tensor_evals_ordered (one launch per evaluation) or osq_msefast_ordered_multi_* (rounds: one
+ *   launch per evaluation of up to 128 searches), the backward through osq_lsq_backward_per_tensor_ordered; "mse_round_groups" n / "bwd_order_chunks" n: chunk groups / level-1
+ *   chunks a workgroup of those launches takes (4 / 4); "mse_sum_order" 64 = per-tensor sums as double-doubles, i.e. order-independent (test mode; one launch per evaluation); 0 = off;
  *   "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
  *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
  *   "fused_spin_limit" / "mse_spin_limit" n: bound of the cross-workgroup waits of the two persistent launch families

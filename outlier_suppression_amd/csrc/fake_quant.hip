@@ -881,7 +881,8 @@ extern "C" int osq_lsq_backward_per_tensor_ordered(const float* x, const float* 
     // (at least 1024 workgroups while there are that many chunks: below ~12 M elements one chunk per workgroup measured best)
     const int64_t units = geom.chunks + 1;
     const int grid = static_cast<int>(std::min<int64_t>(std::max<int64_t>((units + g_bwd_ord_chunks - 1) / g_bwd_ord_chunks, std::min<int64_t>(units, 1024)), kMaxBlocks));
-    hipLaunchKernelGGL(lsq_bwd_tensor_ordered_kernel, dim3(grid), dim3(kBwdOrdThreads), 0, static_cast<hipStream_t>(stream), x, grad_out,
+    const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
+    hipExtLaunchKernelGGL(lsq_bwd_tensor_ordered_kernel, dim3(grid), dim3(kBwdOrdThreads), 0, static_cast<hipStream_t>(stream), th.start, th.stop, 0, x, grad_out,
                        grad_x, n, scale, zero_point, zp_type, mode, grad_factor, static_cast<float>(quant_min),
                        static_cast<float>(quant_max), grad_scale, grad_zero_point, static_cast<float*>(scratch),
                        ws.counter(kFamLsqBackward), g_bwd_sum_order);

@@ -154,7 +154,8 @@ def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max
     ds = torch.empty(1, dtype=torch.float32, device=x.device) if need_scale else None
     dz = torch.empty(1, dtype=torch.float32, device=x.device) if need_zp else None
     ws = _hip.workspace(x.device)
-    if reference_sum_order("bwd") and x.numel() > 0:     # strict: autograd's four fp32 reductions in torch's one-thread order
+    order = reference_sum_order("bwd")
+    if order and x.numel() > 0 and ordered_sum_fits(x.numel(), order):     # default tier: autograd's four fp32 reductions in torch's one-thread order
         scratch, nbytes = _ordered_scratch(x.device, x.numel(), 4)
         _hip.check(lib.osq_lsq_backward_per_tensor_ordered(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
                                                            _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
@@ -162,10 +163,16 @@ def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max
                                                            _hip.ptr(scratch), nbytes, _hip.ptr(ws), _hip.stream_ptr(x.device)),
                    "lsq_backward_per_tensor_ordered")
         return dx, ds, dz
-    _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
-                                               _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
-                                               int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
-                                               _hip.stream_ptr(x.device)), "lsq_backward_per_tensor")
+    if order:                                            # beyond the ordered kernels' capacity: the order-free sums for this call
+        set_tuning("bwd_sum_order", 0)
+    try:
+        _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
+                                                   _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                                                   int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
+                                                   _hip.stream_ptr(x.device)), "lsq_backward_per_tensor")
+    finally:
+        if order:
+            set_tuning("bwd_sum_order", order)
     return dx, ds, dz
 
 
@@ -360,6 +367,15 @@ def reference_sum_order(kind):
     """SIMD width (8 / 16) of the reference host whose summation order the "mse" / "bwd" sums follow, or 0."""
     v = _tuning.get("mse_sum_order" if kind == "mse" else "bwd_sum_order", 0)
     return v if v in (8, 16) else 0
+
+
+def ordered_sum_fits(n, lanes):
+    """Whether the reference-order kernels take a vector of n elements summed on `lanes` SIMD lanes (csrc/aten_order.h:
+    cascade step 2^P with P <= 5, i.e. up to 2^23 rows of 4 * lanes columns: 268 M fp32 / 134 M float64 elements at 8 lanes).
+    Larger tensors keep the order-free sums."""
+    size = (int(n) // lanes) // 4
+    p = max(4, ((size - 1).bit_length() if size > 1 else 0) // 4)
+    return p <= 5
 
 
 def _ordered_scratch(device, n, n_sums):
@@ -639,6 +655,12 @@ def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max
     return r
 
 
+def msefast_ordered_fits(r):
+    """The float64 form of a search's sum is the finer one (half the lanes): it decides."""
+    order = reference_sum_order("mse")
+    return bool(order) and ordered_sum_fits(r.elems, order // 2)
+
+
 def msefast_tensor_run(r, chunk=None, two_d=True):
     """The loss evaluations of one search: one persistent launch when the tensor fits the grid's registers, otherwise one
     launch per evaluation, enqueued in chunks (the converged flag is read back once per chunk; the reference syncs on
@@ -647,8 +669,15 @@ def msefast_tensor_run(r, chunk=None, two_d=True):
     dev = r.x.device
     st = _hip.stream_ptr(dev)
     ws = _hip.workspace(dev)
-    if reference_sum_order("mse"):
+    order = reference_sum_order("mse")
+    if order and msefast_ordered_fits(r):
         return _msefast_tensor_run_ordered(r, chunk, two_d)
+    if order:                                            # beyond the ordered kernels' capacity: the order-free sums for this search
+        set_tuning("mse_sum_order", 0)
+        try:
+            return msefast_tensor_run(r, chunk, two_d)
+        finally:
+            set_tuning("mse_sum_order", order)
     rc = lib.osq_msefast_tensor_search(_hip.ptr(r.state), _hip.ptr(r.x), r.x.numel(), None if r.view is None else ctypes.byref(r.view),
                                        _hip.ptr(r.lengths), _hip.ptr(ws), st)
     if rc not in (0, _hip.ERR_UNSUPPORTED):

@@ -45,9 +45,14 @@ class DeferredSites:
             return 0
         if ops.reference_sum_order("mse"):
             # strict sums: one launch per ROUND of loss evaluations of all the forward's searches (128 per table)
-            for i in range(0, len(pending), ops.ORDERED_GROUP_SITES):
-                ops.msefast_tensor_run_ordered_group([it[1] for it in pending[i:i + ops.ORDERED_GROUP_SITES]])
+            fit = [it for it in pending if ops.msefast_ordered_fits(it[1])]
+            for i in range(0, len(fit), ops.ORDERED_GROUP_SITES):
+                ops.msefast_tensor_run_ordered_group([it[1] for it in fit[i:i + ops.ORDERED_GROUP_SITES]])
                 self.launches += 1
+            for it in pending:
+                if not ops.msefast_ordered_fits(it[1]):              # beyond the ordered kernels' capacity (> 134 M elements)
+                    ops.msefast_tensor_run(it[1], None, it[2])
+                    self.launches += 1
             return self._commit_mse(pending)
         # greedy groups: at most max_sites searches and max_slots float4 slots per lane in a launch (16 and 32); what cannot
         # be resident runs alone

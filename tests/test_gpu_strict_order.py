@@ -225,3 +225,41 @@ def test_ordered_rounds_equal_search_by_search(dev, strict):
     for a, b in zip(one_by_one, rounds):
         assert np.array_equal(N(a.min_val), N(b.min_val)) and np.array_equal(N(a.max_val), N(b.max_val))
         assert np.array_equal(N(a.last_nfev), N(b.last_nfev))
+
+
+def test_tensors_beyond_the_ordered_capacity_keep_order_free_sums(dev):
+    """The reference-order kernels stop at a cascade step of 32 (2^23 rows: 268 M fp32 / 134 M float64 elements, aten_order.h);
+    a larger tensor takes the order-free sums for that call -- same numbers as set_strict(False) -- and the default tier is
+    back afterwards."""
+    import outlier_suppression_amd as osq
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import MSEFastObserver
+    assert ops.reference_sum_order("mse") == 8 and ops.reference_sum_order("bwd") == 8
+    n = (1 << 28) + 64
+    assert ops.ordered_sum_fits(1 << 28, 8) and not ops.ordered_sum_fits(n, 8)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, device=dev, generator=g)
+    gy = torch.randn(n, device=dev, generator=g)
+    s = torch.tensor([0.05], device=dev)
+    z = torch.tensor([31.0], device=dev)
+    got = ops.lsq_backward_per_tensor(x, gy, s, z, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+    assert ops.reference_sum_order("bwd") == 8
+    osq.set_strict(False)
+    try:
+        want = ops.lsq_backward_per_tensor(x, gy, s, z, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+    finally:
+        osq.set_strict(True)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    del gy, got, want
+    m = (1 << 27) + 32                                   # float64 calls: half the lanes
+    xs = x[:m]
+    a = MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
+    a(xs); a(xs)
+    assert ops.reference_sum_order("mse") == 8
+    osq.set_strict(False)
+    try:
+        b = MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
+        b(xs); b(xs)
+    finally:
+        osq.set_strict(True)
+    assert torch.equal(a.min_val, b.min_val) and torch.equal(a.max_val, b.max_val) and torch.equal(a.last_nfev, b.last_nfev)

@@ -221,6 +221,10 @@ class ObserverState:
 
 
 def _prepare(x, lengths, seq_pos):
+    """Masked: remove_padding's [valid tokens, features] copy.  No mask: the reference works on ``x_orig.clone()``
+    (observer.py:134 and the like), which keeps the strides of a dense permuted view, and torch's CPU reductions add such a
+    tensor in MEMORY order -- min / max do not care, the MSE loss of a per-tensor search does in its last bits: hand this
+    function the array in the memory order of the tensor the reference would see (C order for a contiguous one)."""
     x = np.asarray(x, dtype=F32)
     if lengths is not None:
         return remove_padding(x, lengths, seq_pos)

@@ -263,3 +263,73 @@ def test_tensors_beyond_the_ordered_capacity_keep_order_free_sums(dev):
     finally:
         osq.set_strict(True)
     assert torch.equal(a.min_val, b.min_val) and torch.equal(a.max_val, b.max_val) and torch.equal(a.last_nfev, b.last_nfev)
+
+
+def test_small_sites_in_every_layout_equal_oracle_lone_and_in_rounds(dev):
+    """Small sites (a few hundred elements: below one level-1 chunk; lengths that may be zero, or no mask at all; one-sided
+    data) in the layouts the attention blocks hand over -- [B,h,T,d] and [B,h,d,T] views of [B,T,h,d] memory, dense tensors,
+    slices that start 4 bytes off a 16-byte boundary -- searched alone and as the rounds of a deferred forward of several
+    sites: both equal the oracle with the loss summed in the reference's order, call after call."""
+    from outlier_suppression_amd.quantization import observer as OBS
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    from oracle import observer_oracle as OB
+    from conftest import aten_order_mean
+    rng = np.random.default_rng(77)
+    old = OB.MEAN_LIKE_TORCH
+    OB.MEAN_LIKE_TORCH = aten_order_mean
+    try:
+        for case in range(60):
+            sites = []
+            for k in range(int(rng.integers(1, 4))):
+                B, h, d, T = int(rng.integers(1, 9)), int(rng.integers(1, 4)), int(rng.choice([4, 8, 24])), int(rng.integers(2, 40))
+                kind = str(rng.choice(["bhtd", "bhdt"]))
+                shape, seq_pos = ((B, h, T, d), 2) if kind == "bhtd" else ((B, h, d, T), 3)
+                sym = bool(rng.integers(0, 2))
+                lone = OBS.AvgMSEFastObserver(bit=6, symmetric=sym, ch_axis=-1).to(dev)
+                inround = OBS.AvgMSEFastObserver(bit=6, symmetric=sym, ch_axis=-1).to(dev)
+                object.__setattr__(inround, "_defer_ok", True)
+                sites.append((kind, shape, seq_pos, sym, rng.random() < 0.5, rng.random() < 0.6, str(rng.choice(["dense", "permuted", "offset"])),
+                              lone, inround, OB.ObserverState(bit=6, symmetric=sym, ch_axis=-1)))
+            for r in range(2):
+                fed = []
+                with deferred_observation() as rec:
+                    for kind, shape, seq_pos, sym, positive, masked, how, lone, inround, st in sites:
+                        B, T = shape[0], shape[seq_pos]
+                        x_np = rng.standard_normal(shape).astype(np.float32)
+                        if positive:
+                            x_np = np.abs(x_np)
+                        L_np = None
+                        if masked:
+                            L_np = rng.integers(0, T + 1, (B,)).astype(np.int64)
+                            L_np[int(rng.integers(0, B))] = T
+                        if how == "permuted":
+                            perm = (0, 2, 1, 3) if kind == "bhtd" else (0, 3, 1, 2)
+                            back = (0, 2, 1, 3) if kind == "bhtd" else (0, 2, 3, 1)
+                            x = torch.from_numpy(x_np).permute(*perm).contiguous().to(dev).permute(*back)      # [B,T,h,d] memory
+                        elif how == "offset":
+                            buf = torch.zeros(x_np.size + 1, device=dev)
+                            buf[1:] = torch.from_numpy(x_np).reshape(-1).to(dev)
+                            x = buf[1:].view(shape)
+                        else:
+                            x = torch.from_numpy(x_np).to(dev)
+                        L = None if L_np is None else torch.from_numpy(L_np).to(dev)
+                        lone(x, L, seq_pos)
+                        inround(x, L, seq_pos)
+                        if L_np is None and how == "permuted":
+                            # no mask: the reference searches on x_orig.clone() -- strides preserved -- and torch adds a dense
+                            # permuted tensor in MEMORY order (checked against torch on this host: 0 of 200 sums differ from the
+                            # memory-order sum, 97 from the logical-order one); the oracle gets the memory image of the view
+                            x_np = np.ascontiguousarray(np.transpose(x_np, (0, 2, 1, 3) if kind == "bhtd" else (0, 3, 1, 2)))
+                        fed.append((x_np, L_np))
+                    assert len(rec.mse) == len(sites)
+                    rec.flush()
+                for (kind, shape, seq_pos, sym, positive, masked, how, lone, inround, st), (x_np, L_np) in zip(sites, fed):
+                    OB.observe_msefast(st, x_np, L_np, seq_pos, average=True)
+                    want = (np.asarray(st.min_val, dtype=np.float64), np.asarray(st.max_val, dtype=np.float64))
+                    tag = (case, r, kind, shape, sym, positive, how, None if L_np is None else L_np.tolist())
+                    assert np.array_equal(N(lone.min_val).astype(np.float64), want[0]) and np.array_equal(N(lone.max_val).astype(np.float64), want[1]), \
+                        str(("lone", tag, N(lone.min_val), N(lone.max_val), want))
+                    assert np.array_equal(N(inround.min_val).astype(np.float64), want[0]) and np.array_equal(N(inround.max_val).astype(np.float64), want[1]), \
+                        str(("rounds", tag, N(inround.min_val), N(inround.max_val), want))
+    finally:
+        OB.MEAN_LIKE_TORCH = old

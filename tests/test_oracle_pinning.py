@@ -177,3 +177,22 @@ def test_exact_sum():
             if kind == 2:
                 a[rng.integers(0, n, size=n // 2)] = 0.0
             assert exact_sum(a) == math.fsum(a.tolist()), (n, kind)
+
+
+def test_torch_adds_a_dense_permuted_view_in_memory_order():
+    """What an UNMASKED observer call of the reference sums over: `x_orig.clone()` keeps the strides of a dense permuted
+    view (the key layer [B,h,d,T] of [B,T,h,d] memory), and torch's CPU reduction adds such a tensor in memory order --
+    the order the kernels read it in, and the order the oracle must be handed (observer_oracle._prepare)."""
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(0)
+    differs_from_logical = 0
+    for trial in range(100):
+        B, T, h, d = 8, 3 + trial % 5, 1 + trial % 3, 8
+        mem = torch.randn(B, T, h, d, generator=g).abs()
+        x = mem.permute(0, 2, 3, 1).clone()                   # strides preserved
+        assert x.stride() == mem.permute(0, 2, 3, 1).stride()
+        sq = x.abs().pow(2)
+        got = sq.mean().item()
+        assert got == sq.permute(0, 3, 1, 2).contiguous().view(-1).mean().item()
+        differs_from_logical += int(got != sq.contiguous().view(-1).mean().item())
+    assert differs_from_logical > 10

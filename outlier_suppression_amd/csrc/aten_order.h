@@ -308,7 +308,14 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
     if (owner) {
         const int64_t base = my_s * sstride;
         T acc2 = T(0);
-        for (int64_t m = units2 << g.P; m < g.chunks; ++m) acc2 = acc2 + rd.get<T>(base + (m << nc_shift) + my_c);
+        for (int64_t m0 = units2 << g.P; m0 < g.chunks; m0 += 16) {     // up to S - 1 chunk sums: loaded side by side, added in order
+            T v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (m0 + j < g.chunks) ? rd.get<T>(base + ((m0 + j) << nc_shift) + my_c) : T(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (m0 + j < g.chunks) acc2 = acc2 + v[j];
+        }
         const T acc1 = rd.get<T>(base + (g.chunks << nc_shift) + my_c);
         T acc0 = g.tail_rows ? rd.get<T>(base + ((g.chunks + 1) << nc_shift) + my_c) : T(0);
         acc0 = acc0 + acc1;
@@ -317,23 +324,30 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
         col[(my_s << nc_shift) + my_c] = acc0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int64_t v = g.size * 4; v < g.n_vec; ++v)      // left-over vectors join accumulator 0
-            for (int l = 0; l < g.W; ++l) {
-                T t[NS];
-                term(v * g.W + l, t);
+    // the elements behind the rows: n / W % 4 left-over vectors and n % W trailing scalars, fewer than NC together.  Their
+    // terms are produced by as many threads side by side (one load latency instead of up to NC - 1 in a row) into the
+    // tile, which stage 2 no longer needs; thread 0 adds them in the kernel's order.
+    const int64_t rest0 = g.size * 4 * g.W;
+    const int nrest = static_cast<int>(g.n - rest0);
+    if (tid < nrest) {
+        T t[NS];
+        term(rest0 + tid, t);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) col[(s << nc_shift) + l] = col[(s << nc_shift) + l] + t[s];
-            }
+        for (int s = 0; s < NS; ++s) tile[(s << nc_shift) + tid] = t[s];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nvec_rest = static_cast<int>(g.n_vec - g.size * 4);
+        for (int v = 0; v < nvec_rest; ++v)                 // left-over vectors join accumulator 0
+            for (int l = 0; l < g.W; ++l)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) col[(s << nc_shift) + l] = col[(s << nc_shift) + l] + tile[(s << nc_shift) + v * g.W + l];
         T fin[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) fin[s] = T(0);
-        for (int64_t k = g.n_vec * g.W; k < g.n; ++k) {     // trailing scalars
-            T t[NS];
-            term(k, t);
+        for (int k = nvec_rest * g.W; k < nrest; ++k)       // trailing scalars
 #pragma unroll
-            for (int s = 0; s < NS; ++s) fin[s] = fin[s] + t[s];
-        }
+            for (int s = 0; s < NS; ++s) fin[s] = fin[s] + tile[(s << nc_shift) + k];
         for (int l = 0; l < g.W; ++l)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {

@@ -48,6 +48,11 @@ def make_inputs(dev, n_buffers, seed):
     return xs, lengths
 
 
+def _ops_order():
+    from outlier_suppression_amd import ops
+    return ops.reference_sum_order("mse")
+
+
 def make_quantizer(dev):
     from types import SimpleNamespace as NS
     from outlier_suppression_amd.quantization import Quantizer
@@ -1227,6 +1232,8 @@ def main():
                    "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
                    "hbm_bytes_per_step": 8 * n_elem,
                    "launch": launch_mode,
+                   "sum_tier": ("reference order (package default): MSEFast losses and LSQ+ parameter gradients in ATen's one-thread order; the step "
+                                "itself holds no such sum" if _ops_order() else "order-free (OSQ_STRICT=0)"),
                    "eager_ms_per_step": round(eager_dt / args.steps * 1e3, 5),
                    "host_enqueue_ms_per_step": round(eager_host / args.steps * 1e3, 5),
                    "three_launch_path_ms_per_step": round(three_ms, 5),

@@ -184,7 +184,15 @@ def test_lsqplus_site_size_gradients_equal_reference_in_its_summation_order(gold
         (name, N(s.grad), g[f"{name}_dscale"], N(z.grad), g[f"{name}_dzp"])
 
 
-def test_ordered_rounds_equal_search_by_search(dev, strict):
+@pytest.fixture(params=[8, 16])
+def simd_width(request):
+    import outlier_suppression_amd as osq
+    osq.set_strict(True, simd_width=request.param)
+    yield request.param
+    osq.set_strict(True)                                            # the default width
+
+
+def test_ordered_rounds_equal_search_by_search(dev, simd_width):
     """osq_msefast_ordered_multi_*: the strict evaluations of several searches as rounds (one launch = one evaluation of
     every unfinished search) against the same searches run one by one (one launch per evaluation): converged ranges,
     evaluation counts and the running statistics after two batches (fp32 call, then the float64 one) equal bit for bit."""

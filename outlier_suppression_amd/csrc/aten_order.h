@@ -283,6 +283,16 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
     const bool owner = tid < (NS << nc_shift);              // thread (s, c): level 3 and the open levels of column c of sum s
     const int my_s = tid >> nc_shift, my_c = tid & (g.NC - 1);
     T acc3 = T(0);
+    // the open levels' loads (up to 16 chunk sums behind the last full unit, the open level-1 and level-0 sums) leave with
+    // the first level-2 loads instead of after them: one round trip to memory less on the serial tail of every evaluation
+    const int64_t open_base = my_s * sstride, open_m0 = units2 << g.P;
+    T open_v[16], open_a1 = T(0), open_a0 = T(0);
+    if (owner) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) open_v[j] = (open_m0 + j < g.chunks) ? rd.get<T>(open_base + ((open_m0 + j) << nc_shift) + my_c) : T(0);
+        open_a1 = rd.get<T>(open_base + (g.chunks << nc_shift) + my_c);
+        open_a0 = g.tail_rows ? rd.get<T>(open_base + ((g.chunks + 1) << nc_shift) + my_c) : T(0);
+    }
     for (int64_t q0 = 0; q0 < units2; q0 += QT) {
         const int nq = static_cast<int>(units2 - q0 < QT ? units2 - q0 : QT);
         const int per_sum = nq << nc_shift;
@@ -306,9 +316,12 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
         __syncthreads();
     }
     if (owner) {
-        const int64_t base = my_s * sstride;
+        const int64_t base = open_base;
         T acc2 = T(0);
-        for (int64_t m0 = units2 << g.P; m0 < g.chunks; m0 += 16) {     // up to S - 1 chunk sums: loaded side by side, added in order
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (open_m0 + j < g.chunks) acc2 = acc2 + open_v[j];
+        for (int64_t m0 = open_m0 + 16; m0 < g.chunks; m0 += 16) {      // S = 32: up to 15 more chunk sums, loaded side by side, added in order
             T v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = (m0 + j < g.chunks) ? rd.get<T>(base + ((m0 + j) << nc_shift) + my_c) : T(0);
@@ -316,8 +329,8 @@ __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __
             for (int j = 0; j < 16; ++j)
                 if (m0 + j < g.chunks) acc2 = acc2 + v[j];
         }
-        const T acc1 = rd.get<T>(base + (g.chunks << nc_shift) + my_c);
-        T acc0 = g.tail_rows ? rd.get<T>(base + ((g.chunks + 1) << nc_shift) + my_c) : T(0);
+        const T acc1 = open_a1;
+        T acc0 = open_a0;
         acc0 = acc0 + acc1;
         acc0 = acc0 + acc2;
         acc0 = acc0 + acc3;

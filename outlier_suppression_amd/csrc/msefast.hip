@@ -648,7 +648,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
             auto eval = [=](float xf, int64_t, double (&t)[1]) { t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax); };
             if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
+            if (bid == nblk - 1) cascade_units<double, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
         } else {
             cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
         }
@@ -673,7 +673,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
             auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
             if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk, g.chunks);
+            if (bid == nblk - 1) cascade_units<float, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);
         } else {
             cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
         }

@@ -438,7 +438,8 @@ int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat, int64_t n
  * ROUNDS: one launch = one loss evaluation of every unfinished search, each in the reference's order as above.  A launch
  * per evaluation of one site costs ~15 us whatever its size; a round pays that once for up to 128 sites.
  *   table: osq_msefast_ordered_multi_bytes(n_sites) bytes of device memory, ZERO before _prepare (site table + the ticket
- *          counters of every site); _prepare fills the site table (synchronous on `stream`) and returns the grid of a round;
+ *          counters of every site + the workgroup -> site map of a round); _prepare fills table and map (synchronous on
+ *          `stream`), copies the device-side element counts into the table (after the gathers enqueued before it) and returns the grid of a round;
  *   per site: state (between osq_msefast_tensor_begin and _commit), the flat tensor (osq_gather_valid_tokens for a masked
  *          site) with its host-side element bound n[i] and nullable device count n_device[i], and scratch of
  *          osq_ordered_sum_scratch_bytes(n[i], 1) bytes;

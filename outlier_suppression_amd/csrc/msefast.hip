@@ -626,16 +626,19 @@ constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC
 __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, const int64_t n, TensorSearch* __restrict__ ts,
                                                    void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W,
                                                    const unsigned int bid, const unsigned int nblk, double* lds_raw) {
+    // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
     const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
+    const double x_min = ts->S.x_min, x_max = ts->S.x_max;
+    if (ts->S.done) return;                                       // uniform: a converged search costs its workgroups one look
     if (f64) {
         const CascadeGeom g = cascade_geom(n, W / 2);
         // the float64 chain is VALU-bound on its division: the exact reciprocal sequence of the resident search (same bits,
         // sq_err_f64_rcp) whenever its two conditions hold -- a uniform branch, the division out of line
         const double rcp = 1.0 / sd;
-        const bool fast = rcp_division_exact(sd, ts->S.x_min, ts->S.x_max);
+        const bool fast = rcp_division_exact(sd, x_min, x_max);
         auto term = [=](int64_t e, double (&t)[1]) {
             if (fast) t[0] = sq_err_f64_rcp(x[e], sd, rcp, z, qmin, qmax);
             else t[0] = sq_err_f64_outofline(x[e], sd, z, qmin, qmax);
@@ -695,7 +698,6 @@ __global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(con
                                                                             const int64_t* __restrict__ n_dev,
                                                                             TensorSearch* __restrict__ ts, void* __restrict__ scratch,
                                                                             unsigned int* __restrict__ counters, int W) {
-    if (ts->S.done) return;
     __shared__ double lds_raw[kOrdLdsBytes / 8];
     ordered_evaluation(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
 }
@@ -719,16 +721,23 @@ static_assert(sizeof(OrderedSite) == 64, "OrderedSite is a 64-byte table entry")
 constexpr int kOrderedMaxSites = 128;
 constexpr size_t kOrderedCounterBytes = (1 + kTicketShards) * kTicketStride * sizeof(unsigned int);
 
-__global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int W) {
+// A workgroup's first loads are a dependent chain -- which site, its table entry, the search's state, only then the data --
+// and a round has thousands of short-lived workgroups: the chain is kept at three round trips (block -> site map, entry,
+// state; the element count of a masked site is copied into its entry once, by ordered_sites_counts_kernel).
+__global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites,
+                                                                                      const unsigned char* __restrict__ block_site, int n_sites, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
-    int lo = 0, hi = n_sites - 1;                                  // uniform: the site whose range holds this workgroup
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (sites[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid - 1;
+    const OrderedSite s = sites[block_site[blockIdx.x]];
+    ordered_evaluation(s.x, s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
+}
+
+// after the gathers of a group: n_host <- the device-side count of valid elements (same stream, once per group)
+__global__ void ordered_sites_counts_kernel(OrderedSite* __restrict__ sites, int n_sites) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sites && sites[i].n_dev) {
+        sites[i].n_host = sites[i].n_dev[0];
+        sites[i].n_dev = nullptr;
     }
-    const OrderedSite s = sites[lo];
-    if (s.ts->S.done) return;
-    ordered_evaluation(s.x, s.n_dev ? s.n_dev[0] : s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
 }
 
 __global__ void msefast_done_multi_kernel(const OrderedSite* __restrict__ sites, int n_sites, int* __restrict__ done_out) {
@@ -1573,7 +1582,8 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
 static int g_ord_groups = 4;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
-    return static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
+    // site table, ticket counters, block -> site map (one byte per workgroup of a round, at most kMaxBlocks per site)
+    return static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes + static_cast<size_t>(kMaxBlocks));
 }
 
 extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
@@ -1609,11 +1619,18 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
     }
     OSQ_REQUIRE(total < (1ll << 31), "msefast_ordered_multi_prepare: too many workgroups");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the counters behind the table stay as the caller zeroed them; the table is in place when this returns
+    std::vector<unsigned char> map(static_cast<size_t>(total));
+    for (int i = 0; i < n_sites; ++i)
+        std::fill(map.begin() + host[static_cast<size_t>(i)].block_begin, map.begin() + host[static_cast<size_t>(i)].block_begin + host[static_cast<size_t>(i)].blocks,
+                  static_cast<unsigned char>(i));
+    char* const map_dev = counters0 + static_cast<size_t>(n_sites) * kOrderedCounterBytes;
+    // the counters between the table and the map stay as the caller zeroed them; table and map are in place when this returns
     OSQ_REQUIRE(hipMemcpyAsync(table, host.data(), host.size() * sizeof(OrderedSite), hipMemcpyHostToDevice, st) == hipSuccess &&
+                hipMemcpyAsync(map_dev, map.data(), map.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
                 hipStreamSynchronize(st) == hipSuccess, "msefast_ordered_multi_prepare: copying the table failed");
+    hipLaunchKernelGGL(ordered_sites_counts_kernel, dim3(1), dim3(kOrderedMaxSites), 0, st, static_cast<OrderedSite*>(table), n_sites);
     *total_blocks_out = static_cast<int>(total);
-    return OSQ_OK;
+    return check_launch("msefast_ordered_multi_prepare");
 }
 
 extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, int total_blocks, int n_evals, int32_t* done_out,
@@ -1623,8 +1640,9 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
                 "msefast_ordered_multi_evals: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const OrderedSite* sites = static_cast<const OrderedSite*>(table);
+    const unsigned char* block_site = static_cast<const unsigned char*>(table) + static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
     for (int e = 0; e < n_evals; ++e)
-        hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, n_sites,
+        hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites,
                            g_mse_sum_order);
     if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
     return check_launch("msefast_ordered_multi_evals");

@@ -32,7 +32,7 @@ def set_strict(on=True, simd_width=8):
     keeps.  What it buys: a lone per-tensor search runs as one persistent launch (5.7-8.5 us per
     loss evaluation instead of 16-28), the LSQ+ backward runs 1.5x faster.  The searches of an observer PASS (deferred,
     quantization/deferred.py) are faster strict: one launch per round of evaluations of all sites (BASELINE configs[3]:
-    1.56 s against 2.27 s).  From the environment: OSQ_STRICT=0 (and OSQ_STRICT_SIMD=16 for a 16-lane reference host)."""
+    1.09 s against 2.28 s).  From the environment: OSQ_STRICT=0 (and OSQ_STRICT_SIMD=16 for a 16-lane reference host)."""
     from . import ops
     if simd_width not in (8, 16):
         raise ValueError("simd_width must be 8 or 16")

@@ -268,3 +268,13 @@ def test_strict_and_fast_switches_from_the_environment():
     assert out.stdout.split() == ["0", "0", "True", "True"], out.stdout + out.stderr
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, OSQ_STRICT_SIMD="16"), capture_output=True, text=True, timeout=300)
     assert out.stdout.split() == ["16", "16", "False", "True"], out.stdout + out.stderr
+
+
+def test_ordered_sum_capacity_rule():
+    """ops.ordered_sum_fits mirrors the kernels' bound (csrc/aten_order.h: cascade step 2^P, P = max(4, ceil_log2(rows) / 4) <= 5,
+    rows = n / lanes / 4): up to 2^23 rows -- 268 M fp32 elements on 8 lanes, 134 M float64 elements on 4."""
+    from outlier_suppression_amd import ops
+    assert ops.ordered_sum_fits(5, 8) and ops.ordered_sum_fits(25165824, 8) and ops.ordered_sum_fits(1 << 28, 8)
+    assert not ops.ordered_sum_fits((1 << 28) + 32, 8)
+    assert ops.ordered_sum_fits(1 << 27, 4) and not ops.ordered_sum_fits((1 << 27) + 16, 4)
+    assert ops.ordered_sum_fits(1 << 29, 16) and not ops.ordered_sum_fits((1 << 29) + 64, 16)

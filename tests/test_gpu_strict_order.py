@@ -341,3 +341,25 @@ def test_small_sites_in_every_layout_equal_oracle_lone_and_in_rounds(dev):
                         str(("rounds", tag, N(inround.min_val), N(inround.max_val), want))
     finally:
         OB.MEAN_LIKE_TORCH = old
+
+
+def test_backward_on_a_dense_permuted_input_follows_memory_order(dev):
+    """The default (reference-order) LSQ+ backward on the key layer's layout -- [B,h,d,T] view of [B,T,h,d] memory, grad_out
+    handed over contiguous in the LOGICAL layout as autograd may do -- equals the oracle fed the memory image: what torch's
+    own autograd computes for such an input (tests/test_oracle_pinning.py::test_autograd_adds_a_dense_permuted_input_in_memory_order)."""
+    from outlier_suppression_amd import ops
+    from oracle import fake_quant_oracle as FQ
+    rng = np.random.default_rng(19)
+    for B, T, h, d in ((4, 33, 3, 16), (32, 128, 12, 64), (2, 7, 1, 8)):
+        mem = rng.standard_normal((B, T, h, d)).astype(np.float32)
+        gmem = rng.standard_normal((B, T, h, d)).astype(np.float32)
+        x = torch.from_numpy(mem).to(dev).permute(0, 2, 3, 1)
+        gy_logical = torch.from_numpy(gmem).to(dev).permute(0, 2, 3, 1).contiguous()
+        scale, zp, gf = np.float32(0.07), np.float32(29.0), FQ.lsqplus_grad_factor(mem.size, 63)
+        s = torch.tensor([scale], device=dev)
+        z = torch.tensor([zp], device=dev)
+        dx, ds, dz = ops.lsq_backward_per_tensor(x, gy_logical, s, z, 0, 63, ops.PARAM_LSQPLUS, gf)
+        rdx, rds, rdz = FQ.lsqplus_backward_per_tensor_reference_order(mem.reshape(-1), gmem.reshape(-1), scale, zp, 0, 63, gf, vec=8)
+        assert dx.stride() == x.stride()
+        assert np.array_equal(N(dx.permute(0, 3, 1, 2).contiguous()).reshape(-1), rdx.reshape(-1)), (B, T, h, d)
+        assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (B, T, h, d, ds.item(), rds, dz.item(), rdz)

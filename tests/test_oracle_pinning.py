@@ -196,3 +196,35 @@ def test_torch_adds_a_dense_permuted_view_in_memory_order():
         assert got == sq.permute(0, 3, 1, 2).contiguous().view(-1).mean().item()
         differs_from_logical += int(got != sq.contiguous().view(-1).mean().item())
     assert differs_from_logical > 10
+
+
+def test_autograd_adds_a_dense_permuted_input_in_memory_order():
+    """scale.grad / zero_point.grad of an LSQ+ quantizer whose input is a dense permuted view (the key layer [B,h,d,T] of
+    [B,T,h,d] memory): autograd's sum_to_size reductions run over tensors with the input's strides, in MEMORY order -- the
+    oracle's reference-order backward reproduces torch bit for bit when handed the memory image, not the logical one.
+    (The kernels read the saved input in memory order and lay grad_out out like it: ops._like_layout.)"""
+    from oracle import fake_quant_oracle as FQ
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(1)
+    differs_from_logical = 0
+    for trial in range(12):
+        B, T, h, d = 4, 20 + trial, 3, 16
+        mem = torch.randn(B, T, h, d, generator=g)
+        gmem = torch.randn(B, T, h, d, generator=g)
+        x, gy = mem.permute(0, 2, 3, 1), gmem.permute(0, 2, 3, 1)
+        s = torch.tensor([0.07], requires_grad=True)
+        z = torch.tensor([29.0], requires_grad=True)
+        gf = 1e-3
+        scaled = lambda t: (t - t * gf).detach() + t * gf              # grad_scale: value kept, gradient times gf
+        zz = scaled((z.round() - z).detach() + z)
+        ss = scaled(s)
+        u = x / ss + zz
+        u = torch.clamp((u.round() - u).detach() + u, 0, 63)
+        ((u - zz) * ss).backward(gy)
+        in_memory = FQ.lsqplus_backward_per_tensor_reference_order(mem.numpy().reshape(-1), gmem.numpy().reshape(-1), np.float32(0.07),
+                                                                   np.float32(29.0), 0, 63, gf, vec=8)
+        logical = FQ.lsqplus_backward_per_tensor_reference_order(x.contiguous().numpy().reshape(-1), gy.contiguous().numpy().reshape(-1),
+                                                                 np.float32(0.07), np.float32(29.0), 0, 63, gf, vec=8)
+        assert np.float32(s.grad.item()) == in_memory[1] and np.float32(z.grad.item()) == in_memory[2], trial
+        differs_from_logical += int(np.float32(s.grad.item()) != logical[1] or np.float32(z.grad.item()) != logical[2])
+    assert differs_from_logical > 0

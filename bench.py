@@ -645,11 +645,12 @@ def calibration_extra(dev, rank, world, which):
         if os.environ.get("OSQ_BENCH_NO_STRICT") == "1":      # profiling runs of the DEFAULT flow (tools/collect_calibration_profiles.sh)
             return {"config": "configs[3] (default flow only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
         import outlier_suppression_amd as osq
+        prev_width = _ops_order()                             # 8 / 16: the tier this process runs in (0: OSQ_STRICT=0, then this run repeats it)
         osq.set_strict(False)
         try:
             free_wall, free_phases, _, _, free_model = run_once()
         finally:
-            osq.set_strict(True)
+            osq.set_strict(bool(prev_width), prev_width or 8)
         order_free = {"wall_s": round(free_wall, 3), "phases_s": {k: round(v, 3) for k, v in free_phases.items()},
                       "what": "set_strict(False): MSEFast losses as exact (order-free) sums, searches resident in one persistent launch per "
                               "group of sites; the default above adds them in ATen's one-thread order (bit-equal to the reference run on a "

@@ -32,6 +32,11 @@ extern "C" {
 
 typedef void* osq_stream;
 
+/* Bumped whenever a signature or the workspace layout changes; the Python host refuses a library whose
+ * osq_abi_version() differs from the number it was written against (a stale libosq_hip.so must be rebuilt).
+ * 5: the LSQ / LSQ+ backward takes its summation order as an argument (`lanes` / `sum_lanes`). */
+#define OSQ_ABI_VERSION 5
+
 typedef enum osq_status {
     OSQ_OK = 0,
     OSQ_ERR_INVALID_ARGUMENT = -1,
@@ -90,13 +95,13 @@ size_t      osq_workspace_bytes(void);
  *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
  *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
  *   threshold pass; "select_hint" 0 = the selectors of the one-launch observe + fake-quant step do not pre-histogram a window around the
- *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result); "bwd_sum_order" 8 | 16 = the per-tensor LSQ / LSQ+ backward
- *   adds the parameter gradients in autograd's decomposition and ATen's one-thread CPU order, fp32, any length (osq_lsq_backward_per_tensor_ordered);
+ *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result);
  *   "mse_sum_order" 8 | 16 = the MSEFast losses (rows and per-tensor searches of any length, osq_msefast_tensor_evals_ordered) are added in ATen's one-thread CPU
- *   order for 8- / 16-lane SIMD (oracle/aten_sum.py) -- these two are the summation-order switch of the package: results equal to the reference run on a one-thread host bit for
- *   bit.  The C library starts with both at 0; the Python host sets them to 8 when it loads the library (outlier_suppression_amd.set_strict, its DEFAULT tier; OSQ_STRICT=0
- *   keeps 0).  With the order set, per-tensor searches go through osq_msefast_tensor_evals_ordered (one launch per evaluation) or osq_msefast_ordered_multi_* (rounds: one
- *   launch per evaluation of up to 128 searches), the backward through osq_lsq_backward_per_tensor_ordered; "mse_round_groups" n / "bwd_order_chunks" n: chunk groups / level-1
+ *   order for 8- / 16-lane SIMD (oracle/aten_sum.py): results equal to the reference run on a one-thread host bit for bit.  The C library starts at 0; the Python host
+ *   sets 8 when it loads the library (its default tier; OSQ_STRICT=0 keeps 0).  With the order set, per-tensor searches go through osq_msefast_tensor_evals_ordered
+ *   (one launch per evaluation) or osq_msefast_ordered_multi_* (rounds: one launch per evaluation of up to 128 searches).  (The other whole-tensor sum of the path, the
+ *   parameter gradients of the LSQ / LSQ+ backward, takes its order as an ARGUMENT: osq_lsq_backward_per_tensor_ordered(lanes), osq_lsq_backward_per_channel(sum_lanes).)
+ *   "mse_round_groups" n / "bwd_order_chunks" n: chunk groups / level-1
  *   chunks a workgroup of those launches takes (4 / 4); "mse_sum_order" 64 = per-tensor sums as double-doubles, i.e. order-independent (test mode; one launch per evaluation); 0 = off;
  *   "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
  *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
@@ -179,25 +184,27 @@ int osq_lsq_backward_per_tensor(const float* x, const float* grad_out, float* gr
                                 float* grad_scale, float* grad_zero_point,
                                 void* workspace, osq_stream stream);
 
-/* The same backward with "bwd_sum_order" 8 / 16 set: grad_scale / grad_zero_point are the FOUR fp32 reductions autograd
+/* The same backward in the REFERENCE's summation order: grad_scale / grad_zero_point are the FOUR fp32 reductions autograd
  * forms on the reference's CPU (mul + div backward, add + sub backward; util_quant.py:48-55,70-71), each added in the order
- * of torch.sum on a one-thread host (csrc/aten_order.h), for any n.  scratch: osq_ordered_sum_scratch_bytes(n, 4) bytes of
+ * of torch.sum on a one-thread host with `lanes` (8 | 16) fp32 SIMD lanes (csrc/aten_order.h), for any n.  The plain entry point above
+ * accumulates in float64 and rounds once (order-free; 2e-5 from autograd's fp32 sums) and is ~1.3x faster.  scratch: osq_ordered_sum_scratch_bytes(n, 4) bytes of
  * device memory, contents irrelevant.  x, grad_out, grad_x: contiguous, no alignment requirement. */
 size_t osq_ordered_sum_scratch_bytes(int64_t n, int n_sums);
 int osq_lsq_backward_per_tensor_ordered(const float* x, const float* grad_out, float* grad_x, int64_t n,
                                         const float* scale, const void* zero_point, int zp_type,
                                         int mode, float grad_factor, int quant_min, int quant_max,
-                                        float* grad_scale, float* grad_zero_point,
+                                        float* grad_scale, float* grad_zero_point, int lanes,
                                         void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream);
 
-/* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner].  With "bwd_sum_order" set, weights
- * (outer == 1, inner <= 3072) take every row's four reductions in torch's order (bit-equal to the reference's autograd run). */
+/* Per-channel form (util_quant.py:58-67), x viewed as [outer, channels, inner].  sum_lanes 8 | 16: weights
+ * (outer == 1, inner <= 3072) take every row's four reductions in torch's one-thread order on that many SIMD lanes (bit-equal to
+ * the reference's autograd run); 0 (and every other layout): float64 sums rounded once. */
 int osq_lsq_backward_per_channel(const float* x, const float* grad_out, float* grad_x,
                                  int64_t outer, int64_t channels, int64_t inner,
                                  const float* scale, const void* zero_point, int zp_type,
                                  int mode, float grad_factor, int quant_min, int quant_max,
                                  float* grad_scale, float* grad_zero_point,
-                                 osq_stream stream);
+                                 int sum_lanes, osq_stream stream);
 
 /* fake_quant.py:152-153 / 188-191: what LSQFakeQuantize / LSQPlusFakeQuantize do to their
  * parameters on every forward while the observer is off:

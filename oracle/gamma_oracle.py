@@ -35,6 +35,17 @@ def non_scaling_layernorm(x, bias, eps=1e-5):
     return y + np.asarray(bias, dtype=F32)
 
 
+def affine_layernorm(x, weight, bias, eps):
+    """util_layernorm.py:15 (QuantizedLayerNorm keeps the model's own ``nn.LayerNorm``): ``layer_norm(x) * weight + bias``
+    with the moments in float64, the normalised value rounded to fp32 once, then the affine pair in fp32 -- the order
+    of torch's CPU kernel up to its last-bit rounding; compared at 1e-5, not bit for bit."""
+    x64 = np.asarray(x, dtype=np.float64)
+    mu = x64.mean(axis=-1, keepdims=True)
+    var = x64.var(axis=-1, keepdims=True)
+    y = ((x64 - mu) / np.sqrt(var + eps)).astype(F32)
+    return y * np.asarray(weight, dtype=F32) + np.asarray(bias, dtype=F32)
+
+
 def gamma_residual(shortcut, hidden, gamma=None):
     """util_layernorm.py:49-52: ``input * gamma + hidden`` (gamma absent before migration)."""
     s = np.asarray(shortcut, dtype=F32)

@@ -9,48 +9,63 @@ through the C ABI in ``include/osq_hip.h``.  There is no CPU path.
 __version__ = "0.1.0"
 
 
-def set_strict(on=True, simd_width=8):
-    """Sums in the REFERENCE's own order -- the DEFAULT of this package (round 4); ``set_strict(False)`` opts out.
+def set_strict(on=True, simd_width=8, backward=None, _lib=None):
+    """Which rounding of the path's two whole-tensor sums is returned: the REFERENCE's own order, or the correctly rounded sum.
 
     Two numbers of the path are sums over a whole activation: the loss of a per-tensor MSEFast search
     (`.pow(2).mean()`, quantization/observer.py:420-432) and the LSQ / LSQ+ parameter gradients (autograd's `sum_to_size`,
     quantization/util_quant.py:29-67).  The reference adds them with torch.sum on the CPU, whose order (ATen's
-    cascade_sum) depends on the host's SIMD width and -- beyond 32768 elements -- on its thread count.
+    cascade_sum) depends on the host's SIMD width and -- beyond 32768 elements -- on its thread count.  The order this
+    package can pin is torch's on a ONE-thread host with ``simd_width`` fp32 lanes per vector (8: x86 torch; float64 sums
+    use half as many), at any length (csrc/aten_order.h).  Note what that target is: the upstream reference hard-codes
+    `.cuda()` on this path (observer.py:81,95,425), so no upstream run ever had this order -- it is the order of the
+    reference's code run on a CPU with torch.set_num_threads(1), which is what the golden fixtures are
+    (tests/golden/make_golden*.py); a multi-threaded CPU run differs from it beyond 32768 elements.
 
-    By default (strict ON) both sums follow torch's order on a ONE-thread host with ``simd_width`` fp32 lanes per vector
-    (8: x86 torch, AVX2 and AVX-512 builds alike; float64 sums use half as many), at any length: min_val / max_val /
-    scale / zero_point of every MSEFast observer and scale.grad / zero_point.grad of every learnable quantizer --
-    per-tensor (LSQ / LSQ+ activations: what every shipped configuration learns; any size) and per-channel weights
-    (ch_axis = 0, rows of up to 3072 columns) -- equal that reference run bit for bit (tests/test_gpu_strict_order.py,
-    fixtures made by running the reference at BERT-base site sizes; tests/test_gpu_parity.py for the per-channel case).
-    Other per-channel layouts (an inner channel axis, longer rows) keep their float64 sums (2e-5 from autograd's fp32
-    ones).  Per-channel (row) MSEFast searches follow the reference's order in either mode.
+    ``on`` -- the MSEFast losses.  ON by default: min_val / max_val / scale / zero_point of every MSEFast observer equal
+    that reference run bit for bit, and it is also the FASTER form of an observer pass (the searches of a forward run as
+    rounds, quantization/deferred.py: BASELINE configs[3] 1.09 s against 2.28 s).  A lone search pays one launch per
+    evaluation (15-24 us against 6-9 for the resident order-free form).  Per-channel (row) searches follow the
+    reference's order in either mode.
 
-    ``set_strict(False)`` returns the correctly rounded sum instead (float64 / exact accumulation, rounded once:
-    order-free, same bits whatever the reference host would have been), which can differ from ONE particular reference
-    run in the last bits of the sum -- and, for MSEFast, in which of two tied candidates of its staircase loss the search
-    keeps.  What it buys: a lone per-tensor search runs as one persistent launch (5.7-8.5 us per
-    loss evaluation instead of 16-28), the LSQ+ backward runs 1.5x faster.  The searches of an observer PASS (deferred,
-    quantization/deferred.py) are faster strict: one launch per round of evaluations of all sites (BASELINE configs[3]:
-    1.09 s against 2.28 s).  From the environment: OSQ_STRICT=0 (and OSQ_STRICT_SIMD=16 for a 16-lane reference host)."""
+    ``backward`` -- scale.grad / zero_point.grad of the learnable quantizers (default: follows ``on`` when set_strict is
+    called; OFF in the package's default tier since round 5).  ON: bit-equal to the reference's one-thread autograd run
+    (tests/test_gpu_strict_order.py; per-channel weights with ch_axis = 0 and rows of up to 3072 columns included).  OFF:
+    float64 accumulation rounded once -- within 2e-5 of autograd's fp32 sums, 1.3x faster (53 against 68 us on
+    [256,128,768]); BASELINE.json asks 1e-5 on the dequantised tensor and names no bar for gradients.
+
+    Default tier when the library loads: ``set_strict(True, backward=False)``.  OSQ_STRICT=1: everything in the
+    reference's order; OSQ_STRICT=0: everything order-free; OSQ_STRICT_SIMD=16 for a 16-lane reference host.
+    ``reset_tier()`` returns to what the environment says."""
     from . import ops
     if simd_width not in (8, 16):
         raise ValueError("simd_width must be 8 or 16")
-    ops.set_tuning("mse_sum_order", simd_width if on else 0)
-    ops.set_tuning("bwd_sum_order", simd_width if on else 0)
+    backward = on if backward is None else backward
+    ops.set_tuning("mse_sum_order", simd_width if on else 0, _lib)
+    ops.set_tuning("bwd_sum_order", simd_width if backward else 0, _lib)
 
 
 def set_fast(on=True):
-    """Opt into the fusions that are NOT bit-comparable with the eager sequence (today: the one-launch LayerNorm site,
-    util_layernorm.FUSE_LAYERNORM -- see there for the bound)."""
+    """The one-launch LayerNorm site (util_layernorm.FUSE_LAYERNORM; default ON since round 5 -- see there for how it
+    compares with torch-ROCm's LayerNorm against the reference's CPU run).  ``set_fast(False)`` keeps the eager sequence."""
     from . import util_layernorm
     util_layernorm.FUSE_LAYERNORM = bool(on)
 
 
-def _apply_environment():
-    """Applied when the library is first loaded: the reference's summation order unless OSQ_STRICT=0; OSQ_FAST=1 opts
-    into the fusions of set_fast."""
+def reset_tier(_lib=None):
+    """The package's default tier, as the environment states it (applied when the library is first loaded): MSEFast sums in
+    the reference's one-thread order, the backward's sums order-free; OSQ_STRICT=1 / 0 force both; OSQ_FAST=0 / 1 the
+    one-launch LayerNorm site."""
     import os
-    set_strict(os.environ.get("OSQ_STRICT", "1") not in ("", "0"), int(os.environ.get("OSQ_STRICT_SIMD", "8")))
-    if os.environ.get("OSQ_FAST", "0") not in ("", "0"):
-        set_fast(True)
+    width = int(os.environ.get("OSQ_STRICT_SIMD", "8"))
+    strict = os.environ.get("OSQ_STRICT", "")
+    if strict == "":
+        set_strict(True, width, backward=False, _lib=_lib)
+    else:
+        set_strict(strict != "0", width, _lib=_lib)
+    fast = os.environ.get("OSQ_FAST", "")
+    if fast != "":
+        set_fast(fast != "0")
+
+
+_apply_environment = reset_tier

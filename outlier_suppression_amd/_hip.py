@@ -23,6 +23,7 @@ TIME_FAKE_QUANT_STRIDED, TIME_FAKE_QUANT_CHANNEL, TIME_OBSERVE_CHANNELS, TIME_TO
 TIME_OBSERVE_TOKENS = 13
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
+ABI_VERSION = 5               # OSQ_ABI_VERSION of include/osq_hip.h this file was written against
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -68,8 +69,8 @@ SIGNATURES = {
     "osq_fake_quant_weights_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_lsq_backward_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P]),
     "osq_ordered_sum_scratch_bytes": (ctypes.c_size_t, [_L, _I]),
-    "osq_lsq_backward_per_tensor_ordered": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, ctypes.c_size_t, _P, _P]),
-    "osq_lsq_backward_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
+    "osq_lsq_backward_per_tensor_ordered": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _I, _P, ctypes.c_size_t, _P, _P]),
+    "osq_lsq_backward_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _I, _P]),
     "osq_lsq_sanitize": (_I, [_P, _P, _L, _F, _I, _I, _P]),
     "osq_calculate_qparams": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P]),
     "osq_observe_flat": (_I, [_P, _L, _I, _L, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
@@ -144,9 +145,14 @@ def load():
             fn = getattr(lib, name)   # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
+        built = int(lib.osq_abi_version())
+        if built != ABI_VERSION:
+            raise HipLibraryMissing(
+                f"{LIB_PATH} was built against ABI {built}, this package needs ABI {ABI_VERSION}: rebuild it "
+                f"(`make -C {os.path.join(_HERE, 'csrc')}`); signatures or the workspace layout changed.")
+        from . import _apply_environment
+        _apply_environment(lib)   # OSQ_STRICT / OSQ_FAST -- before the library is published: no thread launches in another tier
         _lib = lib
-    from . import _apply_environment
-    _apply_environment()      # OSQ_STRICT / OSQ_FAST
     return _lib
 
 

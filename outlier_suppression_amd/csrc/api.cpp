@@ -67,5 +67,5 @@ extern "C" int osq_timing_elapsed_us(void* start, void* stop, float* us) {
 }
 
 extern "C" const char* osq_last_error(void) { return osq::g_error; }
-extern "C" int osq_abi_version(void) { return 4; }
-extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes + osq::kWsFusedBytes + osq::kWsResidentBytes + osq::kWsOneLaunchBytes; }
+extern "C" int osq_abi_version(void) { return OSQ_ABI_VERSION; }
+extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes + osq::kWsFusedBytes + osq::kWsResidentBytes + osq::kWsTokObsBytes; }

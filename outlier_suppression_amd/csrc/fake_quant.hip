@@ -21,7 +21,7 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 // whether loads / stores carry the non-temporal hint
 static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
 static int g_bwd_ord_chunks = 4;     // osq_set_tuning("bwd_order_chunks", n): level-1 chunks per workgroup of the reference-order backward
-static int g_bwd_sum_order = 0;      // osq_set_tuning("bwd_sum_order", 0 | 8 | 16): the LSQ / LSQ+ gradients summed in ATen's one-thread CPU order on 8- / 16-lane vectors (strict switch, lsq_bwd_tensor_ordered_kernel)
+// the summation order of the LSQ / LSQ+ backward (ATen's one-thread CPU order on 8- / 16-lane vectors, lsq_bwd_tensor_ordered_kernel) is an ARGUMENT of the entry points, not library state
 static int g_fq_max_blocks = 8192;
 static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
 static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
@@ -855,7 +855,6 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
     const int tail = static_cast<int>(n - n4 * 4);
     const int grid = grid_for(n4, kThreads * 2, g_bwd_blocks);
     Workspace ws(workspace);
-    OSQ_REQUIRE(!g_bwd_sum_order, "lsq_backward_per_tensor: with \"bwd_sum_order\" set the backward goes through osq_lsq_backward_per_tensor_ordered");
     const TimingHook th = take_timing_hook(OSQ_TIME_LSQ_BACKWARD);
     hipExtLaunchKernelGGL(lsq_bwd_tensor_kernel, dim3(grid), dim3(kThreads), 0, st, th.start, th.stop, 0, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<const float4*>(grad_out), reinterpret_cast<float4*>(grad_x), n4, x + n4 * 4,
@@ -868,13 +867,12 @@ extern "C" int osq_lsq_backward_per_tensor(const float* x, const float* grad_out
 extern "C" int osq_lsq_backward_per_tensor_ordered(const float* x, const float* grad_out, float* grad_x, int64_t n,
                                                    const float* scale, const void* zero_point, int zp_type,
                                                    int mode, float grad_factor, int quant_min, int quant_max,
-                                                   float* grad_scale, float* grad_zero_point,
+                                                   float* grad_scale, float* grad_zero_point, int lanes,
                                                    void* scratch, size_t scratch_bytes, void* workspace, osq_stream stream) {
     OSQ_REQUIRE(n > 0 && x && grad_out && grad_x && scale && zero_point && scratch && workspace, "lsq_backward_per_tensor_ordered: null pointer or n <= 0");
-    OSQ_REQUIRE(g_bwd_sum_order == 8 || g_bwd_sum_order == 16,
-                "lsq_backward_per_tensor_ordered: set \"bwd_sum_order\" to the reference machine's SIMD width (8 or 16) first");
-    OSQ_REQUIRE(scratch_bytes >= cascade_scratch_bytes(n, g_bwd_sum_order, 4, 4), "lsq_backward_per_tensor_ordered: scratch smaller than osq_ordered_sum_scratch_bytes(n, 4)");
-    const CascadeGeom geom = cascade_geom(n, g_bwd_sum_order);
+    OSQ_REQUIRE(lanes == 8 || lanes == 16, "lsq_backward_per_tensor_ordered: lanes = the reference machine's fp32 SIMD width (8 or 16)");
+    OSQ_REQUIRE(scratch_bytes >= cascade_scratch_bytes(n, lanes, 4, 4), "lsq_backward_per_tensor_ordered: scratch smaller than osq_ordered_sum_scratch_bytes(n, 4)");
+    const CascadeGeom geom = cascade_geom(n, lanes);
     OSQ_REQUIRE(geom.P <= kCascadeMaxP, "lsq_backward_per_tensor_ordered: tensor too large");
     Workspace ws(workspace);
     // a workgroup takes g_bwd_ord_chunks level-1 chunks so that its next chunk's loads travel under the current one's arithmetic
@@ -885,7 +883,7 @@ extern "C" int osq_lsq_backward_per_tensor_ordered(const float* x, const float* 
     hipExtLaunchKernelGGL(lsq_bwd_tensor_ordered_kernel, dim3(grid), dim3(kBwdOrdThreads), 0, static_cast<hipStream_t>(stream), th.start, th.stop, 0, x, grad_out,
                        grad_x, n, scale, zero_point, zp_type, mode, grad_factor, static_cast<float>(quant_min),
                        static_cast<float>(quant_max), grad_scale, grad_zero_point, static_cast<float*>(scratch),
-                       ws.counter(kFamLsqBackward), g_bwd_sum_order);
+                       ws.counter(kFamLsqBackward), lanes);
     return check_launch("lsq_backward_per_tensor_ordered");
 }
 
@@ -894,18 +892,19 @@ extern "C" int osq_lsq_backward_per_channel(const float* x, const float* grad_ou
                                             const float* scale, const void* zero_point, int zp_type,
                                             int mode, float grad_factor, int quant_min, int quant_max,
                                             float* grad_scale, float* grad_zero_point,
-                                            osq_stream stream) {
+                                            int sum_lanes, osq_stream stream) {
     OSQ_REQUIRE(outer >= 0 && channels >= 0 && inner >= 0 && scale && zero_point, "lsq_backward_per_channel: bad argument");
+    OSQ_REQUIRE(sum_lanes == 0 || sum_lanes == 8 || sum_lanes == 16, "lsq_backward_per_channel: sum_lanes must be 0, 8 or 16");
     if (outer * channels * inner == 0) return OSQ_OK;
     OSQ_REQUIRE(x && grad_out && grad_x, "lsq_backward_per_channel: null tensor");
     OSQ_REQUIRE(channels < (1ll << 31), "lsq_backward_per_channel: too many channels");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_bwd_sum_order && outer == 1 && inner <= 3072) {      // strict switch: weight rows in the reference's order (4 x inner floats of LDS)
+    if (sum_lanes && outer == 1 && inner <= 3072) {      // strict switch: weight rows in the reference's order (4 x inner floats of LDS)
         static_assert(kThreads / OSQ_WAVE == 4, "one wave per term");
         hipLaunchKernelGGL(lsq_bwd_channel_ordered_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads),
                            static_cast<size_t>(inner) * 16, st, x, grad_out, grad_x, channels, static_cast<int>(inner), scale, zero_point,
                            zp_type, mode, grad_factor, static_cast<float>(quant_min), static_cast<float>(quant_max), grad_scale,
-                           grad_zero_point, g_bwd_sum_order);
+                           grad_zero_point, sum_lanes);
         return check_launch("lsq_backward_per_channel(reference order)");
     }
     hipLaunchKernelGGL(lsq_bwd_channel_kernel, dim3(static_cast<unsigned>(channels)), dim3(kThreads), 0, st, x, grad_out,
@@ -939,7 +938,6 @@ extern "C" int osq_set_tuning(const char* key, int value) {
     OSQ_REQUIRE(key, "set_tuning: null key");
     const std::string k(key);
     if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
-    else if (k == "bwd_sum_order") { OSQ_REQUIRE(value == 0 || value == 8 || value == 16, "bwd_sum_order must be 0, 8 or 16"); osq::g_bwd_sum_order = value; }
     else if (k == "bwd_order_chunks") { OSQ_REQUIRE(value >= 1 && value <= 64, "bwd_order_chunks must be 1..64"); osq::g_bwd_ord_chunks = value; }
     else if (k == "fq_headsplit") { osq::g_fq_headsplit = value != 0; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }

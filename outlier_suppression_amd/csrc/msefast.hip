@@ -1506,8 +1506,6 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     Workspace ws(workspace);
     const int64_t n4 = n / 4;
     const int grid = grid_for(n4, kThreads * 2, kMaxBlocks);
-    OSQ_REQUIRE(g_mse_sum_order != 8 && g_mse_sum_order != 16,
-                "msefast_tensor_evals_flat: with \"mse_sum_order\" 8 / 16 the evaluations go through osq_msefast_tensor_evals_ordered");
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
@@ -1523,8 +1521,6 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     OSQ_REQUIRE(v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0, "msefast_tensor_evals_tokens: empty view");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
-    OSQ_REQUIRE(g_mse_sum_order != 8 && g_mse_sum_order != 16,
-                "msefast_tensor_evals_tokens: with \"mse_sum_order\" 8 / 16 the site is gathered (osq_gather_valid_tokens) and evaluated by osq_msefast_tensor_evals_ordered");
     double* count = ws.doubles(kFamMseTokens) + kMaxBlocks;        // behind the partials
     hipLaunchKernelGGL(msefast_valid_count_kernel, dim3(1), dim3(64), 0, st, lengths, v.batch, v.tokens,
                        v.feat_outer * v.feat_inner, count);

@@ -4,6 +4,7 @@ Everything here runs on the current HIP stream and never synchronises with the
 host.  No arithmetic on tensor data happens in Python; torch only allocates.
 """
 import ctypes
+import os
 
 import torch
 
@@ -155,24 +156,19 @@ def lsq_backward_per_tensor(x, grad_out, scale, zero_point, quant_min, quant_max
     dz = torch.empty(1, dtype=torch.float32, device=x.device) if need_zp else None
     ws = _hip.workspace(x.device)
     order = reference_sum_order("bwd")
-    if order and x.numel() > 0 and ordered_sum_fits(x.numel(), order):     # default tier: autograd's four fp32 reductions in torch's one-thread order
+    if order and x.numel() > 0 and ordered_sum_fits(x.numel(), order):     # set_strict(backward=True): autograd's four fp32 reductions in torch's one-thread order
         scratch, nbytes = _ordered_scratch(x.device, x.numel(), 4)
         _hip.check(lib.osq_lsq_backward_per_tensor_ordered(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
                                                            _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
-                                                           int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz),
+                                                           int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), order,
                                                            _hip.ptr(scratch), nbytes, _hip.ptr(ws), _hip.stream_ptr(x.device)),
                    "lsq_backward_per_tensor_ordered")
         return dx, ds, dz
-    if order:                                            # beyond the ordered kernels' capacity: the order-free sums for this call
-        set_tuning("bwd_sum_order", 0)
-    try:
-        _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
-                                                   _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
-                                                   int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
-                                                   _hip.stream_ptr(x.device)), "lsq_backward_per_tensor")
-    finally:
-        if order:
-            set_tuning("bwd_sum_order", order)
+    # order-free sums (the default): float64 accumulation rounded once; also what a tensor beyond the ordered kernels' capacity takes
+    _hip.check(lib.osq_lsq_backward_per_tensor(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), x.numel(), _hip.ptr(scale),
+                                               _hip.ptr(zero_point), _zp_type(zero_point), mode, float(grad_factor),
+                                               int(quant_min), int(quant_max), _hip.ptr(ds), _hip.ptr(dz), _hip.ptr(ws),
+                                               _hip.stream_ptr(x.device)), "lsq_backward_per_tensor")
     return dx, ds, dz
 
 
@@ -190,7 +186,8 @@ def lsq_backward_per_channel(x, grad_out, scale, zero_point, ch_axis, quant_min,
     _hip.check(lib.osq_lsq_backward_per_channel(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dx), outer, channels, inner,
                                                 _hip.ptr(scale), _hip.ptr(zero_point), _zp_type(zero_point), mode,
                                                 float(grad_factor), int(quant_min), int(quant_max), _hip.ptr(ds),
-                                                _hip.ptr(dz), _hip.stream_ptr(x.device)), "lsq_backward_per_channel")
+                                                _hip.ptr(dz), reference_sum_order("bwd"), _hip.stream_ptr(x.device)),
+               "lsq_backward_per_channel")
     return dx, ds, dz
 
 
@@ -355,11 +352,16 @@ _wide_min_slots = 32769
 _tuning = {}          # what set_tuning has been given (the summation-order switches decide which entry point a call takes)
 
 
-def set_tuning(key, value):
+def set_tuning(key, value, lib=None):
     """Performance / path-selection knobs of the library (osq_set_tuning).  Results never change -- except for the two
     summation-order switches ("mse_sum_order", "bwd_sum_order": 8 / 16 = the reference's one-thread CPU order, see
-    outlier_suppression_amd.set_strict), which pick WHICH of two roundings of the same sum is returned."""
-    _hip.check(_hip.load().osq_set_tuning(key.encode(), int(value)), f"set_tuning({key})")
+    outlier_suppression_amd.set_strict), which pick WHICH of two roundings of the same sum is returned.
+    "bwd_sum_order" is host state only: the backward's entry points take the order as an argument per call."""
+    if key == "bwd_sum_order":
+        if int(value) not in (0, 8, 16):
+            raise ValueError("bwd_sum_order must be 0, 8 or 16")
+    else:
+        _hip.check((lib or _hip.load()).osq_set_tuning(key.encode(), int(value)), f"set_tuning({key})")
     _tuning[key] = int(value)
 
 
@@ -513,7 +515,6 @@ def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, m
                                 lst.data_ptr() if n >= _wide_min_slots else None, _hip.raw_stream(dev))
     if rc != 0:
         _hip.check(rc, "observe_tokens")
-    _persistent_dirty.add((dev.index, _hip.raw_stream(dev)))      # the one-launch form's selectors wait (bounded) for records
     return view.batch, view.tokens, lengths
 
 
@@ -672,12 +673,8 @@ def msefast_tensor_run(r, chunk=None, two_d=True):
     order = reference_sum_order("mse")
     if order and msefast_ordered_fits(r):
         return _msefast_tensor_run_ordered(r, chunk, two_d)
-    if order:                                            # beyond the ordered kernels' capacity: the order-free sums for this search
-        set_tuning("mse_sum_order", 0)
-        try:
-            return msefast_tensor_run(r, chunk, two_d)
-        finally:
-            set_tuning("mse_sum_order", order)
+    # order-free sums.  (With the reference order set and a tensor beyond the ordered kernels' capacity the resident form
+    # answers OSQ_ERR_UNSUPPORTED and the streaming evaluations below run: no library state is toggled for one call.)
     rc = lib.osq_msefast_tensor_search(_hip.ptr(r.state), _hip.ptr(r.x), r.x.numel(), None if r.view is None else ctypes.byref(r.view),
                                        _hip.ptr(r.lengths), _hip.ptr(ws), st)
     if rc not in (0, _hip.ERR_UNSUPPORTED):
@@ -730,6 +727,33 @@ def _msefast_tensor_run_ordered(r, chunk, two_d):
 
 
 ORDERED_GROUP_SITES = 128     # searches one table of osq_msefast_ordered_multi_* holds
+# Bytes of site data one group of rounds may sweep.  Every round reads every unfinished site of its group once, and a
+# search is 15-500 rounds: a group that fits the 256 MiB Infinity Cache is served from it from its second round on, a
+# forward's worth of sites (BERT-base [32,128]: 0.57 GB) re-streams from HBM every round (profiles/r04_calibration_config3:
+# 3.4 TB/s).  Masked sites count with all their slots (the valid share is only known on the device).  0 = no bound.
+ORDERED_GROUP_BYTES = int(os.environ.get("OSQ_MSE_GROUP_MIB", "192")) << 20
+
+
+def msefast_ordered_groups(searches, two_d):
+    """Partition the searches of a flush into the groups whose rounds run together: nested (2-D) searches first, in
+    forward order, then the 1-D ones (a 1-D search ends after ~20 rounds, a nested one after hundreds -- apart, the
+    short ones do not sit in the long ones' tables), each group bounded by ORDERED_GROUP_SITES and ORDERED_GROUP_BYTES.
+    Grouping never changes a result: every search's evaluations are its own (tests/test_gpu_strict_order.py)."""
+    groups = []
+    for kind in (True, False):
+        cur, used = [], 0
+        for r, nested in zip(searches, two_d):
+            if bool(nested) != kind:
+                continue
+            nbytes = 4 * int(r.elems)
+            if cur and (len(cur) == ORDERED_GROUP_SITES or (ORDERED_GROUP_BYTES and used + nbytes > ORDERED_GROUP_BYTES)):
+                groups.append(cur)
+                cur, used = [], 0
+            cur.append(r)
+            used += nbytes
+        if cur:
+            groups.append(cur)
+    return groups
 
 
 def msefast_tensor_run_ordered_group(group, chunk=64):

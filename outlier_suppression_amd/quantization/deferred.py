@@ -46,8 +46,8 @@ class DeferredSites:
         if ops.reference_sum_order("mse"):
             # strict sums: one launch per ROUND of loss evaluations of all the forward's searches (128 per table)
             fit = [it for it in pending if ops.msefast_ordered_fits(it[1])]
-            for i in range(0, len(fit), ops.ORDERED_GROUP_SITES):
-                ops.msefast_tensor_run_ordered_group([it[1] for it in fit[i:i + ops.ORDERED_GROUP_SITES]])
+            for group in ops.msefast_ordered_groups([it[1] for it in fit], [it[2] for it in fit]):
+                ops.msefast_tensor_run_ordered_group(group)
                 self.launches += 1
             for it in pending:
                 if not ops.msefast_ordered_fits(it[1]):              # beyond the ordered kernels' capacity (> 134 M elements)

@@ -44,11 +44,11 @@ def eq32():
 @pytest.fixture()
 def order_free():
     """The ORDER-FREE tier for one test (outlier_suppression_amd.set_strict(False)): exact / float64 sums, the resident
-    per-tensor MSEFast searches; the package default (the reference's one-thread summation order) is restored afterwards."""
+    per-tensor MSEFast searches; the package's default tier is restored afterwards."""
     import outlier_suppression_amd as osq
     osq.set_strict(False)
     yield
-    osq.set_strict(True)
+    osq.reset_tier()
 
 
 def aten_order_mean(sq):
@@ -70,7 +70,8 @@ def sum_tier(request):
     if request.param == "order-free":
         osq.set_strict(False)
     else:
+        osq.set_strict(True)                      # both sums in the reference's order (the backward's is opt-in since round 5)
         OB.MEAN_LIKE_TORCH = aten_order_mean
     yield request.param
     OB.MEAN_LIKE_TORCH = old
-    osq.set_strict(True)
+    osq.reset_tier()

@@ -161,7 +161,7 @@ def test_lsqplus_gradients_equal_reference_in_its_summation_order(golden, eq32, 
             assert eq32(N(y), g[f"c{k}_y"]) and eq32(N(x.grad), g[f"c{k}_dx"])
             assert eq32(N(s.grad), g[f"c{k}_ds"]) and eq32(N(z.grad), g[f"c{k}_dzp"]), (k, N(s.grad), g[f"c{k}_ds"], N(z.grad), g[f"c{k}_dzp"])
     finally:
-        ops.set_tuning("bwd_sum_order", 8)      # the default
+        ops.set_tuning("bwd_sum_order", 0)      # the default tier (order-free backward sums since round 5)
 
 
 def test_lsqplus_per_channel_gradients_equal_reference_in_its_summation_order(golden, eq32, dev):
@@ -181,7 +181,7 @@ def test_lsqplus_per_channel_gradients_equal_reference_in_its_summation_order(go
         assert eq32(N(y), g["pc_y"]) and eq32(N(x.grad), g["pc_dx"])
         assert eq32(N(s.grad), g["pc_ds"]) and eq32(N(z.grad), g["pc_dzp"]), (N(s.grad), g["pc_ds"], N(z.grad), g["pc_dzp"])
     finally:
-        osq.set_strict(True)
+        osq.reset_tier()
 
 
 def test_lsq_backward_determinism_and_size(dev):

@@ -36,7 +36,7 @@ def strict():
     import outlier_suppression_amd as osq
     osq.set_strict(True)
     yield
-    osq.set_strict(True)
+    osq.reset_tier()
 
 
 def N(t):
@@ -70,7 +70,7 @@ def test_ordered_backward_equals_oracle_at_any_length(dev, width):
             assert np.array_equal(N(dx), rdx), n
             assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (n, width, ds.item(), rds, dz.item(), rdz)
     finally:
-        ops.set_tuning("bwd_sum_order", 8)      # the default
+        ops.set_tuning("bwd_sum_order", 0)      # the default tier
 
 
 def _oracle_order_mean(width):
@@ -189,7 +189,7 @@ def simd_width(request):
     import outlier_suppression_amd as osq
     osq.set_strict(True, simd_width=request.param)
     yield request.param
-    osq.set_strict(True)                                            # the default width
+    osq.reset_tier()                                                # the default tier and width
 
 
 def test_ordered_rounds_equal_search_by_search(dev, simd_width):
@@ -242,34 +242,33 @@ def test_tensors_beyond_the_ordered_capacity_keep_order_free_sums(dev):
     import outlier_suppression_amd as osq
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization.observer import MSEFastObserver
-    assert ops.reference_sum_order("mse") == 8 and ops.reference_sum_order("bwd") == 8
-    n = (1 << 28) + 64
-    assert ops.ordered_sum_fits(1 << 28, 8) and not ops.ordered_sum_fits(n, 8)
-    g = torch.Generator(device=dev).manual_seed(3)
-    x = torch.randn(n, device=dev, generator=g)
-    gy = torch.randn(n, device=dev, generator=g)
-    s = torch.tensor([0.05], device=dev)
-    z = torch.tensor([31.0], device=dev)
-    got = ops.lsq_backward_per_tensor(x, gy, s, z, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
-    assert ops.reference_sum_order("bwd") == 8
-    osq.set_strict(False)
+    osq.set_strict(True)
     try:
+        assert ops.reference_sum_order("mse") == 8 and ops.reference_sum_order("bwd") == 8
+        n = (1 << 28) + 64
+        assert ops.ordered_sum_fits(1 << 28, 8) and not ops.ordered_sum_fits(n, 8)
+        g = torch.Generator(device=dev).manual_seed(3)
+        x = torch.randn(n, device=dev, generator=g)
+        gy = torch.randn(n, device=dev, generator=g)
+        s = torch.tensor([0.05], device=dev)
+        z = torch.tensor([31.0], device=dev)
+        got = ops.lsq_backward_per_tensor(x, gy, s, z, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
+        assert ops.reference_sum_order("bwd") == 8
+        osq.set_strict(False)
         want = ops.lsq_backward_per_tensor(x, gy, s, z, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
-    finally:
         osq.set_strict(True)
-    assert all(torch.equal(a, b) for a, b in zip(got, want))
-    del gy, got, want
-    m = (1 << 27) + 32                                   # float64 calls: half the lanes
-    xs = x[:m]
-    a = MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
-    a(xs); a(xs)
-    assert ops.reference_sum_order("mse") == 8
-    osq.set_strict(False)
-    try:
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+        del gy, got, want
+        m = (1 << 27) + 32                                   # float64 calls: half the lanes
+        xs = x[:m]
+        a = MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
+        a(xs); a(xs)
+        assert ops.reference_sum_order("mse") == 8
+        osq.set_strict(False)
         b = MSEFastObserver(bit=4, symmetric=True, ch_axis=-1).to(dev)
         b(xs); b(xs)
     finally:
-        osq.set_strict(True)
+        osq.reset_tier()
     assert torch.equal(a.min_val, b.min_val) and torch.equal(a.max_val, b.max_val) and torch.equal(a.last_nfev, b.last_nfev)
 
 
@@ -343,8 +342,8 @@ def test_small_sites_in_every_layout_equal_oracle_lone_and_in_rounds(dev):
         OB.MEAN_LIKE_TORCH = old
 
 
-def test_backward_on_a_dense_permuted_input_follows_memory_order(dev):
-    """The default (reference-order) LSQ+ backward on the key layer's layout -- [B,h,d,T] view of [B,T,h,d] memory, grad_out
+def test_backward_on_a_dense_permuted_input_follows_memory_order(dev, strict):
+    """The reference-order LSQ+ backward (set_strict(True)) on the key layer's layout -- [B,h,d,T] view of [B,T,h,d] memory, grad_out
     handed over contiguous in the LOGICAL layout as autograd may do -- equals the oracle fed the memory image: what torch's
     own autograd computes for such an input (tests/test_oracle_pinning.py::test_autograd_adds_a_dense_permuted_input_in_memory_order)."""
     from outlier_suppression_amd import ops

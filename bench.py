@@ -357,6 +357,84 @@ def kernel_table(dev, xs, lengths, reps=20):
 SHORT = os.environ.get("OSQ_BENCH_SHORT") == "1"
 
 
+class CollectiveClock:
+    """Seconds a calibration flow spends inside collectives at N > 1, per phase: a synchronised host-side bracket round
+    every calibration.gather_batch_table / torch.distributed.all_reduce / all_gather_into_tensor the package issues while
+    the clock is installed (the bracket's own synchronisations are part of what is reported: the exchange is latency-
+    bound, a few KB per call).  N = 1: nothing is patched and every figure is 0.0."""
+
+    def __init__(self, world):
+        self.world, self.total, self.calls, self._last, self.phases = world, 0.0, 0, 0.0, {}
+        self._saved = []
+
+    def _wrap(self, fn):
+        def timed(*a, **k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            self.total += time.perf_counter() - t
+            self.calls += 1
+            return r
+        return timed
+
+    def __enter__(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            from outlier_suppression_amd import calibration
+            for mod, name in ((calibration, "gather_batch_table"), (dist, "all_reduce"), (dist, "all_gather_into_tensor")):
+                self._saved.append((mod, name, getattr(mod, name)))
+                setattr(mod, name, self._wrap(getattr(mod, name)))
+        return self
+
+    def __exit__(self, *exc):
+        for mod, name, fn in self._saved:
+            setattr(mod, name, fn)
+        self._saved = []
+
+    def mark(self, phase):
+        """Close a phase: what the collectives took since the previous mark."""
+        self.phases[phase] = round(self.phases.get(phase, 0.0) + self.total - self._last, 4)
+        self._last = self.total
+
+    def report(self):
+        return {"collective_s": round(self.total, 4), "collective_calls": self.calls, "collective_phases_s": dict(self.phases)}
+
+
+def quantizer_exchange_check(model, world, share, dev):
+    """After a sharded calibration every rank must hold the same scale / zero_point bits for every quantizer (SURVEY 8e:
+    the gathered tables are replayed in global batch order on every rank).  Gathers a checksum of all of them."""
+    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
+    acc, n = 0, 0
+    for _, m in model.named_modules():
+        if isinstance(m, QuantizeBase) and getattr(m, "scale", None) is not None:
+            for t in (m.scale, m.zero_point):
+                if t is None:
+                    continue
+                tt = t.detach().reshape(-1)
+                bits = tt.view(torch.int32) if tt.dtype in (torch.float32, torch.int32) else tt.to(torch.float32).view(torch.int32)
+                acc = (acc * 1000003 + int(bits.to(torch.int64).sum().item())) % (1 << 61)
+                n += tt.numel()
+    if world == 1:
+        return {"ranks": 1, "parameters_compared": n, "same_bits_on_every_rank": True}
+    import torch.distributed as dist
+    mine = torch.tensor([acc], dtype=torch.int64, device="cpu" if share else dev)
+    every = torch.empty(world, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(every, mine)
+    same = bool((every == mine).all().item())
+    if not same:
+        raise SystemExit(f"bench.py: ranks ended a sharded calibration with different quantizer parameters: checksums {every.tolist()}")
+    return {"ranks": world, "parameters_compared": n, "same_bits_on_every_rank": same}
+
+
+def device_identity(dev):
+    """Something that tells two physical GPUs apart: the device's UUID, else its PCI address."""
+    p = torch.cuda.get_device_properties(dev)
+    uuid = getattr(p, "uuid", None)
+    pci = ":".join(str(getattr(p, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return f"{uuid}|{pci}|{p.name}"
+
+
 def calibration_wall_clock(dev, rank, world, search="cached"):
     """BASELINE configs[1]: BERT-base (random init, HF default config), CoLA-shaped calibration set
     (256 samples = 8 batches of [32, 128], synthetic ids / lengths), twc_fine_gamma W6A6:
@@ -400,10 +478,18 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
         if world > 1:
             dist.barrier()
 
+    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
+    clock = None
+
     def run(search, strict_learn=False):
-        nonlocal model
+        nonlocal model, clock
         model = quantize_model(fp, w_q, a_q).to(dev)      # deep copy of the FP model, as quant_model.py:44-48: fp stays pristine
         phases = {}
+        with CollectiveClock(world) as clock:
+            return _run(search, strict_learn, phases)
+
+    def _run(search, strict_learn, phases):
+        nonlocal model
         sync()
         t_start = t0 = time.perf_counter()
         with torch.no_grad():
@@ -416,25 +502,26 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
                 fp_output = list(calibration.gather_batch_table(local, n_batches).unbind(0))
             else:
                 fp_output = [model(**b)[0].detach() for b in batches]
-        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("fp_outputs")
         m = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type="bert", task_type="glue"))
-        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("gamma_migration")
         enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
         with torch.no_grad():
             m(**batches[0])
         disable_all(m)
         set_observer_name(m)
-        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("weight_calibration")
         grid = {"iters": 3 if SHORT else 30, "step": 0.01}       # cac_step_iters(6 bit, bs 32, T 128), token_wise_clipping.py:118-129
         if search == "cached":
             ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid,
                                           n_batches=n_batches)
         else:
             ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
-        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("twc_grid_search")
         # N > 1: every Adam step is split inside the batch (32/N samples per rank, averaged gradients)
         (TWC.learn_scale if strict_learn else TWC.learn_scale_sharded)(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
-        sync(); phases["learn_scale"] = time.perf_counter() - t0
+        sync(); phases["learn_scale"] = time.perf_counter() - t0; clock.mark("learn_scale")
+        model = m
         return time.perf_counter() - t_start, phases, ratio
 
     if SHORT:
@@ -449,7 +536,7 @@ def calibration_wall_clock(dev, rank, world, search="cached"):
     out = {"config": "configs[1]: BERT-base CoLA twc_fine_gamma W6A6, 256 samples (8 x [32,128]), random-init weights, synthetic ids",
            "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}, "best_percentile": ratio,
            "first_run_wall_s": round(first_wall, 3), "first_run_phases_s": {k: round(v, 3) for k, v in first_phases.items()},
-           "twc_candidates": 30,
+           "twc_candidates": 30, **clock.report(), "exchange_check": quantizer_exchange_check(model, world, share, dev),
            "search": ("cached per-token extrema + 1 re-threshold launch per candidate, sharded over ranks" if search == "cached"
                       else "literal reference order: 2 model passes per candidate"),
            "learn_scale": ("sequential Adam, one process" if world == 1 else
@@ -495,6 +582,7 @@ def calibration_plain(dev, rank, world):
     res = {}
     for rep in range(2):                       # the second run is the steady state (allocator, library handles)
         model = quantize_model(fp, section.w_qconfig, section.a_qconfig).to(dev)
+        clock = CollectiveClock(world).__enter__()
         sync()
         t0 = time.perf_counter()
         if world == 1:
@@ -513,6 +601,10 @@ def calibration_plain(dev, rank, world):
                 enable_quantization(model)
         sync()
         res = {"wall_s": round(time.perf_counter() - t0, 4), "fp_outputs_s": round(t1 - t0, 4)}
+        clock.mark("observer_pass")
+        res.update(clock.report())
+        clock.__exit__()
+        res["exchange_check"] = quantizer_exchange_check(model, world, os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check"), dev)
     return {"config": "configs[0]: BERT-base CoLA PTQ, plain MinMax flow W6A6 (exp/bert_ptq/minmax), 256 samples (8 x [32,128]), "
                       "random-init weights, synthetic ids", **res, "n_gpus": world,
             "observer_pass": "every site of a forward reduced together (quantization/deferred.py)" if world == 1 else
@@ -555,18 +647,7 @@ def calibration_extra(dev, rank, world, which):
         if world > 1:
             dist.barrier()
 
-    gather_s = [0.0]
-    real_gather = calibration.gather_batch_table
-
-    def timed_gather(*a, **k):          # the collective's share of the wall-clock (host-side bracket, sync'ed)
-        if world == 1:
-            return real_gather(*a, **k)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        r = real_gather(*a, **k)
-        torch.cuda.synchronize()
-        gather_s[0] += time.perf_counter() - t
-        return r
+    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
     twc_a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
     twc_w = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
     phases, out = {}, {}
@@ -590,9 +671,9 @@ def calibration_extra(dev, rank, world, which):
         task, mtype, grid = "squad", "bert", {"iters": int(os.environ.get("OSQ_BENCH_SQUAD_CANDIDATES", "3" if SHORT else "90")), "step": 0.0033}
         out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
     elif which in (4, 5):
-        # 4: bart-base dimensions, what the reference's shipped config points at (exp/xsum/twc_fine_gamma/config.yaml:44);
-        # 5 (opt-in, --calib-configs ...,5): bart-large dimensions, what BASELINE.json's configs[4] names
-        d_model, layers, heads, ffn = (768, 6, 12, 3072) if which == 4 else (1024, 12, 16, 4096)
+        # 4: bart-LARGE dimensions, what BASELINE.json's configs[4] names; 5: bart-base dimensions, what the reference's shipped
+        # config points at (exp/xsum/twc_fine_gamma/config.yaml:44) -- both run by default
+        d_model, layers, heads, ffn = (768, 6, 12, 3072) if which == 5 else (1024, 12, 16, 4096)
         cfg = T.BartConfig(d_model=d_model, encoder_layers=layers, decoder_layers=layers, encoder_attention_heads=heads,
                            decoder_attention_heads=heads, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, max_position_embeddings=1024,
                            dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
@@ -606,7 +687,7 @@ def calibration_extra(dev, rank, world, which):
             b["decoder_attention_mask"] = dm.to(dev)
         task, mtype, grid = "summ", "bart", {"iters": 3 if SHORT else 30, "step": 0.01}
         out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, " +
-                         ("bart-base dimensions (the reference's shipped config)" if which == 4 else
+                         ("bart-base dimensions (the reference's shipped config)" if which == 5 else
                           "bart-LARGE dimensions (d 1024, 16 heads, 12 + 12 layers, ffn 4096: what BASELINE.json names)") +
                          ", 256 samples (64 x ([4,1024] source, [4,62] target)), 30 candidates, learn-scale 3 epochs")
     else:
@@ -672,7 +753,10 @@ def calibration_extra(dev, rank, world, which):
         act_evals = sum(int(q.observer.last_nfev.sum().item()) for q in mine_a if q.observer.last_nfev is not None)
         return {"config": "configs[3]: RoBERTa-base MNLI W4A6, per-channel weights + MSEFast, 256 samples (8 x [32,128])",
                 "wall_s": round(wall, 3), "first_run_wall_s": round(first_wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
-                "collective_s": round(info_w["collective_s"] + info_a["collective_s"], 4), "order_free": order_free,
+                "collective_s": round(info_w["collective_s"] + info_a["collective_s"], 4),
+                "collective_phases_s": {"weight_calibration_msefast_per_channel": round(info_w["collective_s"], 4),
+                                        "activation_calibration_msefast_per_tensor": round(info_a["collective_s"], 4)},
+                "exchange_check": quantizer_exchange_check(model, world, share, dev), "order_free": order_free,
                 "weight_rows_searched_on_rank0": rows, "weight_loss_evaluations_on_rank0": evals,
                 "activation_sites": len(act_q), "activation_sites_on_rank0": len(mine_a),
                 "activation_loss_evaluations_last_batch_on_rank0": act_evals, "n_gpus": world,
@@ -684,7 +768,7 @@ def calibration_extra(dev, rank, world, which):
     n_batches = len(batches)
     mine = calibration.shard_batches(n_batches, rank, world)
     model = quantize_model(fp, twc_w, twc_a).to(dev)
-    calibration.gather_batch_table = timed_gather
+    clock = CollectiveClock(world).__enter__()
     try:
         def targets(bs):
             res = []
@@ -700,17 +784,17 @@ def calibration_extra(dev, rank, world, which):
         sync()
         t_start = t0 = time.perf_counter()
         fp_output = targets(batches)           # every rank: FP targets of all batches (cheap next to the search)
-        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("fp_outputs")
         m = delay_ln(model, NS(a_qconfig=twc_a, w_qconfig=twc_w), NS(model_type=mtype, task_type=task))
-        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("gamma_migration")
         enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
         with torch.no_grad():
             m(**batches[0])
         disable_all(m)
         set_observer_name(m)
-        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("weight_calibration")
         ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid, n_batches=n_batches)
-        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("twc_grid_search")
         if which == 2:        # ptq_qa_quant.py:262-267: smaller batches for the fine stage, targets recomputed with everything off
             disable_all(m)
             model = m
@@ -722,9 +806,11 @@ def calibration_extra(dev, rank, world, which):
         else:
             learn_in, learn_out = batches, fp_output
         TWC.learn_scale_sharded(NS(model=m), learn_in, learn_out, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
-        sync(); phases["learn_scale"] = time.perf_counter() - t0
-        out.update({"wall_s": round(time.perf_counter() - t_start, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
-                    "collective_s": round(gather_s[0], 4), "best_percentile": ratio, "twc_candidates": grid["iters"],
+        sync(); phases["learn_scale"] = time.perf_counter() - t0; clock.mark("learn_scale")
+        wall = time.perf_counter() - t_start
+        out.update({"wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
+                    **clock.report(), "exchange_check": quantizer_exchange_check(m, world, share, dev),
+                    "best_percentile": ratio, "twc_candidates": grid["iters"],
                     "search": "cached per-token extrema, one re-threshold launch per candidate and geometry group, sharded over ranks",
                     "learn_scale": ("sequential Adam, one process" if world == 1 else
                                     ("sequential Adam, every step data-parallel inside the batch (kept-token targets sliced per rank, gradients summed)"
@@ -735,7 +821,7 @@ def calibration_extra(dev, rank, world, which):
                     "n_gpus": world})
         return out
     finally:
-        calibration.gather_batch_table = real_gather
+        clock.__exit__()
         TWC.task_type, TWC.model_type = "glue", "bert"
 
 
@@ -852,7 +938,7 @@ def self_launch(n):
     this process's stdout: rank 0 prints the one JSON line."""
     import socket
     import subprocess
-    share = os.environ.get("OSQ_BENCH_SHARE_GPU") == "1"
+    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have < n and not share:
         print(f"bench.py: --gpus {n} needs {n} visible HIP devices, this node shows {have} "
@@ -887,7 +973,7 @@ def main():
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel timing table")
     ap.add_argument("--calib-search", default="cached", choices=["cached", "literal"])
-    ap.add_argument("--calib-configs", default="0,1,2,3,4", help="BASELINE configs whose calibration wall-clock is measured (5 = configs[4] at bart-large dimensions, opt-in: ~1.5 min)")
+    ap.add_argument("--calib-configs", default="0,1,2,3,4,5", help="BASELINE configs whose calibration wall-clock is measured (4 = configs[4] at the bart-LARGE dimensions BASELINE.json names, ~1 min; 5 = the same flow at bart-base dimensions, what the reference's shipped config uses)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -902,7 +988,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     # test hook (1-GPU box): OSQ_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with a gloo group so that the
     # N > 1 control flow (sharding, exchange, barriers, max-over-ranks clock) can be exercised without N GPUs
-    share = os.environ.get("OSQ_BENCH_SHARE_GPU") == "1"
+    # ("check": the same hook, but the one-process-per-GPU assertion below stays armed -- tests/test_gpu_sharded.py uses it to
+    # see the command refuse N ranks on one device)
+    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
+    enforce_devices = not share or os.environ.get("OSQ_BENCH_SHARE_GPU") == "check"
     if share:
         local_rank = 0
         # several processes on ONE GPU: the one-launch step wants every CU for itself and cannot be ordered against
@@ -924,9 +1013,22 @@ def main():
         probe = torch.tensor([rank], dtype=torch.int64, device="cpu" if share else dev)
         seen = torch.empty(world, dtype=torch.int64, device=probe.device)
         dist.all_gather_into_tensor(seen, probe)
+        # ... and every rank's DEVICE: N ranks must sit on N different GPUs (a mis-set LOCAL_RANK / visibility mask would put
+        # two on one, where RCCL fails late or not at all), and the data path's backend must be RCCL -- fail here, loudly
+        idents = [None] * world
+        dist.all_gather_object(idents, device_identity(dev))
+        distinct = len(set(idents))
         collective = {"backend": "rccl (torch.distributed backend 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend() + " (shared-GPU test hook)",
                       "ranks_seen": int(seen.unique().numel()), "world_size": dist.get_world_size(),
-                      "devices_visible": torch.cuda.device_count(), "shared_gpu": share}
+                      "devices_visible": torch.cuda.device_count(), "distinct_devices": distinct, "shared_gpu": share}
+        if int(seen.unique().numel()) != world:
+            raise SystemExit(f"bench.py: {world} ranks were launched but only {int(seen.unique().numel())} took part in the first collective")
+        if not share and dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py: --gpus {world} must run on RCCL (torch.distributed backend 'nccl'), got {dist.get_backend()!r}")
+        if enforce_devices:
+            if distinct != world:
+                raise SystemExit(f"bench.py: {world} ranks share {distinct} device(s): {idents} -- one process per GPU is the contract "
+                                 "(check LOCAL_RANK / HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)")
     from outlier_suppression_amd import _hip, calibration
     _hip.load()
     for kv in filter(None, os.environ.get("OSQ_BENCH_TUNING", "").split(",")):      # A/B runs: "key=value,key=value" through osq_set_tuning
@@ -1080,6 +1182,8 @@ def main():
             y = issue(pick)
     dt, host_dt, gathered, y = region(pick, exchange=True)
     gc.enable()
+    probe_stats = {m: {"median": round(sorted(v)[len(v) // 2] / args.steps * 1e6, 3), "min": round(min(v) / args.steps * 1e6, 3),
+                       "max": round(max(v) / args.steps * 1e6, 3), "regions": len(v)} for m, v in probes.items() if v}
     launch_mode = ("hipGraph replay of %d captured module calls" % args.steps if pick == "graph" else "eager loop of %d module calls" % args.steps) + graph_note
     if len(modes) > 1:
         launch_mode += "; chosen by untimed probes of both (median of 5 regions, us per step: " + \
@@ -1233,8 +1337,12 @@ def main():
                    "launches_per_step": 1 if fused_on else 3, "buffers_cycled": len(xs),
                    "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
                    "hbm_bytes_per_step": 8 * n_elem,
-                   "launch": launch_mode,
-                   "sum_tier": ("reference order (package default): MSEFast losses and LSQ+ parameter gradients in ATen's one-thread order; the step "
+                   "launch": launch_mode, "launch_picked": pick,
+                   # the untimed probe regions that decided how the timed region is issued (five K-step regions per mode, alternating),
+                   # as numbers: median / min / max microseconds per step of each mode (null: that mode was not probed)
+                   "graph_us_per_step": probe_stats.get("graph", {}).get("median"), "eager_us_per_step": probe_stats.get("eager", {}).get("median"),
+                   "probe_regions_us_per_step": probe_stats,
+                   "sum_tier": ("package default: MSEFast losses in ATen's one-thread order, LSQ / LSQ+ parameter gradients order-free; the step "
                                 "itself holds no such sum" if _ops_order() else "order-free (OSQ_STRICT=0)"),
                    "eager_ms_per_step": round(eager_dt / args.steps * 1e3, 5),
                    "host_enqueue_ms_per_step": round(eager_host / args.steps * 1e3, 5),
@@ -1280,16 +1388,18 @@ def main():
             if which not in wanted:
                 continue
             try:          # a failure here must not cost the headline line
-                out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
+                out["calibration_config4_bart_base" if which == 5 else f"calibration_config{which}"] = calibration_extra(dev, rank, world, which)
             except Exception as e:
                 if world > 1:
                     raise          # see above: never leave the other ranks waiting in a collective
-                out["calibration_config4_bart_large" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                out["calibration_config4_bart_base" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         # Metric 2 in one place: wall-clock and the collective's share of every measured config at the launched N
         out["calibration_summary"] = {
             "n_gpus": world,
-            "configs": {k: {"wall_s": v.get("wall_s"), "collective_s": v.get("collective_s")}
+            "configs": {k: {"wall_s": v.get("wall_s"), "collective_s": v.get("collective_s", 0.0 if world == 1 else None),
+                            "collective_phases_s": v.get("collective_phases_s"),
+                            "same_parameters_on_every_rank": (v.get("exchange_check") or {}).get("same_bits_on_every_rank")}
                         for k, v in out.items() if k.startswith("calibration") and isinstance(v, dict) and "wall_s" in v}}
         if rank == 0 and not SHORT:
             try:

@@ -164,6 +164,24 @@ int osq_fake_quant_per_tensor_strided(const float* x, float* y, float* x_quant,
                                       int mode, float grad_factor, int quant_min, int quant_max,
                                       osq_stream stream);
 
+/* The query / key / value sites of one attention block (model/quant_bert.py:148-155: three Quantizer calls on the
+ * head-split views of three [B, T, h*d] projections) as ONE launch.  Site i reads x = [batch, tokens, heads, head_dim]
+ * memory (contiguous) and writes y = the dense [batch, heads, tokens, head_dim] tensor the batched matmul wants, with
+ * its own (scale, zero_point) -- the same arithmetic, parameter modes (incl. OSQ_PARAM_SANITIZE) and bits as
+ * osq_fake_quant_per_tensor_strided on each site.  1..4 sites of ONE geometry; head_dim / 4 a power of two <= 64,
+ * 16-byte aligned tensors, else OSQ_ERR_UNSUPPORTED (nothing launched: the caller runs the sites one by one). */
+typedef struct osq_headsplit_site {
+    const float* x;
+    float* y;
+    float* scale;
+    void* zero_point;
+    int32_t zp_type, mode;
+    float grad_factor;
+    int32_t quant_min, quant_max, pad;
+} osq_headsplit_site;
+int osq_fake_quant_headsplit_multi(const osq_headsplit_site* sites, int n_sites, int64_t batch, int64_t tokens,
+                                   int64_t heads, int64_t head_dim, osq_stream stream);
+
 /* util_quant.py:18-26 fake_quantize_per_channel_affine (and the per-channel learnable
  * forwards :37-45, :58-67).  x is contiguous and viewed as [outer, channels, inner]
  * with ch_axis in the middle; scale/zero_point have `channels` entries. */

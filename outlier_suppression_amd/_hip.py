@@ -45,6 +45,12 @@ class WeightDesc(ctypes.Structure):
                 ("quant_max", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class HeadSplitSite(ctypes.Structure):
+    """``osq_headsplit_site``: one entry of the table of osq_fake_quant_headsplit_multi."""
+    _fields_ = [("x", _P), ("y", _P), ("scale", _P), ("zero_point", _P), ("zp_type", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("grad_factor", _F), ("quant_min", ctypes.c_int32), ("quant_max", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 class SiteDesc(ctypes.Structure):
     """``osq_site_desc``: one entry of the table of osq_token_minmax_multi."""
     _fields_ = [("x", _P), ("lengths", _P), ("token_min", _P), ("token_max", _P), ("view", TokenView),
@@ -65,6 +71,7 @@ SIGNATURES = {
     "osq_gelu_fake_quant_per_tensor": (_I, [_P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_per_tensor_strided": (_I, [_P, _P, _P, ctypes.POINTER(_L), ctypes.POINTER(_L), ctypes.POINTER(_L),
                                                _P, _P, _I, _I, _F, _I, _I, _P]),
+    "osq_fake_quant_headsplit_multi": (_I, [ctypes.POINTER(HeadSplitSite), _I, _L, _L, _L, _L, _P]),
     "osq_fake_quant_per_channel": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _F, _I, _I, _P]),
     "osq_fake_quant_weights_multi": (_I, [_P, _P, _I, _L, _P]),
     "osq_lsq_backward_per_tensor": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P]),

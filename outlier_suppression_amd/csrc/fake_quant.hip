@@ -235,6 +235,54 @@ __global__ __launch_bounds__(kThreads) void fq_headsplit_kernel(
     }
 }
 
+// The query / key / value sites of one attention block (model/quant_bert.py:148-155) are three independent head splits of
+// the same geometry: ONE launch, blockIdx.y = site, each site with its own tensors and parameters (round 5: 24 launches
+// fewer per BERT-base forward).  Same arithmetic and index map as fq_headsplit_kernel, hence the same bits.
+constexpr int kHeadSplitSites = 4;
+struct HeadSplitSites {
+    const float4* x[kHeadSplitSites];
+    float4* y[kHeadSplitSites];
+    float* scale[kHeadSplitSites];
+    void* zp[kHeadSplitSites];
+    int zp_type[kHeadSplitSites], mode[kHeadSplitSites];
+    float g[kHeadSplitSites], qmin[kHeadSplitSites], qmax[kHeadSplitSites];
+};
+
+template <int UNROLL, int NT>
+__global__ __launch_bounds__(kThreads) void fq_headsplit_multi_kernel(HeadSplitSites s, HeadSplit d, unsigned int n4) {
+    const int site = blockIdx.y;
+    const float4* __restrict__ x = s.x[site];
+    float4* __restrict__ y = s.y[site];
+    const float qmin = s.qmin[site], qmax = s.qmax[site];
+    const QParams p = tensor_params(s.scale[site], s.zp[site], s.zp_type[site], s.mode[site], s.g[site], qmin, qmax);
+    const unsigned int stride = gridDim.x * kThreads;
+    const WtStore ywt(y, (NT & 4) ? n4 : 0);
+    auto out_index = [&](unsigned int e) {
+        const unsigned int bt = magic_div(e, d.row), c = e - bt * d.row.d;
+        const unsigned int b = magic_div(bt, d.tokens), t = bt - b * d.tokens.d;
+        const unsigned int head = c >> d.dv_shift, dd = c & ((1u << d.dv_shift) - 1u);
+        return (((b * d.h + head) * d.T + t) << d.dv_shift) + dd;
+    };
+    unsigned int i = blockIdx.x * kThreads + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = (NT & 1) ? load_stream(&x[i + u * stride]) : x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float4 o, q;
+            fq4<false>(v[u], o, q, p.scale, p.zp, qmin, qmax);
+            const unsigned int yo = out_index(i + u * stride);
+            if (NT & 4) ywt.put(yo, o); else if (NT & 2) store_stream(&y[yo], o); else y[yo] = o;
+        }
+    }
+    for (; i < n4; i += stride) {
+        float4 o, q;
+        fq4<false>(x[i], o, q, p.scale, p.zp, qmin, qmax);
+        y[out_index(i)] = o;
+    }
+}
+
 // ---------------------------------------------------------------- per-channel
 
 // [rows = outer*channels, inner] with inner % 4 == 0: one wave walks whole rows, the
@@ -802,6 +850,50 @@ extern "C" int osq_fake_quant_per_tensor_strided(const float* x, float* y, float
         hipLaunchKernelGGL(fq_tensor_strided_kernel<false>, dim3(grid), dim3(kThreads), 0, st, x, y, x_quant, d, n, scale,
                            zero_point, zp_type, mode, grad_factor, qmin, qmax);
     return check_launch("fake_quant_per_tensor_strided");
+}
+
+extern "C" int osq_fake_quant_headsplit_multi(const osq_headsplit_site* sites, int n_sites, int64_t batch, int64_t tokens,
+                                              int64_t heads, int64_t head_dim, osq_stream stream) {
+    OSQ_REQUIRE(sites && n_sites >= 1 && n_sites <= kHeadSplitSites, "fake_quant_headsplit_multi: 1..4 sites");
+    OSQ_REQUIRE(batch >= 0 && tokens >= 0 && heads >= 1 && head_dim >= 4, "fake_quant_headsplit_multi: bad geometry");
+    const int64_t n = batch * tokens * heads * head_dim, dvv = head_dim / 4;
+    if (n == 0) return OSQ_OK;
+    if (!g_fq_headsplit || head_dim % 4 != 0 || (dvv & (dvv - 1)) != 0 || dvv > 64 || n / 4 >= (1ll << 30) || heads * dvv >= (1ll << 31) ||
+        tokens >= (1ll << 31))
+        return OSQ_ERR_UNSUPPORTED;
+    HeadSplitSites hs_sites{};
+    for (int i = 0; i < n_sites; ++i) {
+        const osq_headsplit_site& t = sites[i];
+        OSQ_REQUIRE(t.x && t.y && t.scale && t.zero_point, "fake_quant_headsplit_multi: null pointer in a site");
+        if (!aligned16(t.x) || !aligned16(t.y)) return OSQ_ERR_UNSUPPORTED;
+        hs_sites.x[i] = reinterpret_cast<const float4*>(t.x);
+        hs_sites.y[i] = reinterpret_cast<float4*>(t.y);
+        hs_sites.scale[i] = t.scale;
+        hs_sites.zp[i] = t.zero_point;
+        hs_sites.zp_type[i] = t.zp_type;
+        hs_sites.mode[i] = t.mode;
+        hs_sites.g[i] = t.grad_factor;
+        hs_sites.qmin[i] = static_cast<float>(t.quant_min);
+        hs_sites.qmax[i] = static_cast<float>(t.quant_max);
+    }
+    HeadSplit hs;
+    hs.row = make_magic(heads * dvv);
+    hs.tokens = make_magic(tokens);
+    hs.dv_shift = 0;
+    while ((1ll << hs.dv_shift) < dvv) ++hs.dv_shift;
+    hs.h = static_cast<unsigned int>(heads);
+    hs.T = static_cast<unsigned int>(tokens);
+    const unsigned int n4 = static_cast<unsigned int>(n / 4);
+    const int hgrid = grid_for(n / 4, kThreads * 2, std::min(g_fq_max_blocks, 8192) / n_sites + 1);
+    const dim3 grid(static_cast<unsigned>(hgrid), static_cast<unsigned>(n_sites));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const TimingHook th = take_timing_hook(OSQ_TIME_FAKE_QUANT_STRIDED);
+#define OSQ_HEADSPLIT_M(NT) hipExtLaunchKernelGGL((fq_headsplit_multi_kernel<2, NT>), grid, dim3(kThreads), 0, st, th.start, th.stop, 0, hs_sites, hs, n4)
+    if (g_fq_nt >= 4 && n / 4 <= kWtMaxFloat4) { if (g_fq_nt & 1) OSQ_HEADSPLIT_M(5); else OSQ_HEADSPLIT_M(4); }
+    else if ((g_fq_nt & 3) == 3) OSQ_HEADSPLIT_M(3);
+    else OSQ_HEADSPLIT_M(1);
+#undef OSQ_HEADSPLIT_M
+    return check_launch("fake_quant_headsplit_multi");
 }
 
 extern "C" int osq_fake_quant_per_channel(const float* x, float* y, float* x_quant,

@@ -24,7 +24,7 @@ from torch import nn
 from ..quant_model_checks import classification_loss, lm_loss, span_loss, with_loss
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
-                              residual_layernorm, split_heads_fake_quant)
+                              qkv_heads_fake_quant, residual_layernorm, split_heads_fake_quant)
 
 
 def shift_tokens_right(input_ids, pad_token_id, decoder_start_token_id):
@@ -110,9 +110,17 @@ class QuantizedBartAttention(QuantizedModule):
         bsz, tgt_len, _ = hidden_states.shape
         source = hidden_states if key_value_states is None else key_value_states
         heads = self.num_heads
-        q = split_heads_fake_quant(self.query_post_act_fake_quantize, self.q_proj(hidden_states) * self.scaling, heads, observation_mask)
-        k = split_heads_fake_quant(self.key_post_act_fake_quantize, self.k_proj(source), heads, observation_mask)
-        v = split_heads_fake_quant(self.value_post_act_fake_quantize, self.v_proj(source), heads, observation_mask)
+        xq, xk, xv = self.q_proj(hidden_states) * self.scaling, self.k_proj(source), self.v_proj(source)
+        # self-attention in the plain quantising state: the three head-split sites in one launch (same bits); cross-attention
+        # (keys / values of another length) and every other state: site by site
+        fused = qkv_heads_fake_quant((self.query_post_act_fake_quantize, self.key_post_act_fake_quantize, self.value_post_act_fake_quantize),
+                                     (xq, xk, xv), heads) if xk.shape == xq.shape else None
+        if fused is not None:
+            q, k, v = fused
+        else:
+            q = split_heads_fake_quant(self.query_post_act_fake_quantize, xq, heads, observation_mask)
+            k = split_heads_fake_quant(self.key_post_act_fake_quantize, xk, heads, observation_mask)
+            v = split_heads_fake_quant(self.value_post_act_fake_quantize, xv, heads, observation_mask)
         proj = (bsz * self.num_heads, -1, self.head_dim)
         q, k, v = q.view(*proj), k.view(*proj), v.view(*proj)
         src_len = k.shape[1]

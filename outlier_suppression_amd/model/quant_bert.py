@@ -22,7 +22,7 @@ from ..quant_model_checks import classification_loss, span_loss, with_loss
 
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
-                              residual_layernorm)
+                              qkv_heads_fake_quant, residual_layernorm)
 
 
 class QuantizedBertEmbeddings(QuantizedModule):
@@ -72,11 +72,16 @@ class QuantizedBertSelfAttention(QuantizedModule):
         return x.view(b, t, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
 
     def forward(self, hidden_states, attention_mask=None, observation_mask=None):
-        q = self._heads(self.query(hidden_states))
-        k = self._heads(self.key(hidden_states))
-        v = self._heads(self.value(hidden_states))
-        q = self.query_permute_post_act_fake_quantize(q, observation_mask, 2)
-        kt = self.key_transpose_post_act_fake_quantize(k.transpose(-1, -2), observation_mask, 3)
+        xq, xk, xv = self.query(hidden_states), self.key(hidden_states), self.value(hidden_states)
+        # plain quantising state: the three head-split sites in one launch (same bits as the three calls below)
+        fused = qkv_heads_fake_quant((self.query_permute_post_act_fake_quantize, self.key_transpose_post_act_fake_quantize,
+                                      self.value_permute_post_act_fake_quantize), (xq, xk, xv), self.num_attention_heads)
+        if fused is not None:
+            q, kt, v = fused[0], fused[1].transpose(-1, -2), fused[2]
+        else:
+            q, k, v = self._heads(xq), self._heads(xk), self._heads(xv)
+            q = self.query_permute_post_act_fake_quantize(q, observation_mask, 2)
+            kt = self.key_transpose_post_act_fake_quantize(k.transpose(-1, -2), observation_mask, 3)
         scores = torch.matmul(q, kt)
         root = math.sqrt(self.attention_head_size)
         if attention_mask is not None and root == 2.0 ** round(math.log2(root)) and not torch.is_grad_enabled():
@@ -89,7 +94,8 @@ class QuantizedBertSelfAttention(QuantizedModule):
                 scores = scores + attention_mask
         probs = self.dropout(nn.functional.softmax(scores, dim=-1))
         probs = self.attention_probs_post_act_fake_quantize(probs, observation_mask, 2)
-        v = self.value_permute_post_act_fake_quantize(v, observation_mask, 2)
+        if fused is None:
+            v = self.value_permute_post_act_fake_quantize(v, observation_mask, 2)
         return merge_heads_fake_quant(self.context_view_post_act_fake_quantize if self.qoutput else None,
                                       torch.matmul(probs, v), observation_mask)
 

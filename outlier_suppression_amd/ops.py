@@ -1054,6 +1054,31 @@ def is_exact_gelu(fn):
     return type(fn).__name__ == "GELUActivation" and inner is F.gelu
 
 
+def fake_quant_headsplit_multi(xs, params, heads):
+    """The query / key / value sites of one attention block as ONE launch (osq_fake_quant_headsplit_multi).
+    xs: 1..4 contiguous [B, T, heads * d] fp32 tensors of one shape; params[i] = (scale, zero_point, quant_min, quant_max,
+    mode, grad_factor) of site i.  Returns the dense [B, heads, T, d] fake-quantised head-split tensors -- the bits of
+    fake_quant_per_tensor on each ``x.view(B, T, heads, d).permute(0, 2, 1, 3)`` -- or None when the kernel does not take the
+    geometry (nothing was launched)."""
+    lib = _hip.load()
+    n = len(xs)
+    b, t, width = xs[0].shape
+    d = width // heads
+    table = (_hip.HeadSplitSite * n)()
+    ys = []
+    for i, (x, (scale, zero_point, quant_min, quant_max, mode, grad_factor)) in enumerate(zip(xs, params)):
+        y = torch.empty((b, heads, t, d), dtype=x.dtype, device=x.device)
+        ys.append(y)
+        e = table[i]
+        e.x, e.y, e.scale, e.zero_point = x.data_ptr(), y.data_ptr(), scale.data_ptr(), zero_point.data_ptr()
+        e.zp_type, e.mode, e.grad_factor, e.quant_min, e.quant_max = _zp_type(zero_point), int(mode), float(grad_factor), int(quant_min), int(quant_max)
+    rc = lib.osq_fake_quant_headsplit_multi(table, n, b, t, heads, d, _hip.stream_ptr(xs[0].device))
+    if rc == _hip.ERR_UNSUPPORTED:
+        return None
+    _hip.check(rc, "fake_quant_headsplit_multi")
+    return ys
+
+
 def gelu_fake_quant_per_tensor(x, scale, zero_point, quant_min, quant_max, mode=PARAM_FIXED, grad_factor=1.0):
     """fake_quant(F.gelu(x)) in ONE launch; x dense fp32 on the device."""
     lib = _hip.load()

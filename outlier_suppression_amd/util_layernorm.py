@@ -22,6 +22,7 @@ from .quantization.fake_quant import _LearnableFakeQuantize
 
 FUSE_LAYERNORM = False
 FUSE_ACTIVATION = True
+FUSE_QKV = True          # the query / key / value head-split sites of a self-attention block as one launch (bit-identical)
 
 
 def _fused_site(mod, x, hidden, gamma, weight, bias, eps, observation_mask):
@@ -198,3 +199,29 @@ def split_heads_fake_quant(quantizer, x, heads, observation_mask=None):
         x = quantizer(x, observation_mask, 1)
     return x.view(b, t, heads, d).transpose(1, 2).contiguous()
 
+
+
+def qkv_heads_fake_quant(quantizers, projections, heads):
+    """The three activation quantizers behind the query / key / value projections of a self-attention block
+    (quant_bert.py:148-155: ``q = Q_q(heads(query(x)), mask, 2)``, ``k^T = Q_k(heads(key(x)).transpose(-1, -2), mask, 3)``,
+    ``v = Q_v(heads(value(x)), mask, 2)``) as ONE launch when all three only fake-quantise (observers off, per tensor, no
+    gradient wanted) and the projections are contiguous [B, T, h*d] tensors of one shape.  Returns [q, k, v] as dense
+    [B, h, T, d] tensors (the caller transposes k), or None: the caller then runs the three sites one by one.  A site's
+    result depends on its own tensor and parameters only, so the order of the three calls does not matter; every site's
+    LSQ / LSQ+ parameter repair (fake_quant.py:188-191) rides in the launch as it does in the per-site form."""
+    if not FUSE_QKV:
+        return None
+    x0 = projections[0]
+    if x0.dim() != 3 or x0.shape[-1] % heads or (x0.shape[-1] // heads) % 4:
+        return None
+    params = []
+    for q, x in zip(quantizers, projections):
+        if not (_plain_quantizing(q, x) and x.is_contiguous() and x.shape == x0.shape and x.data_ptr() % 16 == 0):
+            return None
+        mode = q.param_mode
+        if isinstance(q, _LearnableFakeQuantize):
+            mode |= ops.PARAM_SANITIZE
+            q._touch_qparams()
+        params.append((q.scale.data, q.zero_point.data, q.quant_min, q.quant_max, mode,
+                       q._grad_factor(x) if q.param_mode != ops.PARAM_FIXED else 1.0))
+    return ops.fake_quant_headsplit_multi(list(projections), params, heads)

@@ -1532,3 +1532,54 @@ def test_reciprocal_division_of_the_mse_grid_is_the_ieee_division(dev):
             x = (x.view(torch.int32) + torch.randint(-2, 3, (n,), device=dev, generator=gen).int()).view(torch.float32)
         _hip.check(lib.osq_selftest_division(_hip.ptr(x), _hip.ptr(s), n, _hip.ptr(bad), _hip.stream_ptr(dev)), "selftest_division")
     assert int(bad.item()) == 0
+
+
+def test_qkv_headsplit_sites_in_one_launch(dev):
+    """ops.fake_quant_headsplit_multi / util_layernorm.qkv_heads_fake_quant: the query / key / value activation quantizers of a
+    self-attention block (quant_bert.py:148-155) as ONE launch -- torch.equal to the three per-site launches, parameter
+    repair of the learnable quantizers included (fake_quant.py:188-191), for Fixed / LSQ+ quantizers and BERT / BART
+    geometries; any state other than plain quantising hands the sites back to the per-site path."""
+    from outlier_suppression_amd import util_layernorm as UL
+    from outlier_suppression_amd.quantization import Quantizer
+    gen = torch.Generator().manual_seed(77)
+    for quantizer in ("LSQPlusFakeQuantize", "FixedFakeQuantize", "LSQFakeQuantize"):
+        for (B, T_, h, d) in ((32, 128, 12, 64), (4, 33, 3, 16), (2, 7, 16, 64), (3, 5, 2, 4)):
+            cfg = NS(quantizer=quantizer, observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+            qs = [Quantizer(None, cfg).to(dev) for _ in range(3)]
+            xs = [(torch.randn(B, T_, h * d, generator=gen) * (1.0 + i)).to(dev) for i in range(3)]
+            for i, q in enumerate(qs):
+                q.enable_fake_quant()
+                q.scale.data.fill_(0.05 * (i + 1) * (-1.0 if quantizer != "FixedFakeQuantize" and i == 1 else 1.0))   # a negative scale: the repair must run
+                q.zero_point.data.fill_(20 + 5 * i)
+            with torch.no_grad():
+                saved = [(q.scale.data.clone(), q.zero_point.data.clone()) for q in qs]
+                fused = UL.qkv_heads_fake_quant(qs, xs, h)
+                assert fused is not None, (quantizer, B, T_, h, d)
+                after = [(q.scale.data.clone(), q.zero_point.data.clone()) for q in qs]
+                for q, (s0, z0) in zip(qs, saved):
+                    q.scale.data.copy_(s0); q.zero_point.data.copy_(z0)
+                for i, (q, x) in enumerate(zip(qs, xs)):
+                    want = q(x.view(B, T_, h, d).permute(0, 2, 1, 3))
+                    assert fused[i].shape == (B, h, T_, d) and fused[i].is_contiguous()
+                    assert torch.equal(fused[i], want), (quantizer, i, B, T_, h, d)
+                    assert torch.equal(q.scale.data, after[i][0]) and torch.equal(q.zero_point.data, after[i][1])
+                    if quantizer != "FixedFakeQuantize":
+                        assert q.scale.item() > 0
+    # states the one launch does not take: observing, gradients wanted, another shape
+    cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
+    qs = [Quantizer(None, cfg).to(dev) for _ in range(3)]
+    xs = [torch.randn(2, 8, 64, device=dev) for _ in range(3)]
+    for q in qs:
+        q.enable_fake_quant()
+    assert UL.qkv_heads_fake_quant(qs, xs, 4) is None                     # autograd is on: learn-scale keeps the per-site path
+    with torch.no_grad():
+        assert UL.qkv_heads_fake_quant(qs, xs, 4) is not None
+        qs[1].enable_observer()
+        assert UL.qkv_heads_fake_quant(qs, xs, 4) is None
+        qs[1].disable_observer()
+        assert UL.qkv_heads_fake_quant(qs, [xs[0], xs[1][:, :4], xs[2]], 4) is None
+        UL.FUSE_QKV = False
+        try:
+            assert UL.qkv_heads_fake_quant(qs, xs, 4) is None
+        finally:
+            UL.FUSE_QKV = True

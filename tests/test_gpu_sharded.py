@@ -387,3 +387,29 @@ def test_bench_self_launch_eight_ranks_with_sharded_calibration():
     cal = out["calibration_config2"]
     assert "error" not in cal, cal
     assert cal["n_gpus"] == 8 and cal["wall_s"] > 0 and cal["collective_s"] >= 0, cal
+    # round 5: the collective's share per phase, and every rank ending the calibration with the same parameter bits
+    assert set(cal["collective_phases_s"]) >= {"twc_grid_search", "learn_scale"} and cal["collective_calls"] > 0, cal
+    assert cal["exchange_check"]["ranks"] == 8 and cal["exchange_check"]["same_bits_on_every_rank"], cal["exchange_check"]
+    summary = out["calibration_summary"]["configs"]["calibration_config2"]
+    assert summary["same_parameters_on_every_rank"] is True and summary["collective_s"] == cal["collective_s"], summary
+    # the probe regions that chose how the timed region is issued, as numbers
+    cfg = out["config"]
+    assert cfg["launch_picked"] in ("graph", "eager") and isinstance(cfg["probe_regions_us_per_step"], dict), cfg
+
+
+def test_bench_refuses_two_ranks_on_one_device():
+    """`bench.py --gpus N` all-gathers every rank's device identity (UUID / PCI address) and refuses to measure when N
+    ranks do not sit on N different GPUs -- the failure a mis-set LOCAL_RANK or visibility mask would otherwise turn into a
+    silently wrong scaling point.  Here: two gloo ranks on the one GPU of the box with the assertion left armed
+    (OSQ_BENCH_SHARE_GPU=check)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    env = dict(os.environ, OSQ_BENCH_SHARE_GPU="check")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--settle", "0.1",
+                        "--no-calib", "--no-kernel-table", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "one process per GPU is the contract" in r.stderr, r.stderr[-3000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no JSON line may come out of a refused run"

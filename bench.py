@@ -207,20 +207,6 @@ def kernel_table(dev, xs, lengths, reps=20):
                 "avg_us": round(us, 2), "bound": "hbm + one CU per side for the selection", "algorithmic_MB": round(nb / 1e6, 1),
                 "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBS, 3),
                 "note": "sum of the two launches' own durations; the kernel boundary between them (~1.7 us) is not in it"}
-        # ... and the same observation as the module issues it from its second batch on (ops.observe_tokens with a running
-        # statistic): ONE launch -- the streaming workgroups bin their tokens' |extrema| into a window histogram round the
-        # running statistic, the last workgroups to arrive finish (csrc/token_observe.h); the first batch (no statistic yet)
-        # takes the two launches above
-        for tag_, lens, nb in (("bench lengths", lengths, 4 * valid), ("all tokens", None, 4 * n)):
-            obs_mn, obs_mx = torch.tensor(float("inf"), device=dev), torch.tensor(float("-inf"), device=dev)
-            state = {"cnt": 0}
-
-            def observe_alone(i, lens=lens, state=state, obs_mn=obs_mn, obs_mx=obs_mx):
-                ops.observe_tokens(xs[i % len(xs)], 1, lens, True, PERCENTILE, ops.UPDATE_AVERAGE, state["cnt"], obs_mn, obs_mx, 0, 63, False)
-                state["cnt"] += 1
-            observe_alone(0)
-            add(f"observer alone, ONE launch (AvgPruneMinMax p=0.95 with a running statistic), {tag_}",
-                timed(_hip.TIME_OBSERVE_TOKENS, observe_alone), nb)
         # the default backward adds the two parameter gradients in float64 and rounds once (order-free); set_strict(backward=True)
         # adds autograd's four fp32 sums in ATen's one-thread order (bit-equal to the reference's CPU run, 1.3x slower)
         prev_order = ops.reference_sum_order("bwd")

@@ -275,8 +275,7 @@ template <bool NT>
 __device__ __forceinline__ float4 tok_load(const float4* p) { return NT ? load_stream(p) : *p; }
 
 // The per-token reduction of one wave: the extrema of its (up to) 4 tokens starting at `base`, NaN-poisoned, every
-// lane holding every token's result.  Shared by the stand-alone kernel below and the one-launch observation
-// (token_observe.h).
+// lane holding every token's result.
 template <bool SINGLE_SEGMENT, bool NT>
 __device__ __forceinline__ void token_extrema(const float* __restrict__ base, const osq_token_view& v, const int ntok,
                                               const int lgG, const int inner4, const int lane, MinMax (&acc)[kTokPerWave]) {
@@ -870,7 +869,6 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
 
 #include "token_select.h"   // two-workgroup fast path (one per side), used whenever its layout rules hold
 #include "fused_step.h"     // one persistent launch for observe + fake-quant of a dense [B, T, H] activation
-#include "token_observe.h"  // the per-token launch of a masked observation that also files the extrema into the bucketed window histogram
 
 namespace osq {
 
@@ -899,7 +897,6 @@ static int64_t g_wide_min_slots = 32769;
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
 static int g_obs_blocks = 768;
 static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
-static int g_observe_hist = 1;         // osq_set_tuning("observe_hist", 0|1|2|3): masked observations file their extrema into the bucketed window histogram while they stream (token_observe.h); 0 = the two plain launches, 2 = bucketed launches without a hint (every call falls back: tests), 3 = buckets filled but not used (tests)
 static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
 static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
@@ -1318,7 +1315,6 @@ bool set_observer_tuning(const char* key, int value) {
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
     if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
-    if (k == "observe_hist") { if (value < 0 || value > 3) return false; g_observe_hist = value; return true; }
     if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "select_hint") { g_select_hint = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
@@ -1504,7 +1500,7 @@ extern "C" int osq_token_range_finalize(const float* token_min, const float* tok
     const int64_t per_thread = (batch * tokens + kFinalThreads - 1) / kFinalThreads;
     const bool wide = batch * tokens >= g_wide_min_slots && workspace && (list_scratch || !prune);
     if (!wide && workspace && select_fast_ok(token_min, token_max, batch, tokens, 0, 1)) {
-        const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet(), g_select_shortcut, nullptr, 0};
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, prune, qf, Workspace(workspace).meet(), g_select_shortcut};
         launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr, 0}, 1);
         return check_launch("token_range_finalize(select)");
     }
@@ -1542,47 +1538,6 @@ extern "C" int osq_observe_tokens(const float* x, const osq_token_view* view, co
                                   float* scale_out, void* zero_point_out, int zp_type,
                                   void* workspace, void* list_scratch, osq_stream stream) {
     OSQ_REQUIRE(x && view && token_min && token_max, "observe_tokens: null pointer");
-    {
-        // Bucketed form (token_observe.h): the streaming launch files every token's extrema into the window histogram of
-        // the workspace, the selecting launch ranks from the buckets.  Needs the vector kernel's layout and what
-        // token_select_kernel needs; anything else is the two plain launches below.
-        const osq_token_view v = *view;
-        const bool vec = v.batch > 0 && v.tokens > 0 && v.feat_outer > 0 && v.feat_inner > 0 && v.stride_inner == 1 && v.feat_inner % 4 == 0 &&
-                         aligned16(x) && v.stride_batch % 4 == 0 && v.stride_token % 4 == 0 && (v.feat_outer == 1 || v.stride_outer % 4 == 0) &&
-                         v.feat_inner / 4 < (1 << 30);
-        const int64_t total = v.batch * v.tokens;
-        if (g_observe_hist && workspace && vec && total < g_wide_min_slots && v.batch <= 65535 &&
-            select_fast_ok(token_min, token_max, v.batch, v.tokens, 0, 1)) {
-            const char* why = "";
-            OSQ_REQUIRE(!prune || (percentile >= 0.0 && percentile <= 1.0), "observe_tokens: percentile outside [0, 1]");
-            OSQ_REQUIRE(check_finish_args(update_rule, min_val, max_val, &why), why);
-            const Finish fin{update_rule, cnt, min_val, max_val, cur_minmax, quant_min, quant_max, symmetric, scale_out, zero_point_out, zp_type};
-            const int inner4 = static_cast<int>(v.feat_inner / 4);
-            int lgG = 6;
-            if (v.feat_outer > 1) {
-                lgG = 0;
-                while ((1 << lgG) < inner4 && lgG < 6) ++lgG;
-            }
-            Workspace wsp(workspace);
-            TokObsState* hist = static_cast<TokObsState*>(wsp.tokobs());
-            const bool have_state = update_rule != OSQ_UPDATE_NONE && min_val && max_val;
-            const float* hmin = (have_state && g_observe_hist != 2) ? min_val : nullptr;
-            const float* hmax = (have_state && g_observe_hist != 2) ? max_val : nullptr;
-            hipStream_t st = static_cast<hipStream_t>(stream);
-            const dim3 tgrid(static_cast<unsigned>((v.tokens + kTokPerBlock - 1) / kTokPerBlock), static_cast<unsigned>(v.batch));
-            const TimingHook th = take_timing_hook(OSQ_TIME_TOKEN_MINMAX);
-#define OSQ_TOKH(SEG, NT) \
-    hipExtLaunchKernelGGL((token_minmax_hist_kernel<SEG, NT>), tgrid, dim3(kThreads), 0, st, th.start, th.stop, 0, x, v, lengths, \
-                          token_min, token_max, lgG, inner4, hist, prune ? 1 : 0, hmin, hmax)
-            if (v.feat_outer == 1) { if (g_tok_nt) OSQ_TOKH(true, true); else OSQ_TOKH(true, false); }
-            else { if (g_tok_nt) OSQ_TOKH(false, true); else OSQ_TOKH(false, false); }
-#undef OSQ_TOKH
-            const SelectArgs a{token_min, token_max, v.batch, v.tokens, lengths, prune ? 1 : 0, static_cast<float>(percentile), wsp.meet(),
-                               g_select_shortcut, hist, g_observe_hist == 3 ? 0 : 1};
-            launch_select(st, a, fin, FinalBatch{0, 0, 0, nullptr, 0}, 1);
-            return check_launch("observe_tokens(bucketed)");
-        }
-    }
     const int rc = osq_token_minmax(x, view, lengths, token_min, token_max, stream);
     if (rc != OSQ_OK) return rc;
     return osq_token_range_finalize(token_min, token_max, view->batch, view->tokens, lengths, prune, percentile,
@@ -1787,7 +1742,7 @@ extern "C" int osq_token_range_finalize_batched(const float* token_min, const fl
     const float qf = static_cast<float>(percentile);
     const int64_t problems = static_cast<int64_t>(n_quantizers) * n_batches;
     if (workspace && select_fast_ok(token_min, token_max, batch, tokens, problem_stride, problems)) {
-        const SelectArgs a{token_min, token_max, batch, tokens, lengths, 1, qf, Workspace(workspace).meet(), g_select_shortcut, nullptr, 0};
+        const SelectArgs a{token_min, token_max, batch, tokens, lengths, 1, qf, Workspace(workspace).meet(), g_select_shortcut};
         launch_select(st, a, fin, fb, problems);
         return check_launch("token_range_finalize_batched(select)");
     }

@@ -24,7 +24,6 @@ constexpr int kResidentMaxBlocks = 512;              // workgroups of the reside
 constexpr int kResidentMaxSites = 16;                // searches one multi-site launch can hold (one polling wave each)
 constexpr size_t kWsResidentBytes = 128 + 2 * static_cast<size_t>(kResidentMaxSites) * kResidentMaxBlocks * 2 * 8;   // its epoch / status words + two buffers of partial-sum granules per site
 
-constexpr size_t kWsTokObsBytes = 2 * 16384 * 4 + 2 * 16384 * 16 * 4 + 2 * 2 * 32 * 64 + 64;   // TokObsState of the bucketed masked observation (token_select.h / token_observe.h): per side 2^14 window counters + their 16-entry buckets, sharded above-the-window counters and plain maxima, flags
 
 void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning
@@ -67,7 +66,7 @@ static inline int check_launch(const char* what) {
 }
 
 // Caller-owned scratch: [8 x 4 KiB of ticket counters][8 x 64 KiB of partials][16 KiB + 64 B wide-finaliser state]
-// [64 KiB rendezvous words][2 KiB state of the fused observe + fake-quant launch][256.1 KiB state of the resident MSEFast search][2.1 MiB bucketed window histogram of the masked observation].  Counters are zero between
+// [64 KiB rendezvous words][2 KiB state of the fused observe + fake-quant launch][256.1 KiB state of the resident MSEFast search].  Counters are zero between
 // launches (each kernel's last workgroup resets the one it used).
 struct Workspace {
     char* base;
@@ -81,7 +80,6 @@ struct Workspace {
     }
     void* fused() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes; }
     void* resident() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes + kWsFusedBytes; }
-    void* tokobs() const { return base + kWsHeaderBytes + kWsScratchBytes + kWsWideBytes + kWsMeetBytes + kWsFusedBytes + kWsResidentBytes; }
 };
 
 }  // namespace osq

@@ -27,31 +27,6 @@ namespace osq {
 constexpr int kSelThreads = 1024;
 constexpr int kSelWaves = kSelThreads / OSQ_WAVE;
 
-// ---- the first histogram level built by the STREAMING launch (token_observe.h, round 5) ------------------------------
-// The per-token kernel of a masked observation (token_minmax_hist_kernel) bins every token's |extremum| as it is reduced:
-// a window of 2^14 bins round the observer's running statistic, hint * [1/2, 3/2] (HINT below), one device-scope
-// returning atomic per token and side on the bin's counter, and the value itself into slot `old count` of the bin's
-// 16-entry bucket.  Keys above the window are counted (sharded counters); keys below it follow from the number of valid
-// tokens.  The selecting workgroup then needs no pass over the 32768 token extrema: scan the side's counters for the
-// bin that holds the wanted rank, load that bin's <= 16 values (and the next non-empty bin's when rank + 1 leaves the
-// bin), rank them by counting in one wave, interpolate, apply the threshold rule (select_from_buckets).  Exactness
-// never depends on the hint or the capacity: whenever the window misses the rank, the bin is fuller than its bucket,
-// or the sign facts do not decide the threshold rule, the workgroup runs the full selection from the token arrays
-// (select_side) as before -- the streaming launch always writes them.
-constexpr int kBkBits = 14;
-constexpr int kBkBins = 1 << kBkBits;
-constexpr int kBkCap = 16;
-constexpr int kBkShards = 32;
-
-struct TokObsState {                          // slice of the caller's workspace; counters ALL-ZERO between launches
-    unsigned int count[2][kBkBins];           // side 0: token_max, side 1: -token_min
-    unsigned int entry[2][kBkBins][kBkCap];   // the first kBkCap values (sign kept) that arrived in each bin
-    unsigned int above[2][kBkShards][16];     // keys above the window, sharded by workgroup, one 64-byte line each
-    unsigned int plain[2][kBkShards][16];     // no pruning: ordered bits of the plain maxima (0 = nothing yet)
-    unsigned int bad, pad[15];                // a NaN among the valid tokens
-};
-static_assert(sizeof(TokObsState) == kWsTokObsBytes, "TokObsState must fill its slice of the workspace");
-
 struct SelectArgs {
     const float* tok_min;
     const float* tok_max;
@@ -61,8 +36,6 @@ struct SelectArgs {
     float q;
     unsigned long long* meet;     // one rendezvous word per problem, zero when idle
     int shortcut;                 // 0: always run the threshold pass over the registers (tests)
-    TokObsState* hist;            // non-null: the streaming launch classified this batch's extrema (single problem only)
-    int use_buckets;              // 0: read and reset the state, then run the full selection all the same (tests)
 };
 
 #ifdef OSQ_FINAL_TIMING
@@ -129,16 +102,6 @@ __device__ __forceinline__ SelWindow hint_window(const float hint, const int pru
         w.lo = __float_as_uint(hint * 0.5f);
         w.wd = __float_as_uint(hint * 1.5f) - w.lo + 1u;     // 1.5 octaves of keys: 1536 bins of 8192 keys
         w.sh = level_shift(w.wd);
-    }
-    return w;
-}
-
-// The same window in 2^14 bins (1.5 octaves of keys: 12288 bins of 1024 keys) for the bucketed level of token_observe.h.
-__device__ __forceinline__ SelWindow bucket_window(const float hint, const int prune) {
-    SelWindow w = hint_window(hint, prune);
-    if (w.on) {
-        const unsigned int bits = w.wd <= 1u ? 0u : 32u - __builtin_clz(w.wd - 1u);
-        w.sh = bits > static_cast<unsigned int>(kBkBits) ? bits - kBkBits : 0u;
     }
     return w;
 }
@@ -498,152 +461,6 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
 }
 
 
-// One side's statistic from what the streaming launch left in `st` (see the top of this file); true = *out holds it.
-// Called by all kSelThreads threads; every thread gets the same answer.  Whatever the outcome, the side's counters are
-// read once and put back to zero.
-__device__ __forceinline__ bool select_from_buckets(TokObsState* st, const int side, const int64_t aB, const int64_t aT,
-                                                    const int64_t* lengths, const int prune, const float aq, const int use_shortcut,
-                                                    const int use_buckets, const float hint, SelShared& S, SideResult* out) {
-    constexpr int BPT = kBkBins / kSelThreads;           // 16 counters per thread
-    const int tid = threadIdx.x, lane = tid & (OSQ_WAVE - 1), wv = tid / OSQ_WAVE;
-    const SelWindow win = bucket_window(hint, prune);
-    // ---- everything this side needs, in one round of loads: its counters (then zeroed), the shards, the NaN flag, N
-    unsigned int h[BPT], tot = 0u;
-    {
-        uint4* cp = reinterpret_cast<uint4*>(&st->count[side][tid * BPT]);
-#pragma unroll
-        for (int j = 0; j < BPT; j += 4) {
-            const uint4 c = cp[j / 4];
-            h[j] = c.x; h[j + 1] = c.y; h[j + 2] = c.z; h[j + 3] = c.w;
-        }
-#pragma unroll
-        for (int j = 0; j < BPT; j += 4) cp[j / 4] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    unsigned int ab = 0u, pl = 0u, n = 0u;
-    if (tid < kBkShards) {
-        ab = st->above[side][tid][0];
-        pl = st->plain[side][tid][0];
-        st->above[side][tid][0] = 0u;
-        st->plain[side][tid][0] = 0u;
-    }
-    const unsigned int bad_flag = st->bad;               // uniform address: every thread reads the same word
-    for (int64_t b = tid; b < aB; b += kSelThreads) {
-        int64_t l = lengths ? lengths[b] : aT;
-        l = l < 0 ? 0 : (l > aT ? aT : l);
-        n += static_cast<unsigned int>(l);
-    }
-#pragma unroll
-    for (int j = 0; j < BPT; ++j) tot += h[j];
-    const unsigned int incl_w = wave_inclusive_scan_u32(tot);
-    n = wave_inclusive_scan_u32(n);
-    ab = wave_inclusive_scan_u32(ab);
-    pl = wave_max_u32(pl);
-    if (lane == OSQ_WAVE - 1) { S.s_wtot[wv] = incl_w; S.w_n[wv] = n; S.w_below[wv] = ab; }
-    if (tid == 0) { S.w_plain[0] = pl; S.s_next = 0xffffffffu; }      // wave 0 holds all 32 shards
-    lds_barrier();
-    unsigned int base = 0u, inside = 0u, N = 0u, above = 0u;
-#pragma unroll
-    for (int k = 0; k < kSelWaves; k += 4) {
-        const uint4 t4 = *reinterpret_cast<const uint4*>(&S.s_wtot[k]), n4 = *reinterpret_cast<const uint4*>(&S.w_n[k]);
-        const uint4 a4 = *reinterpret_cast<const uint4*>(&S.w_below[k]);
-        const unsigned int t[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { base += (k + e < wv) ? t[e] : 0u; inside += t[e]; }
-        N += n4.x + n4.y + n4.z + n4.w;
-        above += a4.x + a4.y + a4.z + a4.w;
-    }
-    inside = uniform(inside);
-    N = uniform(N);
-    above = uniform(above);
-    if (N == 0u) { *out = SideResult{0.0f, false, true}; return true; }
-    if (uniform(bad_flag) != 0u) { *out = SideResult{0.0f, true, false}; return true; }     // poisons the statistic: no selection
-    if (!prune) { *out = SideResult{from_ordered_bits(uniform(S.w_plain[0])), false, false}; return true; }
-    if (!win.on || !use_buckets) return false;
-    const unsigned int counted = inside + above;
-    if (counted > N) return false;
-    const unsigned int n_below = N - counted;
-    const float rank = aq * static_cast<float>(N - 1u);
-    const float rlo = floorf(rank);
-    const unsigned int k_lo = static_cast<unsigned int>(rlo), k_hi = static_cast<unsigned int>(ceilf(rank));
-    const float w = rank - rlo;
-    if (n_below > k_lo || k_lo - n_below >= inside) return false;        // the wanted rank lies outside the window
-    const unsigned int r = k_lo - n_below;
-    // ---- the bin that holds rank r of the window (exactly one thread owns it)
-    const unsigned int incl = base + incl_w, excl = incl - tot;
-    if (r >= excl && r < incl) {
-        unsigned int run = excl, bin = 0u, cnt = 0u, below_b = 0u;
-        bool found = false;
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            if (!found && r < run + h[j]) { found = true; bin = static_cast<unsigned int>(tid * BPT + j); below_b = run; cnt = h[j]; }
-            run += h[j];
-        }
-        uint4 pk;
-        pk.x = bin; pk.y = below_b; pk.z = cnt; pk.w = 0u;
-        *reinterpret_cast<uint4*>(&S.pick[0]) = pk;
-    }
-    lds_barrier();
-    const uint4 pk = *reinterpret_cast<const uint4*>(&S.pick[0]);
-    const unsigned int bin0 = uniform(pk.x), cnt0 = uniform(pk.z), r_in = r - uniform(pk.y);
-    if (cnt0 > static_cast<unsigned int>(kBkCap)) return false;          // fuller than its bucket
-    const bool need_next = (k_hi != k_lo) && (r_in + 1u >= cnt0);
-    unsigned int bin1 = 0u, cnt1 = 0u;
-    if (need_next) {
-        // the next non-empty bin and its count, packed so that one minimum finds both
-        unsigned int cand = 0xffffffffu;
-#pragma unroll
-        for (int j = BPT - 1; j >= 0; --j) {
-            const unsigned int bj = static_cast<unsigned int>(tid * BPT + j);
-            if (h[j] != 0u && bj > bin0) cand = (bj << 8) | (h[j] < 255u ? h[j] : 255u);
-        }
-        cand = wave_min_u32(cand);
-        if (lane == 0 && cand != 0xffffffffu) atomicMin(&S.s_next, cand);
-        lds_barrier();
-        const unsigned int nb = S.s_next;
-        if (nb == 0xffffffffu) return false;                             // rank + 1 lies above the window
-        bin1 = nb >> 8;
-        cnt1 = nb & 255u;
-        if (cnt1 > static_cast<unsigned int>(kBkCap)) return false;
-    }
-    // ---- wave 0: the bin's values, ranked by counting; the two order statistics and their sign facts
-    if (wv == 0) {
-        const unsigned int e = static_cast<unsigned int>(lane) < cnt0 ? st->entry[side][bin0][lane & (kBkCap - 1)] : 0xffffffffu;
-        unsigned int e1 = 0xffffffffu;
-        if (need_next && static_cast<unsigned int>(lane) < cnt1) e1 = st->entry[side][bin1][lane & (kBkCap - 1)] & 0x7fffffffu;
-        const unsigned int key = e & 0x7fffffffu;
-        const bool have = static_cast<unsigned int>(lane) < cnt0;
-        unsigned int lt = 0u, le = 0u;
-#pragma unroll
-        for (int j = 0; j < kBkCap; ++j) {
-            const unsigned int o = lane_value_u32(key, j);
-            const bool in = static_cast<unsigned int>(j) < cnt0;
-            lt += (in && o < key) ? 1u : 0u;
-            le += (in && o <= key) ? 1u : 0u;
-        }
-        const bool at_lo = have && lt <= r_in && r_in < le, at_hi = have && lt <= r_in + 1u && r_in + 1u < le;
-        const unsigned long long m_lo = __ballot(at_lo), m_hi = __ballot(at_hi);
-        const unsigned int v_lo = lane_value_u32(key, __builtin_ctzll(m_lo | (1ull << 63)));
-        const bool hi_listed = m_hi != 0ull;
-        unsigned int v_hi = hi_listed ? lane_value_u32(key, __builtin_ctzll(m_hi | (1ull << 63))) : wave_min_u32(e1);
-        if (k_hi == k_lo) v_hi = v_lo;
-        const bool pos_lo = __ballot(at_lo && !(e >> 31)) != 0ull, pos_hi = __ballot(at_hi && !(e >> 31)) != 0ull;
-        // the threshold rule through the sign facts (select_from_registers, "Shortcut"); otherwise the full selection decides
-        const float lo_f = __uint_as_float(v_lo), hi_f = __uint_as_float(v_hi);
-        const float d = hi_f - lo_f;
-        const float t = (w < 0.5f) ? __builtin_fmaf(w, d, lo_f) : __builtin_fmaf(w - 1.0f, d, hi_f);
-        const bool reaches_hi = hi_f > lo_f && t >= hi_f;
-        const bool ok = use_shortcut && m_lo != 0ull && pos_lo && (!reaches_hi || hi_listed);
-        if (lane == 0) {
-            S.pick[0] = ok ? 1u : 0u;
-            S.pick[1] = __float_as_uint((reaches_hi && pos_hi) ? hi_f : lo_f);
-        }
-    }
-    lds_barrier();
-    if (uniform(S.pick[0]) == 0u) return false;
-    *out = SideResult{__uint_as_float(uniform(S.pick[1])), false, false};
-    return true;
-}
-
 // select_side: one side's statistic of a token array in memory (slots b*T + t, valid iff t < lengths[b]; the arrays
 // were written by an earlier launch: plain loads), computed by the calling 1024-thread workgroup; every thread gets
 // the result.  R4 = 16-byte groups per thread; group g = tid + 1024*j covers slots 4g .. 4g+3.
@@ -799,22 +616,12 @@ __global__ __launch_bounds__(kSelThreads) void token_select_kernel(SelectArgs a,
 #else
     long long* stamps = nullptr;
 #endif
-    SideResult r;
-    bool from_buckets = false;
-    if (a.hist) {                              // the streaming launch classified the extrema (token_observe.h)
-        float hint = __builtin_nanf("");
-        if (have_state) hint = __builtin_fabsf(side ? fin.min_val[0] : fin.max_val[0]);     // the statistic as it stands before this batch
-        from_buckets = select_from_buckets(a.hist, side, a.B, a.T, lengths, prune, a.q, a.shortcut, a.use_buckets, hint, S, &r);
-        if (!from_buckets) lds_barrier();      // S is reused by the full selection
-    }
-    if (!from_buckets) r = select_side<R4>(src, side, a.B, a.T, lengths, prune, a.q, a.shortcut, S, stamps);
+    const SideResult r = select_side<R4>(src, side, a.B, a.T, lengths, prune, a.q, a.shortcut, S, stamps);
     if (r.empty) return;                       // nothing observed, nothing updated
     if (threadIdx.x == 0) {
         float cur_min, cur_max;
-        if (meet_sides(&a.meet[p], side, r, &cur_min, &cur_max)) {
+        if (meet_sides(&a.meet[p], side, r, &cur_min, &cur_max))
             finish_entry(fin, 0, cur_min, cur_max, have_state, st_min, st_max);
-            if (a.hist) a.hist->bad = 0u;      // both sides have read it
-        }
     }
 #ifdef OSQ_FINAL_TIMING
     OSQ_SSTAMP(6);

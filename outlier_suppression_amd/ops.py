@@ -727,11 +727,12 @@ def _msefast_tensor_run_ordered(r, chunk, two_d):
 
 
 ORDERED_GROUP_SITES = 128     # searches one table of osq_msefast_ordered_multi_* holds
-# Bytes of site data one group of rounds may sweep.  Every round reads every unfinished site of its group once, and a
-# search is 15-500 rounds: a group that fits the 256 MiB Infinity Cache is served from it from its second round on, a
-# forward's worth of sites (BERT-base [32,128]: 0.57 GB) re-streams from HBM every round (profiles/r04_calibration_config3:
-# 3.4 TB/s).  Masked sites count with all their slots (the valid share is only known on the device).  0 = no bound.
-ORDERED_GROUP_BYTES = int(os.environ.get("OSQ_MSE_GROUP_MIB", "192")) << 20
+# Bytes of site data (and of gathered copies of masked sites, alive together) one group of rounds may hold: a MEMORY bound,
+# not a speed knob -- a group runs its own ~600 rounds, so splitting a forward's searches multiplies the launches, and a
+# round's cost is dominated by its ~14 000 workgroups' start-up, not by where the bytes come from (measured: groups that fit
+# the 256 MiB Infinity Cache are 1.4-2.6x SLOWER than one group, profiles/r05_mse_group_ab.txt).  Masked sites count with all
+# their slots (the valid share is only known on the device).  BERT-base [32,128]: 0.57 GB, one group.  0 = no bound.
+ORDERED_GROUP_BYTES = int(os.environ.get("OSQ_MSE_GROUP_MIB", "2048")) << 20
 
 
 def msefast_ordered_groups(searches, two_d):

@@ -525,6 +525,7 @@ def test_fused_residual_layernorm_fake_quant(dev):
         xs, hs = torch.randn(5, 9, 64, generator=gen).to(dev), torch.randn(5, 9, 64, generator=gen).to(dev)
         L = torch.tensor([9, 3, 1, 9, 5], device=dev)
         outs = {}
+        fuse_default = UL.FUSE_LAYERNORM
         for fuse in (True, False):
             UL.FUSE_LAYERNORM = fuse
             try:
@@ -537,7 +538,7 @@ def test_fused_residual_layernorm_fake_quant(dev):
                     y_q = UL.residual_layernorm(res, mod, xs, hs, L)
                     outs[fuse] = (y_obs.clone(), y_q.clone(), q.scale.item(), q.zero_point.item())
             finally:
-                UL.FUSE_LAYERNORM = False
+                UL.FUSE_LAYERNORM = fuse_default
         assert (outs[True][0] - outs[False][0]).abs().max().item() < 4e-6 * max(1.0, outs[False][0].abs().max().item())
         assert outs[True][2] > 0 and abs(outs[True][2] - outs[False][2]) < 1e-6 * outs[False][2]
         assert (outs[True][1] - outs[False][1]).abs().max().item() <= outs[False][2] * 1.001   # at most one step, at ties

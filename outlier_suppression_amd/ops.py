@@ -735,39 +735,58 @@ ORDERED_GROUP_SITES = 128     # searches one table of osq_msefast_ordered_multi_
 ORDERED_GROUP_BYTES = int(os.environ.get("OSQ_MSE_GROUP_MIB", "2048")) << 20
 
 
+ORDERED_STREAMS = max(1, int(os.environ.get("OSQ_MSE_STREAMS", "2")))     # concurrent groups of nested searches (see msefast_ordered_groups)
+
+
 def msefast_ordered_groups(searches, two_d):
-    """Partition the searches of a flush into the groups whose rounds run together: nested (2-D) searches first, in
-    forward order, then the 1-D ones (a 1-D search ends after ~20 rounds, a nested one after hundreds -- apart, the
-    short ones do not sit in the long ones' tables), each group bounded by ORDERED_GROUP_SITES and ORDERED_GROUP_BYTES.
-    Grouping never changes a result: every search's evaluations are its own (tests/test_gpu_strict_order.py)."""
+    """Partition the searches of a flush into the groups whose rounds run together.
+
+    A round is one launch = one loss evaluation of every unfinished search of its group.  Rounds of DIFFERENT groups are
+    independent, so the groups run on separate streams (msefast_tensor_run_ordered_groups): the short 1-D searches (~20
+    rounds: attention probabilities, one-sided) no longer sit in the tables of the nested ones (hundreds of rounds), and
+    one group's ramp and tail are filled by the other's workgroups.  Measured on BASELINE configs[3]: 1.06 s with one
+    table per forward -> 0.98-1.03 s with the 1-D searches on their own stream and the nested ones dealt into 1-6 groups
+    (the number of groups does not matter beyond that: a round is bound by its float64 arithmetic and its loads, not by
+    launch overhead -- profiles/r05_mse_streams_ab.txt).  Hence: the nested (2-D) searches are dealt into ORDERED_STREAMS
+    groups of about equal bytes (largest first onto the lightest group), the 1-D searches form one more group; every group
+    is bounded by ORDERED_GROUP_SITES and ORDERED_GROUP_BYTES.  Grouping never changes a result: every search's
+    evaluations are its own (tests/test_gpu_strict_order.py)."""
     groups = []
-    for kind in (True, False):
+    nested = [r for r, nd in zip(searches, two_d) if nd]
+    flat = [r for r, nd in zip(searches, two_d) if not nd]
+    if nested:
+        k = min(ORDERED_STREAMS, len(nested))
+        lanes, load = [[] for _ in range(k)], [0] * k
+        for r in sorted(nested, key=lambda r: -int(r.elems)):            # stable: equal sizes keep their forward order
+            i = load.index(min(load))
+            lanes[i].append(r)
+            load[i] += int(r.elems)
+        groups += [g for g in lanes if g]
+    if flat:
+        groups.append(flat)
+    out = []
+    for g in groups:                                                      # the table's and the memory bound's limits
         cur, used = [], 0
-        for r, nested in zip(searches, two_d):
-            if bool(nested) != kind:
-                continue
+        for r in g:
             nbytes = 4 * int(r.elems)
             if cur and (len(cur) == ORDERED_GROUP_SITES or (ORDERED_GROUP_BYTES and used + nbytes > ORDERED_GROUP_BYTES)):
-                groups.append(cur)
+                out.append(cur)
                 cur, used = [], 0
             cur.append(r)
             used += nbytes
         if cur:
-            groups.append(cur)
-    return groups
+            out.append(cur)
+    return out
 
 
-def msefast_tensor_run_ordered_group(group, chunk=64):
-    """The strict form of several searches (MseSearch records of one device, e.g. the MSEFast observers of one forward):
-    rounds of ONE launch = one loss evaluation of every unfinished search, each sum in the order of torch.sum on a
-    one-thread host (csrc/aten_order.h, osq_msefast_ordered_multi_*).  Same numbers as _msefast_tensor_run_ordered
-    search by search (tests/test_gpu_strict_order.py)."""
+def _ordered_group_prepare(group):
+    """Lay out the masked sites of a group (remove_padding order), build the group's table; on the CURRENT stream."""
     lib = _hip.load()
     n_sites = len(group)
     assert 0 < n_sites <= ORDERED_GROUP_SITES
     dev = group[0].x.device
     st = _hip.stream_ptr(dev)
-    flats, ns, n_devs, keep = [], [], [], []
+    flats, ns, n_devs = [], [], []
     for r in group:
         if r.view is None:
             flats.append(r.x)
@@ -801,14 +820,71 @@ def msefast_tensor_run_ordered_group(group, chunk=64):
     _hip.check(lib.osq_msefast_ordered_multi_prepare(_hip.ptr(table), table_bytes, states, xs, n_arr, nd_arr, sc_arr, sb_arr, n_sites,
                                                      ctypes.byref(blocks), st), "msefast_ordered_multi_prepare")
     done = torch.zeros(1, dtype=torch.int32, device=dev)
-    launched = 0
+    return {"table": table, "n_sites": n_sites, "blocks": blocks.value, "done": done, "keep": (flats, n_devs, scratch, group), "launched": 0}
+
+
+def _ordered_group_rounds(ctx, chunk):
+    """Enqueue `chunk` rounds of a prepared group and its all-done check on the CURRENT stream (nothing waits)."""
+    lib = _hip.load()
+    dev = ctx["table"].device
+    _hip.check(lib.osq_msefast_ordered_multi_evals(_hip.ptr(ctx["table"]), ctx["n_sites"], ctx["blocks"], chunk, _hip.ptr(ctx["done"]),
+                                                   _hip.stream_ptr(dev)), "msefast_ordered_multi_evals")
+    ctx["launched"] += chunk
+
+
+def msefast_tensor_run_ordered_group(group, chunk=64):
+    """The strict form of several searches (MseSearch records of one device, e.g. the MSEFast observers of one forward):
+    rounds of ONE launch = one loss evaluation of every unfinished search, each sum in the order of torch.sum on a
+    one-thread host (csrc/aten_order.h, osq_msefast_ordered_multi_*).  Same numbers as _msefast_tensor_run_ordered
+    search by search (tests/test_gpu_strict_order.py)."""
+    ctx = _ordered_group_prepare(group)
     while True:
-        _hip.check(lib.osq_msefast_ordered_multi_evals(_hip.ptr(table), n_sites, blocks.value, chunk, _hip.ptr(done), st),
-                   "msefast_ordered_multi_evals")
-        launched += chunk
-        if int(done.item()) or launched > 500 * 500:
+        _ordered_group_rounds(ctx, chunk)
+        if int(ctx["done"].item()) or ctx["launched"] > 500 * 500:
             break
-    return launched
+    return ctx["launched"]
+
+
+_side_streams = {}
+
+
+def msefast_tensor_run_ordered_groups(groups, chunk=64):
+    """Several groups of strict searches CONCURRENTLY, one stream each (see msefast_ordered_groups for why): the side streams
+    start behind everything the caller's stream has been given, the caller's stream continues behind all of them.  The
+    records of `groups` must stay referenced by the caller until then (they are: the flush commits them afterwards)."""
+    groups = [g for g in groups if g]
+    if not groups:
+        return 0
+    if len(groups) == 1:
+        return msefast_tensor_run_ordered_group(groups[0], chunk)
+    dev = groups[0][0].x.device
+    main = torch.cuda.current_stream(dev)
+    start = torch.cuda.Event()
+    start.record(main)
+    runs = []
+    for i, g in enumerate(groups):
+        key = (_hip._device_index(dev), i)
+        s = _side_streams.get(key)
+        if s is None:
+            s = _side_streams[key] = torch.cuda.Stream(device=dev)
+        s.wait_event(start)
+        with torch.cuda.stream(s):
+            runs.append((s, _ordered_group_prepare(g)))
+    pending = list(runs)
+    while pending:
+        for s, ctx in pending:                   # every unfinished group gets its next rounds before anybody waits
+            with torch.cuda.stream(s):
+                _ordered_group_rounds(ctx, chunk)
+        still = []
+        for s, ctx in pending:
+            with torch.cuda.stream(s):
+                finished = int(ctx["done"].item())
+            if not finished and ctx["launched"] <= 500 * 500:
+                still.append((s, ctx))
+        pending = still
+    for s, _ in runs:
+        main.wait_stream(s)
+    return sum(ctx["launched"] for _, ctx in runs)
 
 
 def msefast_tensor_run_group(group):

@@ -46,9 +46,9 @@ class DeferredSites:
         if ops.reference_sum_order("mse"):
             # strict sums: one launch per ROUND of loss evaluations of all the forward's searches (128 per table)
             fit = [it for it in pending if ops.msefast_ordered_fits(it[1])]
-            for group in ops.msefast_ordered_groups([it[1] for it in fit], [it[2] for it in fit]):
-                ops.msefast_tensor_run_ordered_group(group)
-                self.launches += 1
+            groups = ops.msefast_ordered_groups([it[1] for it in fit], [it[2] for it in fit])
+            ops.msefast_tensor_run_ordered_groups(groups)          # concurrent: one stream per group
+            self.launches += len(groups)
             for it in pending:
                 if not ops.msefast_ordered_fits(it[1]):              # beyond the ordered kernels' capacity (> 134 M elements)
                     ops.msefast_tensor_run(it[1], None, it[2])

@@ -266,6 +266,28 @@ __device__ __forceinline__ double sq_err_f64_rcp(float xf, double s, double y, d
     const double d = fabs(yv - x);
     return d * d;
 }
+// LEAN form of the same term (round 5; profiles/r05_mse_rounds_pmc.txt: a round's VALU pipes are busy 62 % of its time, 15
+// float64 operations per element at 4 clocks each).  Only the INTEGER LEVEL depends on the quotient: q - z =
+// clamp(rint(x / s), qmin - z, qmax - z) for an integer z (exact small-integer arithmetic in the reference's float64 chain
+// too).  The level is taken from an fp32 quotient u32 = x * RN32(1 / s), whose relative error is below 2^-23: for |u| <= 513
+// (the levels lie within +-512, checked by the caller) it is within 6.2e-5 of the float64 quotient, so rint agrees unless u32
+// lies within 5e-4 of a tie -- those elements (one in a thousand) take the exact float64 chain above; beyond the clamp range
+// either rounding saturates to the same level (+-inf included).  The dequantised value, the difference and the square are
+// the reference's float64 operations: c * s, - x, squared ((-d)^2 = d^2 exactly).  6 fp32 + 6 float64 operations instead of 15.
+__device__ __forceinline__ double sq_err_f64_lean(float xf, double s, double y, float y32, float lo32, float hi32, double z, double qmin,
+                                                  double qmax) {
+    const float u = xf * y32;
+    const float r = rintf(u);
+    if (fabsf(u - r) >= 0.4995f) return sq_err_f64_rcp(xf, s, y, z, qmin, qmax);      // false for NaN (u = +-inf): saturates below
+    const float c = fminf(fmaxf(r, lo32), hi32);
+    const double d = static_cast<double>(c) * s - static_cast<double>(xf);
+    return d * d;
+}
+// uniform: may the lean form stand in for sq_err_f64_rcp?  (z an integer, levels within +-512 of it; the caller has checked
+// rcp_division_exact: finite data, a scale in [1e-9, 1e38])
+__device__ __forceinline__ bool lean_level_exact(float z, float qmin, float qmax) {
+    return z == rintf(z) && fabsf(qmin - z) <= 512.0f && fabsf(qmax - z) <= 512.0f && qmin <= qmax;
+}
 __device__ __forceinline__ double sq_err4_f64_rcp(const float4& a, double s, double y, double z, double qmin, double qmax) {
     return (sq_err_f64_rcp(a.x, s, y, z, qmin, qmax) + sq_err_f64_rcp(a.y, s, y, z, qmin, qmax)) +
            (sq_err_f64_rcp(a.z, s, y, z, qmin, qmax) + sq_err_f64_rcp(a.w, s, y, z, qmin, qmax));
@@ -624,8 +646,10 @@ constexpr int kOrdThreads = 512;
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
 // one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
 __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, const int64_t n, TensorSearch* __restrict__ ts,
-                                                   void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W,
+                                                   void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W_and_flags,
                                                    const unsigned int bid, const unsigned int nblk, double* lds_raw) {
+    const int W = W_and_flags & 0xff;                             // 8 | 16; bit 8: the lean float64 term (osq_set_tuning("mse_lean"))
+    const bool lean_ok = (W_and_flags >> 8) & 1;
     // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
@@ -639,8 +663,11 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         // sq_err_f64_rcp) whenever its two conditions hold -- a uniform branch, the division out of line
         const double rcp = 1.0 / sd;
         const bool fast = rcp_division_exact(sd, x_min, x_max);
+        const bool lean = fast && lean_ok && lean_level_exact(z, qmin, qmax);
+        const float rcp32 = static_cast<float>(rcp), lo32 = qmin - z, hi32 = qmax - z;
         auto term = [=](int64_t e, double (&t)[1]) {
-            if (fast) t[0] = sq_err_f64_rcp(x[e], sd, rcp, z, qmin, qmax);
+            if (lean) t[0] = sq_err_f64_lean(x[e], sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
+            else if (fast) t[0] = sq_err_f64_rcp(x[e], sd, rcp, z, qmin, qmax);
             else t[0] = sq_err_f64_outofline(x[e], sd, z, qmin, qmax);
         };
         double* part = static_cast<double*>(scratch);
@@ -648,7 +675,10 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
             // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
             auto load = [=](int64_t e) { return x[e]; };
-            auto eval = [=](float xf, int64_t, double (&t)[1]) { t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax); };
+            auto eval = [=](float xf, int64_t, double (&t)[1]) {
+                if (lean) t[0] = sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
+                else t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax);
+            };
             if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             if (bid == nblk - 1) cascade_units<double, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
@@ -930,6 +960,7 @@ constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
 static int g_mse_rows_order = 8;                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
+static int g_mse_lean = 1;                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
 static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
@@ -1571,7 +1602,7 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     const int grid = static_cast<int>(std::min<int64_t>(g.chunks + 1, kMaxBlocks));
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreads), 0, st, x_flat, n, n_device,
-                           static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order);
+                           static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order | (g_mse_lean ? 256 : 0));
     return check_launch("msefast_tensor_evals_ordered");
 }
 
@@ -1639,7 +1670,7 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
     const unsigned char* block_site = static_cast<const unsigned char*>(table) + static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites,
-                           g_mse_sum_order);
+                           g_mse_sum_order | (g_mse_lean ? 256 : 0));
     if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
     return check_launch("msefast_ordered_multi_evals");
 }
@@ -1652,6 +1683,7 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
+    if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }

@@ -362,3 +362,46 @@ def test_backward_on_a_dense_permuted_input_follows_memory_order(dev, strict):
         assert dx.stride() == x.stride()
         assert np.array_equal(N(dx.permute(0, 3, 1, 2).contiguous()).reshape(-1), rdx.reshape(-1)), (B, T, h, d)
         assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (B, T, h, d, ds.item(), rds, dz.item(), rdz)
+
+
+def test_lean_float64_term_equals_the_full_chain(dev, strict):
+    """csrc/msefast.hip, sq_err_f64_lean (round 5): from a site's second call on the reference-order evaluations take the
+    integer level from a guarded fp32 quotient (6 fp32 + 6 float64 operations per element instead of 15 float64 ones); an
+    element within 5e-4 of a rounding tie takes the exact float64 chain.  osq_set_tuning("mse_lean", 0) runs the full chain
+    everywhere: statistics and evaluation counts of every batch must be EQUAL -- on ordinary activations and on data built
+    to sit on and next to the ties of plausible candidate scales, far outside the clamp range, tiny, and of mixed sign."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+    g = torch.Generator().manual_seed(505)
+    cases = []
+    base = torch.randn(8, 64, 96, generator=g)
+    base[..., 5] *= 15
+    cases.append([base, base * 1.1 + 0.01, base * 0.9])
+    # values on a lattice of half-steps of scales the search is likely to visit, with offsets of a few ulps to either side
+    lattice = (torch.arange(-40, 41, dtype=torch.float32)[None, :] + 0.5) * torch.tensor([0.05, 0.0625, 0.1, 0.3])[:, None]
+    ulps = torch.tensor([0.0, 1e-7, -1e-7, 3e-4, -3e-4, 6e-4, -6e-4])
+    tie = (lattice.reshape(-1, 1) * (1.0 + ulps[None, :])).reshape(-1)
+    tie = torch.cat([tie, torch.tensor([0.0, -0.0, 1e-30, -1e-30, 3e4, -3e4, 1e-3, 77.7])])
+    pad = torch.randn(4 * 32 * 64 - tie.numel(), generator=g) * 2
+    adv = torch.cat([tie, pad])[torch.randperm(4 * 32 * 64, generator=g)].reshape(4, 32, 64)
+    cases.append([adv, adv.flip(0), adv * 1.003])
+    cases.append([torch.randn(2, 16, 8, generator=g), torch.randn(2, 16, 8, generator=g) * 5, torch.randn(2, 16, 8, generator=g)])
+    results = {}
+    for lean in (1, 0):
+        ops.set_tuning("mse_lean", lean)
+        try:
+            out = []
+            for ci, batches in enumerate(cases):
+                for cls, bit, sym in ((AvgMSEFastObserver, 6, False), (MSEFastObserver, 4, True), (AvgMSEFastObserver, 8, False)):
+                    ob = cls(bit=bit, symmetric=sym).to(dev)
+                    L = torch.full((batches[0].shape[0],), batches[0].shape[1], device=dev)
+                    L[0] = max(1, batches[0].shape[1] // 2)
+                    for x in batches:
+                        ob(x.to(dev), L, 1)
+                        out.append((N(ob.min_val).copy(), N(ob.max_val).copy(), N(ob.last_nfev).copy()))
+            results[lean] = out
+        finally:
+            ops.set_tuning("mse_lean", 1)
+    assert len(results[1]) == len(results[0])
+    for i, (a, b) in enumerate(zip(results[1], results[0])):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b)), (i, a, b)

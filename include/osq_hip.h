@@ -469,23 +469,6 @@ int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat, int64_t n
  *          site) with its host-side element bound n[i] and nullable device count n_device[i], and scratch of
  *          osq_ordered_sum_scratch_bytes(n[i], 1) bytes;
  *   _evals: n_evals rounds, then done_out[0] = 1 if every search has converged (nullable). */
-/* The same searches with their sites RESIDENT on the chip (csrc/msefast_resident_ordered.h): ONE persistent launch runs
- * float64 searches to completion -- every workgroup keeps chunk groups of the sites in registers, per evaluation the chunk
- * sums meet at the site's master workgroup (the last to arrive), which adds the upper levels in order, takes the Brent step
- * and publishes the next candidate; sites advance independently.  No kernel boundary and no HBM stream per evaluation; same
- * additions in the same order as osq_msefast_ordered_multi_evals, same bits.
- *   _items(n, &capacity): register slots a search over n elements needs (its chunk groups + 1), 0 = it cannot be resident
- *          (more than ~8.4 M elements: cascade step 32; no persistent grid; "mse_sum_order" not set); capacity = slots of one launch;
- *   _resident: searches begun with float64_input = 1 whose slots add up to at most the capacity; flat inputs as for
- *          _multi_prepare with EXACT element counts n[i]; scratch[i] of osq_ordered_sum_scratch_bytes(n[i], 1) bytes;
- *          table: osq_msefast_ordered_resident_bytes(n_sites) bytes of device memory, ZERO; afterwards its first 32-bit word is
- *          a status (non-zero: a workgroup gave up waiting for the others -- the searches' results are invalid).
- *          OSQ_ERR_UNSUPPORTED: does not fit / no persistent grid: nothing was launched. */
-int    osq_msefast_ordered_resident_items(int64_t n, int* capacity_out);
-size_t osq_msefast_ordered_resident_bytes(int n_sites);
-int    osq_msefast_ordered_resident(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
-                                    const int64_t* n, void* const* scratch, const size_t* scratch_bytes, int n_sites,
-                                    osq_stream stream);
 size_t osq_msefast_ordered_multi_bytes(int n_sites);
 int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
                                       const int64_t* n, const int64_t* const* n_device, void* const* scratch,

@@ -101,10 +101,6 @@ SIGNATURES = {
     "osq_msefast_tensor_evals_tokens": (_I, [_P, _P, ctypes.POINTER(TokenView), _P, _I, _P, _P]),
     "osq_gather_valid_tokens": (_I, [_P, ctypes.POINTER(TokenView), _P, _P, _P, _P]),
     "osq_msefast_tensor_evals_ordered": (_I, [_P, _P, _L, _P, _I, _P, ctypes.c_size_t, _P, _P]),
-    "osq_msefast_ordered_resident_items": (_I, [_L, ctypes.POINTER(_I)]),
-    "osq_msefast_ordered_resident_bytes": (ctypes.c_size_t, [_I]),
-    "osq_msefast_ordered_resident": (_I, [_P, ctypes.c_size_t, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L), ctypes.POINTER(_P),
-                                          ctypes.POINTER(ctypes.c_size_t), _I, _P]),
     "osq_msefast_ordered_multi_bytes": (ctypes.c_size_t, [_I]),
     "osq_msefast_ordered_multi_prepare": (_I, [_P, ctypes.c_size_t, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L),
                                                ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t), _I,

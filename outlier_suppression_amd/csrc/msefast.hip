@@ -761,10 +761,6 @@ __global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_k
     ordered_evaluation(s.x, s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
 }
 
-}  // namespace osq
-#include "msefast_resident_ordered.h"      // the same searches with their sites resident in registers (one persistent launch)
-namespace osq {
-
 // after the gathers of a group: n_host <- the device-side count of valid elements (same stream, once per group)
 __global__ void ordered_sites_counts_kernel(OrderedSite* __restrict__ sites, int n_sites) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -964,7 +960,6 @@ constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
 static int g_mse_rows_order = 8;                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
-static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();     // osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 (processes that SHARE a GPU): no persistent launches
 static int g_mse_lean = 1;                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
 static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
@@ -1680,107 +1675,15 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
     return check_launch("msefast_ordered_multi_evals");
 }
 
-// ---- the reference-order searches with their sites resident on the chip (msefast_resident_ordered.h)
-static int g_ro_ki = 8;                       // osq_set_tuning("mse_resident_items", 8 | 10 | 12): chunk groups a worker workgroup keeps in registers (16 VGPRs each)
-#define kRoKI g_ro_ki
-constexpr int kRoMasters = 16;                // workgroups of the grid that hold no data: the sites' masters
-static int ro_grid() {
-    static int grid = -1;                     // per process; devices of one node are identical
-    if (grid < 0) grid = persistent_grid_for(reinterpret_cast<const void*>(&msefast_ordered_resident_kernel<12>), kRoThreads);
-    return grid;
-}
-/* Items (register slots of the resident grid) a float64-summed search over n elements occupies, 0 = it cannot be resident
- * (cascade step 32: more than 8.4 M elements; no persistent grid on this device).  *capacity_out: items one launch holds. */
-extern "C" int osq_msefast_ordered_resident_items(int64_t n, int* capacity_out) {
-    const int grid = g_mse_resident ? ro_grid() : 0;
-    if (capacity_out) *capacity_out = grid > kRoMasters ? (grid - kRoMasters) * kRoKI : 0;
-    if (grid <= kRoMasters || n <= 0 || (g_mse_sum_order != 8 && g_mse_sum_order != 16)) return 0;
-    const CascadeGeom g = cascade_geom(n, g_mse_sum_order / 2);
-    if (g.P != 4 || g.S * g.NC > kRoThreads) return 0;
-    const int G = kRoThreads / (g.S * g.NC);
-    const int64_t items = (g.chunks + G - 1) / G;          // chunk groups; a site without a full chunk has nothing to keep resident
-    if (items == 0) return 0;
-    return items > static_cast<int64_t>(grid - kRoMasters) * kRoKI ? 0 : static_cast<int>(items);
-}
-extern "C" size_t osq_msefast_ordered_resident_bytes(int n_sites) {
-    if (n_sites <= 0) return 0;
-    const int grid = ro_grid();
-    return 64 + static_cast<size_t>(n_sites) * (sizeof(RoSync) + sizeof(RoSite)) + static_cast<size_t>(grid > kRoMasters ? grid - kRoMasters : 0) * kRoKI * sizeof(RoItem);
-}
-/* Runs the float64 searches states[0 .. n_sites) (each begun with float64_input, flat inputs as for
- * osq_msefast_ordered_multi_prepare, n[i] EXACT element counts) to completion in ONE persistent launch.  table:
- * osq_msefast_ordered_resident_bytes(n_sites) bytes of device memory, ZERO; its first word is a sticky status (1 = a
- * workgroup gave up waiting: the searches' results are invalid).  OSQ_ERR_UNSUPPORTED: the searches do not fit one launch
- * (osq_msefast_ordered_resident_items) -- nothing was launched. */
-extern "C" int osq_msefast_ordered_resident(void* table, size_t table_bytes, void* const* states, const float* const* x_flat,
-                                            const int64_t* n, void* const* scratch, const size_t* scratch_bytes, int n_sites,
-                                            osq_stream stream) {
-    OSQ_REQUIRE(table && states && x_flat && n && scratch && scratch_bytes, "msefast_ordered_resident: null pointer");
-    OSQ_REQUIRE(n_sites > 0 && n_sites <= kRoMaxSites, "msefast_ordered_resident: 1 .. 128 searches per launch");
-    OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
-                "msefast_ordered_resident: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
-    OSQ_REQUIRE(table_bytes >= osq_msefast_ordered_resident_bytes(n_sites), "msefast_ordered_resident: table smaller than osq_msefast_ordered_resident_bytes(n_sites)");
-    const int grid = g_mse_resident ? ro_grid() : 0;
-    if (grid <= kRoMasters) return OSQ_ERR_UNSUPPORTED;
-    const int workers = grid - kRoMasters;
-    std::vector<RoSite> sites(static_cast<size_t>(n_sites));
-    std::vector<RoItem> items(static_cast<size_t>(workers) * kRoKI, RoItem{static_cast<unsigned short>(kRoNoSite), 0, 0u});
-    int64_t total = 0;
-    for (int i = 0; i < n_sites; ++i) {
-        OSQ_REQUIRE(states[i] && x_flat[i] && n[i] > 0 && scratch[i], "msefast_ordered_resident: bad site");
-        OSQ_REQUIRE(scratch_bytes[i] >= osq_ordered_sum_scratch_bytes(n[i], 1), "msefast_ordered_resident: scratch smaller than osq_ordered_sum_scratch_bytes(n, 1)");
-        const int k = osq_msefast_ordered_resident_items(n[i], nullptr);
-        if (k == 0) return OSQ_ERR_UNSUPPORTED;
-        RoSite& s = sites[static_cast<size_t>(i)];
-        s = RoSite{};
-        s.x = x_flat[i];
-        s.ts = static_cast<TensorSearch*>(states[i]);
-        s.part = static_cast<double*>(scratch[i]);
-        s.n = n[i];
-        s.items = static_cast<unsigned int>(k);
-        if (total + k > static_cast<int64_t>(workers) * kRoKI) return OSQ_ERR_UNSUPPORTED;
-        // the site's items go round the worker workgroups one by one: slot t of the launch is (worker t % workers, register slot t / workers)
-        for (int q = 0; q < k; ++q, ++total) {
-            RoItem& it = items[static_cast<size_t>(total % workers) * kRoKI + static_cast<size_t>(total / workers)];
-            it.site = static_cast<unsigned short>(i);
-            it.kind = 0;
-            it.q = static_cast<unsigned int>(q);
-        }
-    }
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!persistent_serialize(st)) return OSQ_ERR_UNSUPPORTED;
-    char* base = static_cast<char*>(table);
-    RoSync* sync_dev = reinterpret_cast<RoSync*>(base + 64);
-    RoSite* sites_dev = reinterpret_cast<RoSite*>(base + 64 + static_cast<size_t>(n_sites) * sizeof(RoSync));
-    RoItem* items_dev = reinterpret_cast<RoItem*>(reinterpret_cast<char*>(sites_dev) + static_cast<size_t>(n_sites) * sizeof(RoSite));
-    OSQ_REQUIRE(hipMemcpyAsync(sites_dev, sites.data(), sites.size() * sizeof(RoSite), hipMemcpyHostToDevice, st) == hipSuccess &&
-                hipMemcpyAsync(items_dev, items.data(), items.size() * sizeof(RoItem), hipMemcpyHostToDevice, st) == hipSuccess &&
-                hipStreamSynchronize(st) == hipSuccess, "msefast_ordered_resident: copying the tables failed");
-    RoArgs a{};
-    a.sites = sites_dev;
-    a.sync = sync_dev;
-    a.items = items_dev;
-    a.status = reinterpret_cast<unsigned int*>(base);
-    a.n_sites = n_sites;
-    a.W = g_mse_sum_order;
-    a.lean_ok = g_mse_lean;
-    a.n_masters = kRoMasters;
-    a.spin_limit = g_res_spin_limit ? g_res_spin_limit - 1u : kRoSpinLimit;
-    if (g_ro_ki == 12) hipLaunchKernelGGL(msefast_ordered_resident_kernel<12>, dim3(static_cast<unsigned>(grid)), dim3(kRoThreads), 0, st, a);
-    else if (g_ro_ki == 10) hipLaunchKernelGGL(msefast_ordered_resident_kernel<10>, dim3(static_cast<unsigned>(grid)), dim3(kRoThreads), 0, st, a);
-    else hipLaunchKernelGGL(msefast_ordered_resident_kernel<8>, dim3(static_cast<unsigned>(grid)), dim3(kRoThreads), 0, st, a);
-    return check_launch("msefast_ordered_resident");
-}
-
 // osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 in the environment (the switch for processes that SHARE a GPU:
 // persistent grids of two processes cannot be ordered against each other): per-tensor searches run one launch per evaluation
+static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
-    if (std::string(key) == "mse_resident_items") { if (value != 8 && value != 10 && value != 12) return false; g_ro_ki = value; return true; }
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }

@@ -626,7 +626,7 @@ def msefast_rows(w, ch_axis, quant_min, quant_max, symmetric, one_side, two_d):
 
 class MseSearch:
     """One per-tensor MSEFast search between its begin and its commit (state on the device, what the launches need)."""
-    __slots__ = ("state", "x", "view", "lengths", "args", "elems", "f64")
+    __slots__ = ("state", "x", "view", "lengths", "args", "elems")
 
 
 def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,
@@ -653,7 +653,6 @@ def msefast_tensor_begin(x, cur, observation_mask, seq_pos, quant_min, quant_max
         x = x.clone()          # the flat kernels read 16 bytes per lane: a misaligned buffer (a slice of a larger one) is copied once
     r.x, r.view, r.lengths, r.elems = x, view, lengths, x.numel()
     r.args = (int(quant_min), int(quant_max), int(bool(symmetric)))
-    r.f64 = bool(float64_input)
     return r
 
 
@@ -844,104 +843,6 @@ def msefast_tensor_run_ordered_group(group, chunk=64):
         if int(ctx["done"].item()) or ctx["launched"] > 500 * 500:
             break
     return ctx["launched"]
-
-
-ORDERED_RESIDENT = os.environ.get("OSQ_MSE_RESIDENT", "1") not in ("", "0")
-
-
-def msefast_tensor_run_ordered_resident(searches):
-    """The float64 searches among `searches` whose sites fit the resident grid, run to completion with their sites RESIDENT
-    in registers (csrc/msefast_resident_ordered.h: one persistent launch per packing of sites, no HBM stream per loss
-    evaluation; same bits as the streaming rounds).  Returns the searches it did NOT take (fp32 calls, sites beyond ~8.4 M
-    elements or beyond a launch's capacity, no persistent grid): the caller runs those as streaming rounds.  A masked site
-    is laid out first (remove_padding order) and the exact element counts are read back once (one synchronisation per
-    flush) -- the packing needs them."""
-    lib = _hip.load()
-    cap = ctypes.c_int(0)
-    lib.osq_msefast_ordered_resident_items(1 << 20, ctypes.byref(cap))
-    if not (ORDERED_RESIDENT and cap.value > 0 and _tuning.get("mse_resident", 1)):
-        return list(searches)
-    take = [r for r in searches if r.f64]
-    rest = [r for r in searches if not r.f64]
-    if not take:
-        return rest
-    dev = take[0].x.device
-    st = _hip.stream_ptr(dev)
-    flats, n_devs = [], []
-    for r in take:
-        if r.view is None:
-            flats.append(r.x)
-            n_devs.append(None)
-        else:
-            n = r.view.batch * r.view.tokens * r.view.feat_outer * r.view.feat_inner
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-            n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-            _hip.check(lib.osq_gather_valid_tokens(_hip.ptr(r.x), ctypes.byref(r.view), _hip.ptr(r.lengths), _hip.ptr(flat),
-                                                   _hip.ptr(n_dev), st), "gather_valid_tokens")
-            flats.append(flat)
-            n_devs.append(n_dev)
-    masked = [t for t in n_devs if t is not None]
-    counts = torch.cat(masked).cpu().tolist() if masked else []
-    ns, k = [], 0
-    for r, t in zip(take, n_devs):
-        if t is None:
-            ns.append(int(r.x.numel()))
-        else:
-            ns.append(int(counts[k]))
-            k += 1
-    # first-fit decreasing into launches of `cap` register slots; what has no slot count (or no elements) goes back
-    order = sorted(range(len(take)), key=lambda i: -ns[i])
-    launches = []
-    for i in order:
-        items = int(lib.osq_msefast_ordered_resident_items(ns[i], None)) if ns[i] > 0 else 0
-        if items == 0:
-            rest.append(take[i])
-            continue
-        for L in launches:
-            if L["used"] + items <= cap.value and len(L["idx"]) < 128:
-                L["idx"].append(i)
-                L["used"] += items
-                break
-        else:
-            launches.append({"idx": [i], "used": items})
-    vp = ctypes.c_void_p
-    tables = []
-    for L in launches:
-        idx = L["idx"]
-        m = len(idx)
-        sizes = [int(lib.osq_ordered_sum_scratch_bytes(ns[i], 1)) for i in idx]
-        offs, total = [], 0
-        for b in sizes:
-            offs.append(total)
-            total += (b + 255) // 256 * 256
-        scratch = torch.empty(total, dtype=torch.uint8, device=dev)
-        nbytes = int(lib.osq_msefast_ordered_resident_bytes(m))
-        table = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        states = (vp * m)(*[_hip.ptr(take[i].state) for i in idx])
-        xs = (vp * m)(*[_hip.ptr(flats[i]) for i in idx])
-        n_arr = (ctypes.c_int64 * m)(*[ns[i] for i in idx])
-        sc_arr = (vp * m)(*[scratch.data_ptr() + o for o in offs])
-        sb_arr = (ctypes.c_size_t * m)(*sizes)
-        rc = lib.osq_msefast_ordered_resident(_hip.ptr(table), nbytes, states, xs, n_arr, sc_arr, sb_arr, m, st)
-        if rc == _hip.ERR_UNSUPPORTED:
-            rest.extend(take[i] for i in idx)
-            continue
-        _hip.check(rc, "msefast_ordered_resident")
-        tables.append((table, scratch))
-    if tables:
-        status = torch.stack([t[0][:4].view(torch.int32) for t in tables]).cpu()          # one synchronisation: the searches took milliseconds
-        if os.environ.get("OSQ_RO_TIMING"):
-            for t in tables:
-                w = t[0][:64].view(torch.int64).cpu().tolist()
-                n = max(w[5], 1)
-                print("resident round of site 0 (10 ns ticks -> us): open %.2f finish %.2f tell %.2f publish %.2f workers %.2f over %d rounds"
-                      % tuple([v / n / 100.0 for v in (w[1], w[2], w[3], w[4], w[6])] + [w[5]]))
-        if int(status.abs().sum()):
-            raise PersistentLaunchTimeout(
-                "outlier_suppression_amd: a resident MSEFast launch (reference-order searches) timed out waiting for its own "
-                "workgroups; the statistics of this flush are invalid.  Cause: the grid was not resident together (another "
-                "process on the GPU?).  OSQ_MSE_RESIDENT=0 keeps the searches on the streaming rounds.")
-    return rest
 
 
 _side_streams = {}

@@ -46,11 +46,6 @@ class DeferredSites:
         if ops.reference_sum_order("mse"):
             # strict sums: one launch per ROUND of loss evaluations of all the forward's searches (128 per table)
             fit = [it for it in pending if ops.msefast_ordered_fits(it[1])]
-            # float64 searches whose sites fit the chip: resident, one persistent launch per packing; the others: streaming rounds
-            left = ops.msefast_tensor_run_ordered_resident([it[1] for it in fit])
-            left_ids = {id(r) for r in left}
-            self.launches += 1 if len(left) < len(fit) else 0
-            fit = [it for it in fit if id(it[1]) in left_ids]
             groups = ops.msefast_ordered_groups([it[1] for it in fit], [it[2] for it in fit])
             ops.msefast_tensor_run_ordered_groups(groups)          # concurrent: one stream per group
             self.launches += len(groups)

@@ -405,60 +405,3 @@ def test_lean_float64_term_equals_the_full_chain(dev, strict):
     assert len(results[1]) == len(results[0])
     for i, (a, b) in enumerate(zip(results[1], results[0])):
         assert all(np.array_equal(u, v) for u, v in zip(a, b)), (i, a, b)
-
-
-def test_resident_ordered_searches_equal_the_streaming_rounds(dev, strict):
-    """csrc/msefast_resident_ordered.h (round 5): the float64 searches of an observer pass with their sites RESIDENT in
-    registers -- one persistent launch, chunk sums -> master workgroup -> next candidate per evaluation -- against the
-    streaming rounds (ops.ORDERED_RESIDENT = False) and against the searches run one by one: statistics and evaluation counts
-    after every one of four batches EQUAL.  Sites: masked hidden states at BERT-base width, a GELU-sized site, one with fewer
-    elements than a chunk (open unit only), one whose length is no multiple of anything, and -- beyond 8.4 M elements -- one
-    the resident grid does not take (it must fall back on the rounds inside the same flush)."""
-    from outlier_suppression_amd import ops
-    from outlier_suppression_amd.quantization.deferred import deferred_observation
-    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
-    g = torch.Generator().manual_seed(909)
-    shapes = [((32, 128, 768), True), ((32, 128, 3072), True), ((2, 5, 7), False), ((3, 50, 37), True), ((16, 128, 768), False),
-              ((40, 128, 1664), False)]
-    cases = []
-    for shape, masked in shapes:
-        xs = []
-        for b in range(4):
-            x = torch.randn(*shape, generator=g) * (1.0 + 0.15 * b)
-            x[..., 3] *= 12
-            xs.append(x.to(dev))
-        L = (torch.randint(1, shape[1] + 1, (shape[0],), generator=g) if masked else torch.full((shape[0],), shape[1])).to(dev)
-        cases.append((xs, L))
-
-    def observers():
-        return [(AvgMSEFastObserver if i % 2 == 0 else MSEFastObserver)(bit=6 if i % 3 else 4, symmetric=False).to(dev) for i in range(len(cases))]
-
-    def run(resident):
-        old = ops.ORDERED_RESIDENT
-        ops.ORDERED_RESIDENT = resident
-        try:
-            obs = observers()
-            for ob in obs:
-                object.__setattr__(ob, "_defer_ok", True)
-            trace = []
-            with deferred_observation() as sites:
-                for b in range(4):
-                    for ob, (xs, L) in zip(obs, cases):
-                        ob(xs[b], L, 1)
-                    sites.flush()
-                    trace.append([(N(o.min_val).copy(), N(o.max_val).copy(), N(o.last_nfev).copy()) for o in obs])
-            return trace
-        finally:
-            ops.ORDERED_RESIDENT = old
-
-    resident, rounds = run(True), run(False)
-    for b, (ta, tb) in enumerate(zip(resident, rounds)):
-        for i, (a, c) in enumerate(zip(ta, tb)):
-            assert all(np.array_equal(u, v) for u, v in zip(a, c)), (b, i, a, c)
-    one_by_one = observers()
-    for b in range(4):
-        for ob, (xs, L) in zip(one_by_one, cases):
-            ob(xs[b], L, 1)
-    for i, ob in enumerate(one_by_one):
-        a = resident[-1][i]
-        assert np.array_equal(N(ob.min_val), a[0]) and np.array_equal(N(ob.max_val), a[1]) and np.array_equal(N(ob.last_nfev), a[2]), i

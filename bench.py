@@ -252,6 +252,16 @@ def kernel_table(dev, xs, lengths, reps=20):
             add(f"site {tag}: token_select p=0.95", timed(_hip.TIME_TOKEN_SELECT, lambda i: ops.token_range_finalize(
                 tk[0], tk[1], tk[2], tk[3], tk[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
                 8 * shp[0] * shp[sp])
+            # learn-scale's backward at site size, both summation tiers (12 B per element: x, grad_out in, dx out)
+            gsite = torch.randn_like(xsite)
+            prev_order = ops.reference_sum_order("bwd")
+            try:
+                for order, what in ((0, "default: order-free"), (8, "set_strict(backward=True): reference order")):
+                    ops.set_tuning("bwd_sum_order", order)
+                    add(f"site {tag}: lsq_plus_backward ({what})", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
+                        xsite, gsite, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * xsite.numel())
+            finally:
+                ops.set_tuning("bwd_sum_order", prev_order)
         # ---- rows of SURVEY.md section 8d that have no dispatch-attached timer: stream-order events around the call
         # (they include one kernel boundary, ~2 us)
         def ev_timed(fn, inner=1):

@@ -45,7 +45,7 @@ __host__ __device__ inline CascadeGeom cascade_geom(int64_t n, int W) {
     g.n = n;
     g.W = W;
     g.NC = 4 * W;
-    g.n_vec = n / W;
+    g.n_vec = n >> cascade_ceil_log2(W);                   // W is 4, 8 or 16: a shift, not a 64-bit division per workgroup
     g.size = g.n_vec / 4;
     const int p = cascade_ceil_log2(g.size) / 4;
     g.P = p < 4 ? 4 : p;
@@ -164,14 +164,16 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
 // half as wide).  NS sums share the pass (`eval(raw, e, t[NS])`; it may write per-element results on the way).  Same
 // additions in the same order.  Requires S * NC <= THREADS; `lds` holds 2 * NS * THREADS values of T.
 // The open unit (m == chunks) stays with cascade_units(..., first_unit = chunks).
-template <typename T, int NS, int P, int THREADS, typename Raw, typename Load, typename Eval>
+// NCS >= 0: the caller knows log2(NC) at compile time (it branched on it): a thread's R loads are then ONE 64-bit address
+// and R immediate offsets (k * NC elements apart), not R address computations.
+template <typename T, int NS, int P, int THREADS, typename Raw, typename Load, typename Eval, int NCS = -1>
 __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T* __restrict__ part, T* lds, Load load, Eval eval,
                                                          const unsigned int bid, const unsigned int nblk_grid) {
     constexpr int S = 1 << P;
     constexpr int R = 16;                                   // rows in flight per thread: a block of S = 32 rows is two steps
     constexpr int H = S / R;
     constexpr int KB = NS == 1 ? 16 : 8;                    // terms computed side by side
-    const int nc_shift = __builtin_ctz(static_cast<unsigned int>(g.NC));
+    const int nc_shift = NCS >= 0 ? NCS : __builtin_ctz(static_cast<unsigned int>(g.NC));
     const int64_t sstride = (g.chunks + 2) * g.NC;          // part[s][m][c], as in cascade_units
     const int tpc = S << nc_shift;                          // (block, column) pairs of a chunk
     const int G = THREADS / tpc;
@@ -180,13 +182,16 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
     const int j = tid / tpc, rem = tid - j * tpc, blk = rem >> nc_shift, c = rem & (g.NC - 1);
     const bool lane_ok = tid < G * tpc;
     Raw cur[R], nxt[R];
+    // BRANCH-FREE: a fetch behind a condition leaves the compiler without a count of the loads in flight at the join, and it
+    // answers with `s_waitcnt vmcnt(0)` in front of the first term -- the current group's arithmetic then waits for the NEXT
+    // group's loads, the pipelining undone (round 5: the MSEFast rounds' waves sat parked 55 % of their time).  A lane with
+    // nothing to fetch (past the last chunk, no next group) reads rows 0..R-1 of chunk 0 instead: every such lane of a
+    // column the same 16 lines, in bounds because chunks > 0 (the callers' condition), never used.
     auto fetch = [&](const int64_t grp, const int h, Raw (&r)[R]) {
         const int64_t m = grp * G + j;
-        if (lane_ok && m < g.chunks) {
-            const int64_t row0 = (((m << P) + blk) << P) + h * R;
+        const int64_t e0 = (lane_ok && m < g.chunks) ? (((((m << P) + blk) << P) + h * R) << nc_shift) + c : static_cast<int64_t>(c);
 #pragma unroll
-            for (int k = 0; k < R; ++k) r[k] = load(((row0 + k) << nc_shift) + c);
-        }
+        for (int k = 0; k < R; ++k) r[k] = load(e0 + (static_cast<int64_t>(k) << nc_shift));
     };
     int64_t grp = bid;
     if (grp < ngroups) fetch(grp, 0, cur);
@@ -200,7 +205,7 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             if (h + 1 < H) fetch(grp, h + 1, nxt);
-            else if (grp + nblk_grid < ngroups) fetch(grp + nblk_grid, 0, nxt);
+            else fetch(grp + nblk_grid < ngroups ? grp + nblk_grid : ngroups, 0, nxt);     // ngroups: no such chunk, the dummy rows
             if (lane_ok && m < g.chunks) {
                 const int64_t row0 = (((m << P) + blk) << P) + h * R;
 #pragma unroll

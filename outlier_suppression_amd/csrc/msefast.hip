@@ -279,7 +279,7 @@ __device__ __forceinline__ double sq_err_f64_lean(float xf, double s, double y, 
     const float u = xf * y32;
     const float r = rintf(u);
     if (fabsf(u - r) >= 0.4995f) return sq_err_f64_rcp(xf, s, y, z, qmin, qmax);      // false for NaN (u = +-inf): saturates below
-    const float c = fminf(fmaxf(r, lo32), hi32);
+    const float c = __builtin_amdgcn_fmed3f(r, lo32, hi32);       // the clamp as ONE instruction (lo32 <= hi32, r is not NaN here: fminf(fmaxf()) is three, two of them canonicalising moves)
     const double d = static_cast<double>(c) * s - static_cast<double>(xf);
     return d * d;
 }
@@ -645,9 +645,13 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
 constexpr int kOrdThreads = 512;
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
 // one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
-__device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, const int64_t n, TensorSearch* __restrict__ ts,
+__device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_generic, const int64_t n, TensorSearch* __restrict__ ts,
                                                    void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W_and_flags,
                                                    const unsigned int bid, const unsigned int nblk, double* lds_raw) {
+    // The rounds kernel takes x from a TABLE in memory: to the compiler a generic pointer, whose loads are flat_load_dword (they
+    // tick lgkmcnt as well as vmcnt, so every LDS wait also waits for data loads in flight).  x is device memory by the entry
+    // points' contract: say so, and the loads are global_load_dword.
+    const GlobalF32 x = as_global(x_generic);
     const int W = W_and_flags & 0xff;                             // 8 | 16; bit 8: the lean float64 term (osq_set_tuning("mse_lean"))
     const bool lean_ok = (W_and_flags >> 8) & 1;
     // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
@@ -662,8 +666,10 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         // the float64 chain is VALU-bound on its division: the exact reciprocal sequence of the resident search (same bits,
         // sq_err_f64_rcp) whenever its two conditions hold -- a uniform branch, the division out of line
         const double rcp = 1.0 / sd;
-        const bool fast = rcp_division_exact(sd, x_min, x_max);
-        const bool lean = fast && lean_ok && lean_level_exact(z, qmin, qmax);
+        // uniform facts, and the compiler is told so: they come from vector loads of the search's state, and as per-lane values
+        // every term sat behind three levels of exec masks (~12 scalar instructions per element next to ~14 vector ones)
+        const bool fast = __builtin_amdgcn_readfirstlane(rcp_division_exact(sd, x_min, x_max) ? 1 : 0) != 0;
+        const bool lean = __builtin_amdgcn_readfirstlane((fast && lean_ok && lean_level_exact(z, qmin, qmax)) ? 1 : 0) != 0;
         const float rcp32 = static_cast<float>(rcp), lo32 = qmin - z, hi32 = qmax - z;
         auto term = [=](int64_t e, double (&t)[1]) {
             if (lean) t[0] = sq_err_f64_lean(x[e], sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
@@ -674,13 +680,29 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         double* lds = lds_raw;
         if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
             // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
+#ifdef OSQ_MSE_DBG
+            const bool dbg_noload = (W_and_flags >> 9) & 1, dbg_trivial = (W_and_flags >> 10) & 1;
+            auto load = [=](int64_t e) { return dbg_noload ? __int_as_float(0x3f000000 + static_cast<int>(e & 0xfffff)) : x[e]; };
+#else
+            constexpr bool dbg_trivial = false;
             auto load = [=](int64_t e) { return x[e]; };
-            auto eval = [=](float xf, int64_t, double (&t)[1]) {
-                if (lean) t[0] = sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
-                else t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax);
-            };
-            if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+#endif
+            if (lean && g.NC == 16) {
+                // the common case by far (a finite tensor, an integer zero point, the reference machine's W = 8): its own loop --
+                // the lean term alone, log2(NC) a constant (one address per thread and step, 16 immediate offsets)
+                auto eval = [=](float xf, int64_t, double (&t)[1]) {
+                    t[0] = dbg_trivial ? static_cast<double>(xf) : sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
+                };
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk);
+                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk);
+            } else {
+                auto eval = [=](float xf, int64_t, double (&t)[1]) {
+                    if (lean) t[0] = sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
+                    else t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax);
+                };
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            }
             if (bid == nblk - 1) cascade_units<double, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
         } else {
             cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
@@ -704,7 +726,9 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x, 
         if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
             auto load = [=](int64_t e) { return x[e]; };
             auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
-            if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+            if (g.NC == 32 && g.P == 4)                         // the reference machine's W = 8 (S * NC <= 512 leaves P = 4 only): log2(NC) a constant, as above
+                cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk);
+            else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
             if (bid == nblk - 1) cascade_units<float, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);
         } else {
@@ -960,6 +984,7 @@ constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
 static int g_mse_rows_order = 8;                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
+static int g_mse_dbg = 0;                            // -DOSQ_MSE_DBG builds only (tools/mse_dbg_probe.py): 1 = generated values instead of data loads, 2 = a conversion instead of the term; WRONG results, timing probes
 static int g_mse_lean = 1;                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
 static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
 static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
@@ -1606,7 +1631,7 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     return check_launch("msefast_tensor_evals_ordered");
 }
 
-static int g_ord_groups = 4;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
+static int g_ord_groups = 8;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
     // site table, ticket counters, block -> site map (one byte per workgroup of a round, at most kMaxBlocks per site)
@@ -1670,7 +1695,7 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
     const unsigned char* block_site = static_cast<const unsigned char*>(table) + static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites,
-                           g_mse_sum_order | (g_mse_lean ? 256 : 0));
+                           g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_dbg << 9));
     if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
     return check_launch("msefast_ordered_multi_evals");
 }
@@ -1684,6 +1709,9 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
+#ifdef OSQ_MSE_DBG
+    if (std::string(key) == "mse_dbg") { g_mse_dbg = value & 3; return true; }
+#endif
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;
 } }

@@ -11,6 +11,11 @@
 
 namespace osq {
 
+// A pointer the compiler cannot trace to a kernel argument (read from a table in memory) is GENERIC: its loads are flat_load_*,
+// which tick lgkmcnt as well as vmcnt and so serialise against every LDS wait.  Device memory by contract -> address space 1.
+typedef const float __attribute__((address_space(1)))* GlobalF32;
+__device__ __forceinline__ GlobalF32 as_global(const float* p) { return (GlobalF32)p; }
+
 struct QParams {   // effective parameters that reach the quantiser
     float scale;
     float zp;

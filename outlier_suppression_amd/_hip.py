@@ -11,7 +11,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libosq_hip.so")
+# OSQ_HIP_LIBRARY: another build of the same ABI (A/B runs of a kernel variant, the -DOSQ_MSE_DBG probe build); the ABI version
+# check applies to it as to the in-tree library
+LIB_PATH = os.environ.get("OSQ_HIP_LIBRARY") or os.path.join(_HERE, "libosq_hip.so")
 
 # zero-point storage / parameter mode / update rule (mirrors include/osq_hip.h)
 ZP_INT32, ZP_FLOAT32 = 0, 1

@@ -155,6 +155,18 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
     cascade_units<T, NS, THREADS, Term>(g, part, lds, term, blockIdx.x, gridDim.x);
 }
 
+// A barrier for exchanges through LDS only.  __syncthreads() is a workgroup-scope fence around s_barrier: it also waits for every
+// global load and store the wave has in flight (vmcnt(0)).
+__device__ __forceinline__ void cascade_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// cur <- nxt of the pipelined stage.  For a float the copy is an explicit v_mov: with a plain assignment the compiler may
+// alias `cur` to the load's destination registers, and its wait-count pass then re-waits (vmcnt(0): the NEXT step's loads too)
+// at every basic block that reads them -- seen in the S = 32 form, whose second step began behind the loads it had just issued.
+template <typename Raw> __device__ __forceinline__ void cascade_rotate(Raw& cur, const Raw& nxt) { cur = nxt; }
+template <> __device__ __forceinline__ void cascade_rotate<float>(float& cur, const float& nxt) {
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cur) : "v"(nxt));
+}
+
 // Stage 1 of ONE sum over the FULL level-1 chunks with the memory latency hidden.  The generic form above is a chain per
 // chunk -- loads, terms, barrier, the S block sums, publish -- of ~3 us with two workgroups per CU to overlap it: 1.7 us per
 // million elements, the whole cost of a strict MSEFast round.  Here a thread's S raw inputs of its NEXT chunk (`load(e)`,
@@ -162,13 +174,24 @@ __device__ __forceinline__ void cascade_units(const CascadeGeom& g, T* __restric
 // added in order; the block sums go through a double-buffered LDS tile (one barrier per chunk), and a workgroup whose
 // threads outnumber a chunk's S * NC (block, column) pairs takes G = THREADS / (S * NC) chunks at a time (float64: NC is
 // half as wide).  NS sums share the pass (`eval(raw, e, t[NS])`; it may write per-element results on the way).  Same
-// additions in the same order.  Requires S * NC <= THREADS; `lds` holds 2 * NS * THREADS values of T.
+// additions in the same order.  Requires S * NC <= THREADS and chunks > 0.
 // The open unit (m == chunks) stays with cascade_units(..., first_unit = chunks).
+//
+// What keeps the loads in flight (round 5, read off the ISA and stamped):
+//  * the fetch is BRANCH-FREE -- behind a condition the compiler has no count of the loads in flight at the join and puts
+//    `s_waitcnt vmcnt(0)` in front of the first term: the current group's arithmetic then waits for the NEXT group's loads;
+//  * the barrier of a group is an LDS-only barrier, not __syncthreads() (which drains vmcnt: the next group's loads);
+//  * NO STORE leaves inside the loop over a batch's groups: vmcnt counts loads and stores in one order, so the wave that
+//    published a group's block sums (write-through, ~1.5 us to acknowledge) stalled on them at its next wait for loads,
+//    and the workgroup on that wave at the next barrier -- and a store behind a condition costs the compiler its count again.
+//    The block sums of a BATCH of up to kCascadeHold groups wait in LDS (`lds` beyond the two tiles; lds_values is its
+//    capacity, >= 2 * NS * THREADS + NS * G * NC) and leave in one burst of stores from as many lanes.
 // NCS >= 0: the caller knows log2(NC) at compile time (it branched on it): a thread's R loads are then ONE 64-bit address
 // and R immediate offsets (k * NC elements apart), not R address computations.
+constexpr int kCascadeHold = 16;
 template <typename T, int NS, int P, int THREADS, typename Raw, typename Load, typename Eval, int NCS = -1>
 __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T* __restrict__ part, T* lds, Load load, Eval eval,
-                                                         const unsigned int bid, const unsigned int nblk_grid) {
+                                                         const unsigned int bid, const unsigned int nblk_grid, const int lds_values) {
     constexpr int S = 1 << P;
     constexpr int R = 16;                                   // rows in flight per thread: a block of S = 32 rows is two steps
     constexpr int H = S / R;
@@ -181,12 +204,14 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
     const int tid = threadIdx.x;
     const int j = tid / tpc, rem = tid - j * tpc, blk = rem >> nc_shift, c = rem & (g.NC - 1);
     const bool lane_ok = tid < G * tpc;
+    const int cols = G << nc_shift;                         // block sums a group leaves, per sum
+    // block sums held back in LDS behind the two tiles: pub[hold][NS * cols]
+    const int room = (lds_values - 2 * NS * THREADS) / (NS * cols);
+    const int hold = room > kCascadeHold ? kCascadeHold : (room < 1 ? 1 : room);
+    T* const pub = lds + 2 * NS * THREADS;
     Raw cur[R], nxt[R];
-    // BRANCH-FREE: a fetch behind a condition leaves the compiler without a count of the loads in flight at the join, and it
-    // answers with `s_waitcnt vmcnt(0)` in front of the first term -- the current group's arithmetic then waits for the NEXT
-    // group's loads, the pipelining undone (round 5: the MSEFast rounds' waves sat parked 55 % of their time).  A lane with
-    // nothing to fetch (past the last chunk, no next group) reads rows 0..R-1 of chunk 0 instead: every such lane of a
-    // column the same 16 lines, in bounds because chunks > 0 (the callers' condition), never used.
+    // a lane with nothing to fetch (past the last chunk, no next group) reads rows 0..R-1 of chunk 0 instead: every such lane
+    // of a column the same 16 lines, in bounds because chunks > 0, never used
     auto fetch = [&](const int64_t grp, const int h, Raw (&r)[R]) {
         const int64_t m = grp * G + j;
         const int64_t e0 = (lane_ok && m < g.chunks) ? (((((m << P) + blk) << P) + h * R) << nc_shift) + c : static_cast<int64_t>(c);
@@ -196,52 +221,63 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
     int64_t grp = bid;
     if (grp < ngroups) fetch(grp, 0, cur);
     int buf = 0;
-    for (; grp < ngroups; grp += nblk_grid) {
-        const int64_t m = grp * G + j;
-        T* const tile = lds + buf * (NS * THREADS);
-        T acc[NS];
+    while (grp < ngroups) {
+        // ---- a batch of up to `hold` groups: loads, arithmetic and LDS only
+        const int64_t grp0 = grp;
+        int held = 0;
+        for (; grp < ngroups && held < hold; grp += nblk_grid, ++held) {
+            const int64_t m = grp * G + j;
+            T* const tile = lds + buf * (NS * THREADS);
+            T acc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = T(0);
+            for (int s = 0; s < NS; ++s) acc[s] = T(0);
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            if (h + 1 < H) fetch(grp, h + 1, nxt);
-            else fetch(grp + nblk_grid < ngroups ? grp + nblk_grid : ngroups, 0, nxt);     // ngroups: no such chunk, the dummy rows
-            if (lane_ok && m < g.chunks) {
-                const int64_t row0 = (((m << P) + blk) << P) + h * R;
+            for (int h = 0; h < H; ++h) {
+                if (h + 1 < H) fetch(grp, h + 1, nxt);
+                else fetch(grp + nblk_grid < ngroups ? grp + nblk_grid : ngroups, 0, nxt);     // ngroups: no such chunk, the dummy rows
+                if (lane_ok && m < g.chunks) {
+                    const int64_t row0 = (((m << P) + blk) << P) + h * R;
 #pragma unroll
-                for (int k0 = 0; k0 < R; k0 += KB) {
-                    T t[KB][NS];
+                    for (int k0 = 0; k0 < R; k0 += KB) {
+                        T t[KB][NS];
 #pragma unroll
-                    for (int k = 0; k < KB; ++k) eval(cur[k0 + k], ((row0 + k0 + k) << nc_shift) + c, t[k]);
+                        for (int k = 0; k < KB; ++k) eval(cur[k0 + k], ((row0 + k0 + k) << nc_shift) + c, t[k]);
 #pragma unroll
-                    for (int k = 0; k < KB; ++k)
+                        for (int k = 0; k < KB; ++k)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) acc[s] = acc[s] + t[k][s];
+                            for (int s = 0; s < NS; ++s) acc[s] = acc[s] + t[k][s];
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < R; ++k) cascade_rotate<Raw>(cur[k], nxt[k]);
             }
+            if (lane_ok && m < g.chunks) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) cur[k] = nxt[k];
-        }
-        if (lane_ok && m < g.chunks) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) tile[s * THREADS + (((j << P) + blk) << nc_shift) + c] = acc[s];
-        }
-        __syncthreads();
-        for (int t = tid; t < NS * (G << nc_shift); t += THREADS) {
-            const int s = t / (G << nc_shift), r = t - s * (G << nc_shift);
-            const int jj = r >> nc_shift, cc = r & (g.NC - 1);
-            const int64_t mm = grp * G + jj;
-            if (mm < g.chunks) {
+                for (int s = 0; s < NS; ++s) tile[s * THREADS + (((j << P) + blk) << nc_shift) + c] = acc[s];
+            }
+            cascade_lds_barrier();                          // the tile is complete (and the previous batch's burst has read pub)
+            for (int t = tid; t < NS * cols; t += THREADS) {
+                const int s = t / cols, r = t - s * cols;
+                const int jj = r >> nc_shift, cc = r & (g.NC - 1);
                 T v[S];
 #pragma unroll
                 for (int b = 0; b < S; ++b) v[b] = tile[s * THREADS + (((jj << P) + b) << nc_shift) + cc];
                 T a = T(0);
 #pragma unroll
                 for (int b = 0; b < S; ++b) a = a + v[b];
-                cascade_publish<T>(&part[s * sstride + (mm << nc_shift) + cc], a);
+                pub[held * (NS * cols) + t] = a;            // a chunk past the last one: whatever the tile held, never published
             }
+            buf ^= 1;                                       // the next chunk's block sums go to the other tile: one barrier per chunk
         }
-        buf ^= 1;                                           // the next chunk's block sums go to the other tile: one barrier per chunk
+        // ---- the batch's burst of stores: its block sums, from as many lanes
+        cascade_lds_barrier();
+        for (int t = tid; t < held * NS * cols; t += THREADS) {
+            const int hslot = t / (NS * cols), q = t - hslot * (NS * cols);
+            const int s = q / cols, r = q - s * cols;
+            const int jj = r >> nc_shift, cc = r & (g.NC - 1);
+            const int64_t mm = (grp0 + static_cast<int64_t>(hslot) * nblk_grid) * G + jj;
+            if (mm < g.chunks) cascade_publish<T>(&part[s * sstride + (mm << nc_shift) + cc], pub[t]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's published sums have left before the workgroup's ticket
     __syncthreads();

@@ -642,6 +642,15 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
 // BERT-base site sizes included (tests/test_gpu_parity.py::test_msefast_*_equals_reference_in_its_summation_order,
 // ::test_msefast_site_size_equals_reference_in_its_summation_order).  A masked / strided site is first gathered into
 // the flat layout the reference's remove_padding builds (gather_valid_tokens_kernel: once per search, not per evaluation).
+#ifdef OSQ_MSE_DBG
+// development build: thread 0 of every workgroup of a round adds its phase durations (100 MHz ticks) here; osq_mse_dbg_read
+__device__ unsigned long long g_mse_phase[8];
+#define OSQ_MSE_STAMP(var) long long var = 0; do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = wall_clock64(); } while (0)
+#define OSQ_MSE_PHASE(slot, d) do { if (threadIdx.x == 0) atomicAdd(&g_mse_phase[slot], static_cast<unsigned long long>(d)); } while (0)
+#else
+#define OSQ_MSE_STAMP(var) do { } while (0)
+#define OSQ_MSE_PHASE(slot, d) do { } while (0)
+#endif
 constexpr int kOrdThreads = 512;
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
 // one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
@@ -652,6 +661,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
     // tick lgkmcnt as well as vmcnt, so every LDS wait also waits for data loads in flight).  x is device memory by the entry
     // points' contract: say so, and the loads are global_load_dword.
     const GlobalF32 x = as_global(x_generic);
+    OSQ_MSE_STAMP(t_entry);
     const int W = W_and_flags & 0xff;                             // 8 | 16; bit 8: the lean float64 term (osq_set_tuning("mse_lean"))
     const bool lean_ok = (W_and_flags >> 8) & 1;
     // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
@@ -661,6 +671,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
     const double x_min = ts->S.x_min, x_max = ts->S.x_max;
     if (ts->S.done) return;                                       // uniform: a converged search costs its workgroups one look
+    OSQ_MSE_STAMP(t_state);
     if (f64) {
         const CascadeGeom g = cascade_geom(n, W / 2);
         // the float64 chain is VALU-bound on its division: the exact reciprocal sequence of the resident search (same bits,
@@ -693,21 +704,27 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
                 auto eval = [=](float xf, int64_t, double (&t)[1]) {
                     t[0] = dbg_trivial ? static_cast<double>(xf) : sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
                 };
-                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk);
-                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk);
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             } else {
                 auto eval = [=](float xf, int64_t, double (&t)[1]) {
                     if (lean) t[0] = sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
                     else t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax);
                 };
-                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             }
+            OSQ_MSE_STAMP(t_groups);
             if (bid == nblk - 1) cascade_units<double, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
+            OSQ_MSE_PHASE(0, t_state - t_entry); OSQ_MSE_PHASE(1, t_groups - t_state); OSQ_MSE_PHASE(4, 1);
         } else {
             cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
         }
-        if (grid_last_block(counters, nblk, bid)) {
+        OSQ_MSE_STAMP(t_before_ticket);
+        const bool last_wg = grid_last_block(counters, nblk, bid);
+        OSQ_MSE_STAMP(t_after_ticket);
+        OSQ_MSE_PHASE(2, t_after_ticket - t_before_ticket);
+        if (last_wg) {
             double sum[1];
             cascade_finish<double, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 8, term, sum);
             if (threadIdx.x == 0) {
@@ -717,6 +734,8 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
                                  &ts->scale_d);
                 grid_reset(counters, nblk);
             }
+            OSQ_MSE_STAMP(t_finished);
+            OSQ_MSE_PHASE(3, t_finished - t_after_ticket); OSQ_MSE_PHASE(5, 1);
         }
     } else {
         const CascadeGeom g = cascade_geom(n, W);
@@ -727,9 +746,9 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
             auto load = [=](int64_t e) { return x[e]; };
             auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
             if (g.NC == 32 && g.P == 4)                         // the reference machine's W = 8 (S * NC <= 512 leaves P = 4 only): log2(NC) a constant, as above
-                cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk);
-            else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
-            else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk);
+                cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
+            else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
+            else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
             if (bid == nblk - 1) cascade_units<float, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);
         } else {
             cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
@@ -1869,3 +1888,13 @@ extern "C" int osq_msefast_tensor_commit(const void* state, int update_rule, int
                        symmetric, scale_out, zero_point_out, zp_type, nfev, ref_float64);
     return check_launch("msefast_tensor_commit");
 }
+
+#ifdef OSQ_MSE_DBG
+// development build only: read and clear the rounds kernel's phase accumulators (8 x uint64)
+extern "C" int osq_mse_dbg_read(unsigned long long* out) {
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(osq::g_mse_phase), sizeof(zero)) != hipSuccess) return -2;
+    return hipMemcpyToSymbol(HIP_SYMBOL(osq::g_mse_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -2;
+}
+#endif

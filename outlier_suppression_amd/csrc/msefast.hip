@@ -1681,10 +1681,13 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
         s.counters = reinterpret_cast<unsigned int*>(counters0 + static_cast<size_t>(i) * kOrderedCounterBytes);
         s.n_host = n[i];
         s.block_begin = static_cast<unsigned int>(total);
-        // a workgroup of a round takes g_ord_groups chunk groups (8192 elements each, fp32 and float64 alike) so that the loads of
-        // its next group travel under the arithmetic of the current one (aten_order.h, cascade_chunks_pipelined)
-        const int64_t groups = (g.chunks + 1) / 2 + 1;
-        s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>((groups + g_ord_groups - 1) / g_ord_groups, 1), kMaxBlocks));
+        // a workgroup of a round takes g_ord_groups chunk groups (8192 elements each, fp32 and float64 alike: 64 K elements at
+        // the default) so that the loads of its next group travel under the arithmetic of the current one (aten_order.h,
+        // cascade_chunks_pipelined); S = 32 (beyond 8.4 M elements): chunks of 16384 elements, 8 to a workgroup (measured best)
+        const int64_t chunk_elems = static_cast<int64_t>(g.S) * g.S * g.NC;
+        const int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
+        const int64_t groups = (g.chunks + per_wg - 1) / per_wg + 1;
+        s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>(groups, 1), kMaxBlocks));
         s.pad[0] = s.pad[1] = 0u;
         total += s.blocks;
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, job 17: the two bench lines of record at the round's last kernels (default flags; the driver's flags)
+# round 5, bench lines: the two bench lines of record at the round's last kernels (default flags; the driver's flags)
 mkdir -p gpurun_out/r05
 S=$SECONDS
 timeout 600 python bench.py > gpurun_out/r05/final_bench.json 2> gpurun_out/r05/final_bench.err

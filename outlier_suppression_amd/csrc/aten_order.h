@@ -207,7 +207,9 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
     const int cols = G << nc_shift;                         // block sums a group leaves, per sum
     // block sums held back in LDS behind the two tiles: pub[hold][NS * cols]
     const int room = (lds_values - 2 * NS * THREADS) / (NS * cols);
-    const int hold = room > kCascadeHold ? kCascadeHold : (room < 1 ? 1 : room);
+    // NS > 1 is the LSQ+ backward, whose eval stores dx element by element: its loop is not store-free whatever happens to the
+    // block sums, and a batch of one measured 2-8 % ahead there (same-box A/B)
+    const int hold = NS > 1 ? 1 : (room > kCascadeHold ? kCascadeHold : (room < 1 ? 1 : room));
     T* const pub = lds + 2 * NS * THREADS;
     Raw cur[R], nxt[R];
     // a lane with nothing to fetch (past the last chunk, no next group) reads rows 0..R-1 of chunk 0 instead: every such lane

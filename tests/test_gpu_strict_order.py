@@ -235,6 +235,39 @@ def test_ordered_rounds_equal_search_by_search(dev, simd_width):
         assert np.array_equal(N(a.last_nfev), N(b.last_nfev))
 
 
+@pytest.mark.parametrize("round_groups", [1, 3, 40, 64])
+def test_rounds_do_not_depend_on_the_workgroups_share_of_chunk_groups(dev, strict, round_groups):
+    """The chunk pipeline holds a batch of up to 16 groups' block sums in LDS and publishes them in one burst
+    (csrc/aten_order.h, cascade_chunks_pipelined): a workgroup with 1, 3, 40 or 64 groups (several batches, a partial last one,
+    groups past the last chunk) adds the same numbers -- the rounds' results equal the default share's bit for bit, fp32 and
+    float64 call, a site with an odd number of chunks and an S = 32 site (beyond 8.4 M elements) included."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.deferred import deferred_observation
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
+    g = torch.Generator().manual_seed(11)
+    shapes = [(32, 128, 768), (5, 77, 211), (3, 4097, 31), (36, 128, 2048)]                # 3.1 M; 81 K (odd chunks, open rows); 381 K; 9.4 M (S = 32)
+    batches = [[(torch.randn(*sh, generator=g) * (1 + 0.3 * b)).to(dev) for sh in shapes] for b in range(2)]
+
+    def run(groups):
+        ops.set_tuning("mse_round_groups", groups)
+        try:
+            obs = [AvgMSEFastObserver(bit=6, symmetric=False).to(dev) for _ in shapes]
+            for ob in obs:
+                object.__setattr__(ob, "_defer_ok", True)
+            with deferred_observation() as sites:
+                for b in range(2):
+                    for ob, x in zip(obs, batches[b]):
+                        ob(x, None, 1)
+                    sites.flush()
+            return [(N(ob.min_val).copy(), N(ob.max_val).copy(), N(ob.last_nfev).copy()) for ob in obs]
+        finally:
+            ops.set_tuning("mse_round_groups", 8)
+
+    want, got = run(8), run(round_groups)
+    for sh, a, b in zip(shapes, want, got):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b)), (sh, round_groups, a, b)
+
+
 def test_tensors_beyond_the_ordered_capacity_keep_order_free_sums(dev):
     """The reference-order kernels stop at a cascade step of 32 (2^23 rows: 268 M fp32 / 134 M float64 elements, aten_order.h);
     a larger tensor takes the order-free sums for that call -- same numbers as set_strict(False) -- and the default tier is

@@ -271,14 +271,15 @@ __device__ __forceinline__ double sq_err_f64_rcp(float xf, double s, double y, d
 // clamp(rint(x / s), qmin - z, qmax - z) for an integer z (exact small-integer arithmetic in the reference's float64 chain
 // too).  The level is taken from an fp32 quotient u32 = x * RN32(1 / s), whose relative error is below 2^-23: for |u| <= 513
 // (the levels lie within +-512, checked by the caller) it is within 6.2e-5 of the float64 quotient, so rint agrees unless u32
-// lies within 5e-4 of a tie -- those elements (one in a thousand) take the exact float64 chain above; beyond the clamp range
+// lies within 1e-4 of a tie (0.5 - 0.4999 > 6.2e-5) -- those elements, one in five thousand, take the exact float64 chain above
+// (a 5e-4 guard measured the same: the rounds are not bound by their VALU work); beyond the clamp range
 // either rounding saturates to the same level (+-inf included).  The dequantised value, the difference and the square are
 // the reference's float64 operations: c * s, - x, squared ((-d)^2 = d^2 exactly).  6 fp32 + 6 float64 operations instead of 15.
 __device__ __forceinline__ double sq_err_f64_lean(float xf, double s, double y, float y32, float lo32, float hi32, double z, double qmin,
                                                   double qmax) {
     const float u = xf * y32;
     const float r = rintf(u);
-    if (fabsf(u - r) >= 0.4995f) return sq_err_f64_rcp(xf, s, y, z, qmin, qmax);      // false for NaN (u = +-inf): saturates below
+    if (fabsf(u - r) >= 0.4999f) return sq_err_f64_rcp(xf, s, y, z, qmin, qmax);      // false for NaN (u = +-inf): saturates below
     const float c = __builtin_amdgcn_fmed3f(r, lo32, hi32);       // the clamp as ONE instruction (lo32 <= hi32, r is not NaN here: fminf(fmaxf()) is three, two of them canonicalising moves)
     const double d = static_cast<double>(c) * s - static_cast<double>(xf);
     return d * d;

@@ -412,7 +412,7 @@ def test_lean_float64_term_equals_the_full_chain(dev, strict):
     cases.append([base, base * 1.1 + 0.01, base * 0.9])
     # values on a lattice of half-steps of scales the search is likely to visit, with offsets of a few ulps to either side
     lattice = (torch.arange(-40, 41, dtype=torch.float32)[None, :] + 0.5) * torch.tensor([0.05, 0.0625, 0.1, 0.3])[:, None]
-    ulps = torch.tensor([0.0, 1e-7, -1e-7, 3e-4, -3e-4, 6e-4, -6e-4])
+    ulps = torch.tensor([0.0, 1e-7, -1e-7, 2e-6, -2e-6, 5e-6, -5e-6, 1e-5, -1e-5, 3e-4, -3e-4, 6e-4, -6e-4])     # round the guard (1e-4 absolute of a tie) on both sides
     tie = (lattice.reshape(-1, 1) * (1.0 + ulps[None, :])).reshape(-1)
     tie = torch.cat([tie, torch.tensor([0.0, -0.0, 1e-30, -1e-30, 3e4, -3e4, 1e-3, 77.7])])
     pad = torch.randn(4 * 32 * 64 - tie.numel(), generator=g) * 2

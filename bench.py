@@ -14,7 +14,12 @@ element for the fake-quant; the HBM traffic the launch really causes is reported
 Contract (driver): python bench.py --gpus N --steps K --warmup W.  N > 1: either launched by the driver as
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...``
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or called plainly as ``python bench.py --gpus N ...``, in
-which case it re-launches itself under torch.distributed.run (one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+which case it re-launches itself under torch.distributed.run (one rank per GPU, RCCL).
+
+Output (rank 0): the LAST stdout line is ONE compact JSON object (< 4 KB: headline, `roofline`, `cpu_baseline`, a
+`{config: wall_s, collective_s}` calibration summary; benchlib/line.py).  Everything else -- the per-kernel table
+(benchlib/kernels.py), the calibration flows with their phases (benchlib/calibration_flows.py), the probe regions -- is
+printed BEFORE it as `detail <section> <json>` lines and written to bench_detail.json beside this file.
 """
 import argparse
 import json
@@ -27,905 +32,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SHAPE = (256, 128, 768)          # BASELINE.json: BERT-base 256 x 128 x 768 activations
-PERCENTILE = 0.95
-HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-COPY_RATE_GBS = 6290.0   # float4 copy kernel on MI355X (MI355X_MICROARCH.md): the practical ceiling of a read + write stream
-GIB = float(1 << 30)
-
-
-def make_inputs(dev, n_buffers, seed):
-    """BASELINE.md section 4 synthetic inputs: randn with 6 seeded outlier hidden dims x20; lengths randint(8,129)."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    outliers = torch.randperm(SHAPE[2], generator=g)[:6]
-    lengths = torch.randint(8, 129, (SHAPE[0],), generator=g)
-    gd = torch.Generator(device=dev).manual_seed(seed)
-    xs = []
-    for _ in range(n_buffers):
-        x = torch.randn(*SHAPE, device=dev, generator=gd)
-        x[..., outliers.to(dev)] *= 20.0
-        xs.append(x)
-    return xs, lengths
-
-
-def _ops_order():
-    from outlier_suppression_amd import ops
-    return ops.reference_sum_order("mse")
-
-
-def make_quantizer(dev):
-    from types import SimpleNamespace as NS
-    from outlier_suppression_amd.quantization import Quantizer
-    cfg = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    q = Quantizer(None, cfg).to(dev)
-    q.observer.set_name("bert.encoder.layer.0.output.LayerNorm.layernorm_post_act_fake_quantize.observer")
-    q.observer.set_percentile(PERCENTILE)
-    q.enable_observer()
-    q.enable_fake_quant()
-    return q
-
-
-def cpu_baseline(seed, budget_s=20.0):
-    """The same step through oracle/torch_eager.py (the eager op chains the reference executes) on the
-    host cores, on the FULL [256,128,768] tensor of the GPU step (same generator recipe), repeated for
-    ~budget_s.  Stock torch ops on a many-core host get slower with every extra thread once the per-op
-    work is small, so a short probe picks the fastest thread count among {8, 16, 32, 64, all cores}."""
-    from oracle import torch_eager as TE
-    cores = os.cpu_count() or 1
-    g = torch.Generator().manual_seed(seed)
-    outliers = torch.randperm(SHAPE[2], generator=g)[:6]
-    lengths = torch.randint(8, 129, (SHAPE[0],), generator=g)
-    x = torch.randn(*SHAPE, generator=g)
-    x[..., outliers] *= 20.0
-    bytes_step = 4 * int(lengths.sum()) * SHAPE[2] + 8 * x.numel()
-
-    def run(n_threads, seconds, max_reps):
-        torch.set_num_threads(n_threads)
-        state = [torch.tensor(float("inf")), torch.tensor(float("-inf")), 0]
-        with torch.no_grad():
-            TE.observe_prune_then_quantize(x, lengths, PERCENTILE, state)     # warm-up
-            t0 = time.perf_counter()
-            reps = 0
-            while True:
-                TE.observe_prune_then_quantize(x, lengths, PERCENTILE, state)
-                reps += 1
-                if time.perf_counter() - t0 > seconds or reps >= max_reps:
-                    break
-            return (time.perf_counter() - t0) / reps, reps
-
-    # thread count: probed on the reference's own batch size (32 of the 256 sequences, 8.6 ms per step) -- a probe on
-    # the full tensor costs a second per repetition, and 256 threads on small ops cost a minute
-    xs_, ls_ = x[:32].contiguous(), lengths[:32]
-    bytes_slice = 4 * int(ls_.sum()) * SHAPE[2] + 8 * xs_.numel()
-
-    def run_slice(n_threads, seconds):
-        torch.set_num_threads(n_threads)
-        state = [torch.tensor(float("inf")), torch.tensor(float("-inf")), 0]
-        with torch.no_grad():
-            TE.observe_prune_then_quantize(xs_, ls_, PERCENTILE, state)
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < seconds:
-                TE.observe_prune_then_quantize(xs_, ls_, PERCENTILE, state)
-                reps += 1
-            return (time.perf_counter() - t0) / reps
-
-    candidates = sorted({c for c in (8, 16, 32, 64) if c <= cores})
-    probe = {}
-    for c in candidates:
-        probe[c] = run_slice(c, 0.5)
-        if probe[c] > 2.0 * min(probe.values()):     # wider only gets worse from here (oversubscribed small ops)
-            break
-    tried = sorted(probe)
-    best = min(c for c in tried if probe[c] <= 1.1 * min(probe.values()))
-    slice_dt = run_slice(best, 3.0)
-    dt, reps = run(best, max(budget_s - 5.0, 5.0), 200)
-    # Primary value: the reference's OWN batch size (32 sequences per observer call, exp/**/config.yaml), where its
-    # remove_padding is not yet quadratic -- the kinder figure for the CPU.  The full-tensor figure (the exact workload of
-    # the GPU line, 8 such batches in one call) is reported beside it.
-    return {"value": round(bytes_slice / slice_dt / GIB, 4), "unit": "GiB/s", "cores": best, "kind": "port",
-            "host_cores": cores,
-            "reference_batch": {"shape": [32, SHAPE[1], SHAPE[2]], "ms_per_step": round(slice_dt * 1e3, 3),
-                                "GiB_per_s": round(bytes_slice / slice_dt / GIB, 4), "algorithmic_bytes": bytes_slice},
-            "full_tensor": {"shape": list(SHAPE), "ms_per_step": round(dt * 1e3, 2), "GiB_per_s": round(bytes_step / dt / GIB, 4),
-                            "algorithmic_bytes": bytes_step, "reps": reps},
-            "thread_probe_ms_per_step": {str(c): round(probe[c] * 1e3, 2) for c in tried},
-            "sample": f"oracle/torch_eager.py (stock torch CPU ops = what the reference executes) on {best} of {cores} host cores, "
-                      f"same byte accounting as `value` of the GPU line; `value` = the reference's own batch size "
-                      f"([32,128,768] slices of the GPU tensor, {slice_dt * 1e3:.2f} ms per step, 3 s of repetitions); "
-                      f"full_tensor = the whole [256,128,768] step in one call ({reps} reps, {dt * 1e3:.1f} ms per step: "
-                      f"remove_padding's incremental torch.cat, observer.py:81-83, is quadratic in the batch)"}
-
-
-def kernel_table(dev, xs, lengths, reps=20):
-    """Every kernel of the path on the BASELINE tensor, one at a time, each launch timed by HIP events that ride
-    on its own dispatch packet (osq_time_next_launch), inputs cycled through buffers larger than the Infinity
-    Cache.  Algorithmic bytes per BASELINE.md: fake-quant 8 B/elem, observers 4 B per observed elem, LSQ+ backward
-    12 B/elem; the selection kernel reads the per-token extrema (8 B per token slot) and is latency/issue bound."""
-    import ctypes
-    from outlier_suppression_amd import _hip, ops
-    lib = _hip.load()
-    n = xs[0].numel()
-    valid = int(lengths.sum().item()) * SHAPE[2]
-    full = torch.full_like(lengths, SHAPE[1])
-    s = torch.tensor([0.7], device=dev)
-    zf = torch.tensor([31.0], device=dev)
-    mn = torch.tensor(float("inf"), device=dev)
-    mx = torch.tensor(float("-inf"), device=dev)
-    cur = torch.empty(2, device=dev)
-    gy = torch.randn_like(xs[0])
-    tok = ops.token_minmax(xs[0], 1, lengths)
-
-    def timed(which, fn):
-        out = []
-        for i in range(reps + 3):
-            a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            _hip.check(lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b)), "timing_events_create")
-            lib.osq_time_next_launch(which, a, b)
-            fn(i)
-            us = ctypes.c_float()
-            _hip.check(lib.osq_timing_elapsed_us(a, b, ctypes.byref(us)), "timing_elapsed_us")
-            lib.osq_timing_events_destroy(a, b)
-            if i >= 3:
-                out.append(us.value)
-        return sum(out) / len(out)
-
-    rows = {}
-    # What this clock reads for a launch that moves (almost) nothing: a 4 KiB fake-quant.  The site-size rows below sit on
-    # this floor (a [32,128,768] site is 6.6-25 MB: 1-4 us of HBM time): their bandwidth fractions say "too small a tensor for
-    # one launch", `us_above_floor` says how much of the launch is the kernel's own
-    tiny = torch.randn(1024, device=dev)
-    with torch.no_grad():
-        floor_us = timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(tiny, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
-    rows["launch floor (fake-quant of 4 KiB)"] = {"avg_us": round(floor_us, 2),
-                                                  "bound": "launch: dispatch + one HBM round trip + completion, as the dispatch events see it"}
-
-    def add(name, us, nbytes):
-        if "token_select" in name:     # two workgroups per problem on one CU each: exact order statistics, not a stream
-            rows[name] = {"avg_us": round(us, 2), "bound": "one CU per side: VALU issue + LDS atomic rate (not HBM)",
-                          "token_slots_MB": round(nbytes / 1e6, 2), "us_above_floor": round(us - floor_us, 2)}
-            return
-        rows[name] = {"avg_us": round(us, 2), "bound": "hbm", "algorithmic_MB": round(nbytes / 1e6, 1),
-                      "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3),
-                      "us_above_floor": round(us - floor_us, 2)}
-
-    with torch.no_grad():
-        add("fake_quant_forward", timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(
-            xs[i % len(xs)], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * n)
-        add("observe_flat (MinMax / AvgMinMax, no mask)", timed(_hip.TIME_OBSERVE_FLAT, lambda i: ops.observe_flat(
-            xs[i % len(xs)], ops.UPDATE_RUNNING, 0, mn, mx, 0, 63, False)), 4 * n)
-        add("token_minmax, all tokens", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xs[i % len(xs)], 1, full)), 4 * n)
-        add("token_minmax, bench lengths", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xs[i % len(xs)], 1, lengths)), 4 * valid)
-        add("token_select p=0.95 (32768 slots)", timed(_hip.TIME_TOKEN_SELECT, lambda i: ops.token_range_finalize(
-            tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
-            8 * SHAPE[0] * SHAPE[1])
-        # BASELINE.md section 2's "observer forward" row: the north-star observer ALONE (AvgPruneMinMaxObserver, fake-quant off
-        # -- the state of every observer pass of token-wise clipping) = the two launches above, back to back
-        for tag_, mm, nb in (("bench lengths", "token_minmax, bench lengths", 4 * valid), ("all tokens", "token_minmax, all tokens", 4 * n)):
-            us = rows[mm]["avg_us"] + rows["token_select p=0.95 (32768 slots)"]["avg_us"]
-            rows[f"observer alone (AvgPruneMinMax p=0.95: token_minmax + token_select), {tag_}"] = {
-                "avg_us": round(us, 2), "bound": "hbm + one CU per side for the selection", "algorithmic_MB": round(nb / 1e6, 1),
-                "GBps": round(nb / us / 1e3, 1), "frac_of_8TBps": round(nb / us / 1e3 / HBM_PEAK_GBS, 3),
-                "note": "sum of the two launches' own durations; the kernel boundary between them (~1.7 us) is not in it"}
-        # the default backward adds the two parameter gradients in float64 and rounds once (order-free); set_strict(backward=True)
-        # adds autograd's four fp32 sums in ATen's one-thread order (bit-equal to the reference's CPU run, 1.3x slower)
-        prev_order = ops.reference_sum_order("bwd")
-        ops.set_tuning("bwd_sum_order", 0)
-        try:
-            add("lsq_plus_backward (default: order-free parameter gradients)", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
-                xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
-            ops.set_tuning("bwd_sum_order", 8)
-            add("lsq_plus_backward (set_strict(backward=True): gradients summed in the reference's order)", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
-                xs[i % len(xs)], gy, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * n)
-        finally:
-            ops.set_tuning("bwd_sum_order", prev_order)
-        # LayerNorm site of a quantized block: GammaResidual -> split LayerNorm -> + beta/gamma -> fake-quant, one launch
-        gamma = torch.rand(SHAPE[2], device=dev) + 0.5
-        shift = torch.randn(SHAPE[2], device=dev)
-        quant = (s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
-        add("residual+layernorm+fake_quant (one launch)", timed(_hip.TIME_LAYERNORM, lambda i: ops.residual_layernorm_fake_quant(
-            xs[i % len(xs)], gy, gamma, None, shift, 1e-5, quant)), 12 * n)
-        # the same site as the eager sequence (4 launches; stream-order events around the whole sequence)
-        import torch.nn.functional as F
-        ev = []
-        for i in range(reps + 3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = ops.gamma_residual(xs[i % len(xs)], gy, gamma)
-            r = F.layer_norm(r, (SHAPE[2],), None, None, 1e-5)
-            r += shift
-            r = ops.fake_quant_per_tensor(r, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)
-            e1.record()
-            ev.append((e0, e1))
-        torch.cuda.synchronize()
-        seq_us = sum(a.elapsed_time(b) for a, b in ev[3:]) / reps * 1e3
-        # BASELINE.md section 4 secondary slices: one calibration site of BERT-base at batch 32 (launch-latency regime)
-        for shp, sp in (((32, 128, 768), 1), ((32, 12, 128, 128), 2), ((32, 128, 3072), 1), ((32, 384, 768), 1)):
-            xsite = torch.randn(*shp, device=dev)
-            lsite = torch.randint(8, shp[sp] + 1, (shp[0],), device=dev)
-            vsite = int(lsite.sum().item()) * (xsite.numel() // shp[0] // shp[sp])
-            tag = "x".join(str(d) for d in shp)
-            add(f"site {tag}: fake_quant_forward", timed(_hip.TIME_FAKE_QUANT, lambda i: ops.fake_quant_per_tensor(
-                xsite, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * xsite.numel())
-            add(f"site {tag}: token_minmax (masked)", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(xsite, sp, lsite)), 4 * vsite)
-            tk = ops.token_minmax(xsite, sp, lsite)
-            add(f"site {tag}: token_select p=0.95", timed(_hip.TIME_TOKEN_SELECT, lambda i: ops.token_range_finalize(
-                tk[0], tk[1], tk[2], tk[3], tk[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)),
-                8 * shp[0] * shp[sp])
-            # learn-scale's backward at site size, both summation tiers (12 B per element: x, grad_out in, dx out)
-            gsite = torch.randn_like(xsite)
-            prev_order = ops.reference_sum_order("bwd")
-            try:
-                for order, what in ((0, "default: order-free"), (8, "set_strict(backward=True): reference order")):
-                    ops.set_tuning("bwd_sum_order", order)
-                    add(f"site {tag}: lsq_plus_backward ({what})", timed(_hip.TIME_LSQ_BACKWARD, lambda i: ops.lsq_backward_per_tensor(
-                        xsite, gsite, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 12 * xsite.numel())
-            finally:
-                ops.set_tuning("bwd_sum_order", prev_order)
-        # ---- rows of SURVEY.md section 8d that have no dispatch-attached timer: stream-order events around the call
-        # (they include one kernel boundary, ~2 us)
-        def ev_timed(fn, inner=1):
-            ev = []
-            for i in range(reps + 3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(inner):
-                    fn(i)
-                e1.record()
-                ev.append((e0, e1))
-            torch.cuda.synchronize()
-            return sum(a.elapsed_time(b) for a, b in ev[3:]) / reps * 1e3 / inner
-
-        def add_ev(name, us, nbytes, note=None):
-            rows[name] = {"avg_us": round(us, 2), "bound": "hbm", "algorithmic_MB": round(nbytes / 1e6, 1),
-                          "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3),
-                          "timer": "stream events around the call (one kernel boundary included)"}
-            if note:
-                rows[name]["note"] = note
-
-        # the whole step as ONE launch, by mask
-        from outlier_suppression_amd.quantization import Quantizer
-        qf = make_quantizer(dev)
-        for tag, lens in (("bench lengths", lengths), ("all tokens valid", full)):
-            v = int(lens.sum().item()) * SHAPE[2]
-            add(f"fused observe+fake-quant step, {tag}", timed(_hip.TIME_FUSED_STEP, lambda i: qf(xs[i % len(xs)], lens, 1)), 4 * v + 8 * n)
-        # attention head-split views of [B,T,h,d] memory (quant_bert.py:128-150): q / v as [B,h,T,d], k as [B,h,d,T]
-        mem = torch.randn(32, 128, 12, 64, device=dev)
-        l32 = torch.randint(8, 129, (32,), device=dev)
-        for tag, view, sp in (("32x12x128x64 (q/v view of [B,T,h,d])", mem.permute(0, 2, 1, 3), 2),
-                              ("32x12x64x128 (key view, strided)", mem.permute(0, 2, 3, 1), 3)):
-            add(f"site {tag}: fake_quant_forward", timed(_hip.TIME_FAKE_QUANT_STRIDED, lambda i: ops.fake_quant_per_tensor(
-                view, s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4)), 8 * mem.numel())
-            vv = int(l32.sum().item()) * 12 * 64
-            add(f"site {tag}: token_minmax (masked)", timed(_hip.TIME_TOKEN_MINMAX, lambda i: ops.token_minmax(view, sp, l32)), 4 * vv)
-        # weights: per-channel fake-quant (6-bit symmetric, ch_axis 0) and per-channel MinMax observer (+ qparams), one launch each
-        for shp in ((768, 768), (3072, 768), (30522, 768)):
-            w = torch.randn(*shp, device=dev) * 0.05
-            ws_, wz_ = torch.full((shp[0],), 0.01, device=dev), torch.zeros(shp[0], dtype=torch.int32, device=dev)
-            wmn, wmx = torch.full((shp[0],), float("inf"), device=dev), torch.full((shp[0],), float("-inf"), device=dev)
-            tag = "x".join(str(d) for d in shp)
-            add(f"weight {tag}: fake_quant per-channel", timed(_hip.TIME_FAKE_QUANT_CHANNEL, lambda i: ops.fake_quant_per_channel(
-                w, ws_, wz_, 0, -32, 31)), 8 * w.numel())
-            add(f"weight {tag}: MinMaxObserver per-channel (+qparams)", timed(_hip.TIME_OBSERVE_CHANNELS, lambda i: ops.observe_channels(
-                w, 0, ops.UPDATE_RUNNING, 0, wmn, wmx, -32, 31, True, ops.QParamSink(ws_, wz_))), 4 * w.numel())
-            if shp[0] <= 3072:
-                us = timed(_hip.TIME_MSEFAST_ROWS, lambda i: ops.msefast_rows(w, 0, -8, 7, True, "no", False))
-                rows[f"weight {tag}: MSEFast 4-bit symmetric per-channel (one bounded-Brent search per row)"] = {
-                    "avg_us": round(us, 2), "bound": "compute (row in registers, ~15 loss evaluations per row)",
-                    "algorithmic_MB": round(4 * w.numel() / 1e6, 1), "rows": shp[0]}
-        # per-tensor MSEFast (configs[3] activations): one asymmetric search = 300-600 loss evaluations; resident form (one
-        # persistent launch, tensor in registers) against one launch per evaluation, second call (float64 arithmetic)
-        from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
-        for tag, shp in (("32x128x768", (32, 128, 768)), ("32x128x3072", (32, 128, 3072))):
-            xm = torch.randn(*shp, device=dev)
-            xm[..., 5] *= 20
-            res = {}
-            for resident in (1, 0):
-                ops.set_tuning("mse_resident", resident)
-                try:
-                    ob = AvgMSEFastObserver(bit=6, symmetric=False).to(dev)
-                    ob(xm, l32, 1)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    ob(xm, l32, 1)
-                    torch.cuda.synchronize()
-                    res[resident] = ((time.perf_counter() - t0) * 1e6, int(ob.last_nfev.sum().item()))
-                finally:
-                    ops.set_tuning("mse_resident", 1)
-            rows[f"site {tag}: AvgMSEFast per-tensor 6-bit asymmetric search (masked)"] = {
-                "wall_us": round(res[1][0], 1), "loss_evaluations": res[1][1], "us_per_evaluation": round(res[1][0] / max(res[1][1], 1), 2),
-                "one_launch_per_evaluation_us_per_evaluation": round(res[0][0] / max(res[0][1], 1), 2),
-                "bound": "per evaluation: fp64 VALU work on the resident tensor + one exchange through memory (~2 us) + the serial Brent step (~1.5 us)"}
-        # Infinity Cache: the same 96 MiB tensor over and over (x + y = 192 MiB < 256 MiB) against the buffer cycle above
-        warm_y = ev_timed(lambda i: ops.fake_quant_per_tensor(xs[0], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
-        add_ev("fake_quant_forward, warm (same input every launch; Infinity Cache)", warm_y, 8 * n)
-        cold_y = ev_timed(lambda i: ops.fake_quant_per_tensor(xs[i % len(xs)], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
-        add_ev("fake_quant_forward, cold (4 inputs cycled, 384 MiB)", cold_y, 8 * n)
-        rows["same site, eager sequence (gamma_residual, layer_norm, add, fake_quant)"] = {
-            "avg_us": round(seq_us, 2), "bound": "hbm", "algorithmic_MB": round(12 * n / 1e6, 1), "GBps": round(12 * n / seq_us / 1e3, 1),
-            "frac_of_8TBps": round(12 * n / seq_us / 1e3 / HBM_PEAK_GBS, 3)}
-    return rows
-
-
-# OSQ_BENCH_SHORT=1: the calibration flows with 2 batches, 3 candidates and 1 learn-scale epoch, run once -- the same kernels
-# in the same states, a few thousand dispatches instead of a few hundred thousand: what the PMC passes of
-# tools/collect_calibration_profiles.sh profile (rocprofv3 --pmc costs milliseconds per dispatch).  Never a measured wall-clock.
-SHORT = os.environ.get("OSQ_BENCH_SHORT") == "1"
-
-
-class CollectiveClock:
-    """Seconds a calibration flow spends inside collectives at N > 1, per phase: a synchronised host-side bracket round
-    every calibration.gather_batch_table / torch.distributed.all_reduce / all_gather_into_tensor the package issues while
-    the clock is installed (the bracket's own synchronisations are part of what is reported: the exchange is latency-
-    bound, a few KB per call).  N = 1: nothing is patched and every figure is 0.0."""
-
-    def __init__(self, world):
-        self.world, self.total, self.calls, self._last, self.phases = world, 0.0, 0, 0.0, {}
-        self._saved = []
-
-    def _wrap(self, fn):
-        def timed(*a, **k):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r = fn(*a, **k)
-            torch.cuda.synchronize()
-            self.total += time.perf_counter() - t
-            self.calls += 1
-            return r
-        return timed
-
-    def __enter__(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            from outlier_suppression_amd import calibration
-            for mod, name in ((calibration, "gather_batch_table"), (dist, "all_reduce"), (dist, "all_gather_into_tensor")):
-                self._saved.append((mod, name, getattr(mod, name)))
-                setattr(mod, name, self._wrap(getattr(mod, name)))
-        return self
-
-    def __exit__(self, *exc):
-        for mod, name, fn in self._saved:
-            setattr(mod, name, fn)
-        self._saved = []
-
-    def mark(self, phase):
-        """Close a phase: what the collectives took since the previous mark."""
-        self.phases[phase] = round(self.phases.get(phase, 0.0) + self.total - self._last, 4)
-        self._last = self.total
-
-    def report(self):
-        return {"collective_s": round(self.total, 4), "collective_calls": self.calls, "collective_phases_s": dict(self.phases)}
-
-
-def quantizer_exchange_check(model, world, share, dev):
-    """After a sharded calibration every rank must hold the same scale / zero_point bits for every quantizer (SURVEY 8e:
-    the gathered tables are replayed in global batch order on every rank).  Gathers a checksum of all of them."""
-    from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
-    acc, n = 0, 0
-    for _, m in model.named_modules():
-        if isinstance(m, QuantizeBase) and getattr(m, "scale", None) is not None:
-            for t in (m.scale, m.zero_point):
-                if t is None:
-                    continue
-                tt = t.detach().reshape(-1)
-                bits = tt.view(torch.int32) if tt.dtype in (torch.float32, torch.int32) else tt.to(torch.float32).view(torch.int32)
-                acc = (acc * 1000003 + int(bits.to(torch.int64).sum().item())) % (1 << 61)
-                n += tt.numel()
-    if world == 1:
-        return {"ranks": 1, "parameters_compared": n, "same_bits_on_every_rank": True}
-    import torch.distributed as dist
-    mine = torch.tensor([acc], dtype=torch.int64, device="cpu" if share else dev)
-    every = torch.empty(world, dtype=torch.int64, device=mine.device)
-    dist.all_gather_into_tensor(every, mine)
-    same = bool((every == mine).all().item())
-    if not same:
-        raise SystemExit(f"bench.py: ranks ended a sharded calibration with different quantizer parameters: checksums {every.tolist()}")
-    return {"ranks": world, "parameters_compared": n, "same_bits_on_every_rank": same}
-
-
-def device_identity(dev):
-    """Something that tells two physical GPUs apart: the device's UUID, else its PCI address."""
-    p = torch.cuda.get_device_properties(dev)
-    uuid = getattr(p, "uuid", None)
-    pci = ":".join(str(getattr(p, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    return f"{uuid}|{pci}|{p.name}"
-
-
-def calibration_wall_clock(dev, rank, world, search="cached"):
-    """BASELINE configs[1]: BERT-base (random init, HF default config), CoLA-shaped calibration set
-    (256 samples = 8 batches of [32, 128], synthetic ids / lengths), twc_fine_gamma W6A6:
-    gamma migration -> weight calibration -> token-wise-clipping grid (30 candidates, step 0.01) ->
-    LSQ+ learn-scale (3 epochs, lr 1e-5).  Clock: batches resident on device -> every quantizer has
-    its final scale / zero_point.  N > 1: the grid search is sharded (batch b on rank b mod N, one
-    all-gather of statistics and one of losses per candidate); learn-scale is sequential Adam: every step
-    is split inside the batch (32/N samples per rank, gradients averaged by one small all-reduce;
-    DESIGN.md section 6)."""
-    import logging
-    from types import SimpleNamespace as NS
-    import torch.distributed as dist
-    from transformers import BertConfig, BertForSequenceClassification
-    from outlier_suppression_amd import calibration, token_wise_clipping as TWC
-    from outlier_suppression_amd.gamma_migration import delay_ln
-    from outlier_suppression_amd.quant_model import quantize_model
-    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
-    from outlier_suppression_amd.quantization.state import set_observer_name
-
-    logging.getLogger("transformer").setLevel(logging.WARNING)
-    torch.manual_seed(0)
-    cfg = BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    fp = BertForSequenceClassification(cfg).eval().to(dev)
-    g = torch.Generator().manual_seed(42)
-    n_batches, B, T = (2 if SHORT else 8), 32, 128
-    batches = []
-    for _ in range(n_batches):
-        L = torch.randint(8, T + 1, (B,), generator=g)
-        mask = (torch.arange(T)[None, :] < L[:, None]).long()
-        ids = torch.randint(1000, 30000, (B, T), generator=g) * mask
-        batches.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev),
-                        "token_type_ids": torch.zeros_like(ids).to(dev)})
-    a_q = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    TWC.task_type, TWC.model_type = "glue", "bert"
-    mine = calibration.shard_batches(n_batches, rank, world)
-    model = None
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
-    clock = None
-
-    def run(search, strict_learn=False):
-        nonlocal model, clock
-        model = quantize_model(fp, w_q, a_q).to(dev)      # deep copy of the FP model, as quant_model.py:44-48: fp stays pristine
-        phases = {}
-        with CollectiveClock(world) as clock:
-            return _run(search, strict_learn, phases)
-
-    def _run(search, strict_learn, phases):
-        nonlocal model
-        sync()
-        t_start = t0 = time.perf_counter()
-        with torch.no_grad():
-            if world > 1:    # FP targets: each rank runs its own batches, the [batches, 32, 2] logits are all-gathered
-                rows = (n_batches + world - 1) // world
-                mine_out = [model(**batches[b])[0].detach() for b in mine]
-                local = torch.zeros(rows, *mine_out[0].shape, device=dev)
-                for j, o in enumerate(mine_out):
-                    local[j] = o
-                fp_output = list(calibration.gather_batch_table(local, n_batches).unbind(0))
-            else:
-                fp_output = [model(**b)[0].detach() for b in batches]
-        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("fp_outputs")
-        m = delay_ln(model, NS(a_qconfig=a_q, w_qconfig=w_q), NS(model_type="bert", task_type="glue"))
-        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("gamma_migration")
-        enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
-        with torch.no_grad():
-            m(**batches[0])
-        disable_all(m)
-        set_observer_name(m)
-        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("weight_calibration")
-        grid = {"iters": 3 if SHORT else 30, "step": 0.01}       # cac_step_iters(6 bit, bs 32, T 128), token_wise_clipping.py:118-129
-        if search == "cached":
-            ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid,
-                                          n_batches=n_batches)
-        else:
-            ratio = TWC.find_ratio(NS(model=m), batches, fp_output, grid)
-        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("twc_grid_search")
-        # N > 1: every Adam step is split inside the batch (32/N samples per rank, averaged gradients)
-        (TWC.learn_scale if strict_learn else TWC.learn_scale_sharded)(NS(model=m), batches, fp_output, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
-        sync(); phases["learn_scale"] = time.perf_counter() - t0; clock.mark("learn_scale")
-        model = m
-        return time.perf_counter() - t_start, phases, ratio
-
-    if SHORT:
-        wall, phases, ratio = run(search)
-        return {"config": "configs[1] SHORT (profiling only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
-
-    # The whole calibration runs twice on fresh copies of the model: the first pass also pays the process's one-time
-    # costs (rocBLAS / hipBLASLt kernel loading and heuristics for forward and backward shapes, allocator growth,
-    # first RCCL collectives) and is reported separately; the second is the steady-state wall-clock.
-    first_wall, first_phases, _ = run(search)
-    wall, phases, ratio = run(search)
-    out = {"config": "configs[1]: BERT-base CoLA twc_fine_gamma W6A6, 256 samples (8 x [32,128]), random-init weights, synthetic ids",
-           "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}, "best_percentile": ratio,
-           "first_run_wall_s": round(first_wall, 3), "first_run_phases_s": {k: round(v, 3) for k, v in first_phases.items()},
-           "twc_candidates": 30, **clock.report(), "exchange_check": quantizer_exchange_check(model, world, share, dev),
-           "search": ("cached per-token extrema + 1 re-threshold launch per candidate, sharded over ranks" if search == "cached"
-                      else "literal reference order: 2 model passes per candidate"),
-           "learn_scale": ("sequential Adam, one process" if world == 1 else
-                           f"sequential Adam, every step data-parallel inside the batch ({B // world} samples per rank, "
-                           "one all-reduce of the 196 gradients per step)" if B % world == 0 else "replicated on every rank"),
-           "n_gpus": world}
-    if world > 1:
-        # SURVEY 8e: bit-for-bit parity with the sequential reference needs learn-scale replicated on every rank; the line
-        # above ran the rounding-close data-parallel variant, this is the strict one on the same warm process
-        strict_wall, strict_phases, _ = run(search, strict_learn=True)
-        out["strict_replicated_learn_scale"] = {"wall_s": round(strict_wall, 3), "learn_scale_s": round(strict_phases["learn_scale"], 3)}
-    return out
-
-
-def calibration_plain(dev, rank, world):
-    """BASELINE configs[0]: BERT-base CoLA PTQ with the plain MinMax flow (exp/bert_ptq/minmax/cola/config.yaml: W6 per-channel
-    MinMaxObserver, A6 AvgMinMaxObserver + FixedFakeQuantize, no token-wise clipping, no gamma migration), 256 samples = 8 x
-    [32,128], through ptq.run (ptq_glue_quant.py:228-251).  N > 1: the observer pass is sharded (calibration.calibrate_sharded:
-    batch b on rank b mod N, one all-gather of the per-batch statistics, replay in batch order -- bit-identical)."""
-    import logging
-    from types import SimpleNamespace as NS
-    import torch.distributed as dist
-    import transformers as T
-    from outlier_suppression_amd import calibration, ptq
-    from outlier_suppression_amd.quant_model import quantize_model
-    from outlier_suppression_amd.quantization import enable_calibration_woquantization, enable_quantization
-    logging.getLogger("transformer").setLevel(logging.WARNING)
-    torch.manual_seed(0)
-    g = torch.Generator().manual_seed(100)
-    fp = T.BertForSequenceClassification(T.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).eval().to(dev)
-    batches = []
-    for _ in range(8):
-        L = torch.randint(8, 129, (32,), generator=g)
-        mask = (torch.arange(128)[None, :] < L[:, None]).long()
-        ids = torch.randint(1000, 29000, (32, 128), generator=g) * mask
-        batches.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev), "token_type_ids": torch.zeros_like(ids).to(dev)})
-    section = ptq.SHIPPED_QUANT_SECTIONS["minmax"]
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-    res = {}
-    for rep in range(2):                       # the second run is the steady state (allocator, library handles)
-        model = quantize_model(fp, section.w_qconfig, section.a_qconfig).to(dev)
-        clock = CollectiveClock(world).__enter__()
-        sync()
-        t0 = time.perf_counter()
-        if world == 1:
-            with torch.no_grad():
-                fp_in, fp_out = ptq.prepare_input_output(model, batches)
-                t1 = time.perf_counter()
-                model = ptq.run(model, fp_in, fp_out, section, NS(model_type="bert", task_type="glue"))
-        else:
-            with torch.no_grad():
-                t1 = time.perf_counter()
-                enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
-                model(**batches[0])
-                enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
-                mine = calibration.shard_batches(len(batches), rank, world)
-                calibration.calibrate_sharded(model, [batches[b] for b in mine], lambda m, b: m(**b), n_batches=len(batches))
-                enable_quantization(model)
-        sync()
-        res = {"wall_s": round(time.perf_counter() - t0, 4), "fp_outputs_s": round(t1 - t0, 4)}
-        clock.mark("observer_pass")
-        res.update(clock.report())
-        clock.__exit__()
-        res["exchange_check"] = quantizer_exchange_check(model, world, os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check"), dev)
-    return {"config": "configs[0]: BERT-base CoLA PTQ, plain MinMax flow W6A6 (exp/bert_ptq/minmax), 256 samples (8 x [32,128]), "
-                      "random-init weights, synthetic ids", **res, "n_gpus": world,
-            "observer_pass": "every site of a forward reduced together (quantization/deferred.py)" if world == 1 else
-                             "sharded over ranks, one all-gather of the per-batch statistics"}
-
-
-def calibration_extra(dev, rank, world, which):
-    """Calibration wall-clock (SURVEY.md section 8d Metric 2) of BASELINE configs[2], [3], [4] at the reference's sizes,
-    random-init weights and synthetic ids; clock: batches resident on device -> every quantizer has its final
-    scale / zero_point.  One run each (the process is warm from configs[1]); phases as section 8d lists them.
-
-      2  BERT-base SQuAD-v1 twc_fine_gamma W6A6: T = 384, 256 features = 8 x [32, 384], 90 candidates (step 0.0033:
-         cac_step_iters(6 bit, bs 32, T 384), token_wise_clipping.py:118-129), masked two-headed loss, learn-scale at
-         batch 8 with re-prepared targets (ptq_qa_quant.py:235-277);
-      3  RoBERTa-base MNLI W4A6: weights 4-bit symmetric per output channel with MSEFastObserver (one bounded-Brent search
-         per row: 134 K rows, observer.py:496-517), activations 6-bit AvgMSEFastObserver, 8 x [32, 128];
-      4  BART XSum twc_fine_gamma W6A6, encoder + decoder: bart-base dimensions as the reference's shipped config uses
-         (exp/xsum/twc_fine_gamma/config.yaml:44; BASELINE names bart-large), 64 x ([4, 1024] source, [4, 62] target),
-         30 candidates, learn-scale 3 epochs (ptq_summ_quant.py:124-154).
-    N > 1: the grid search is sharded (batch b on rank b mod N); the statistics / loss tables are all-gathered per candidate
-    (calibration.gather_batch_table); learn-scale runs data-parallel inside each batch when the batch divides over the ranks
-    (TWC.learn_scale_sharded: configs 2 at batch 8; config 4's batches of 4 on 8 ranks: one sample on each of the first four); config 3's MSEFast observers keep
-    state that the next batch's arithmetic depends on, so there the SITES are dealt over the ranks (calibration.calibrate_owned_sites)."""
-    import logging
-    from types import SimpleNamespace as NS
-    import torch.distributed as dist
-    import transformers as T
-    from outlier_suppression_amd import calibration, token_wise_clipping as TWC
-    from outlier_suppression_amd.gamma_migration import delay_ln
-    from outlier_suppression_amd.quant_model import quantize_model
-    from outlier_suppression_amd.quantization import enable_calibration_woquantization, disable_all
-    from outlier_suppression_amd.quantization.state import set_observer_name
-
-    logging.getLogger("transformer").setLevel(logging.WARNING)
-    torch.manual_seed(which)
-    g = torch.Generator().manual_seed(100 + which)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    share = os.environ.get("OSQ_BENCH_SHARE_GPU") in ("1", "check")
-    twc_a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    twc_w = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    phases, out = {}, {}
-
-    def masked_batches(n_batches, B, Tn, vocab, lo):
-        res = []
-        for _ in range(n_batches):
-            L = torch.randint(lo, Tn + 1, (B,), generator=g)
-            mask = (torch.arange(Tn)[None, :] < L[:, None]).long()
-            ids = torch.randint(1000, vocab - 1000, (B, Tn), generator=g) * mask + (1 - mask)
-            res.append({"input_ids": ids.to(dev), "attention_mask": mask.to(dev)})
-        return res
-
-    if which == 2:
-        cfg = T.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-        fp = T.BertForQuestionAnswering(cfg).eval().to(dev)
-        batches = masked_batches(2 if SHORT else 8, 32, 384, 30522, 64)
-        for b in batches:
-            b["token_type_ids"] = torch.zeros_like(b["input_ids"])
-        # OSQ_BENCH_SQUAD_CANDIDATES: test hook (tests/test_gpu_sharded.py runs eight ranks on one GPU); the measured config has 90
-        task, mtype, grid = "squad", "bert", {"iters": int(os.environ.get("OSQ_BENCH_SQUAD_CANDIDATES", "3" if SHORT else "90")), "step": 0.0033}
-        out["config"] = "configs[2]: BERT-base SQuAD-v1 twc_fine_gamma W6A6, 256 features (8 x [32,384]), 90 candidates, learn-scale at batch 8"
-    elif which in (4, 5):
-        # 4: bart-LARGE dimensions, what BASELINE.json's configs[4] names; 5: bart-base dimensions, what the reference's shipped
-        # config points at (exp/xsum/twc_fine_gamma/config.yaml:44) -- both run by default
-        d_model, layers, heads, ffn = (768, 6, 12, 3072) if which == 5 else (1024, 12, 16, 4096)
-        cfg = T.BartConfig(d_model=d_model, encoder_layers=layers, decoder_layers=layers, encoder_attention_heads=heads,
-                           decoder_attention_heads=heads, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, max_position_embeddings=1024,
-                           dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
-        fp = T.BartForConditionalGeneration(cfg).eval().to(dev)
-        batches = masked_batches(4 if SHORT else 64, 4, 1024, 50265, 256)
-        for b in batches:
-            DL = torch.randint(16, 63, (4,), generator=g)
-            DL[0] = 62
-            dm = (torch.arange(62)[None, :] < DL[:, None]).long()
-            b["decoder_input_ids"] = (torch.randint(1000, 49000, (4, 62), generator=g) * dm + (1 - dm)).to(dev)
-            b["decoder_attention_mask"] = dm.to(dev)
-        task, mtype, grid = "summ", "bart", {"iters": 3 if SHORT else 30, "step": 0.01}
-        out["config"] = ("configs[4]: BART XSum twc_fine_gamma W6A6 encoder+decoder, " +
-                         ("bart-base dimensions (the reference's shipped config)" if which == 5 else
-                          "bart-LARGE dimensions (d 1024, 16 heads, 12 + 12 layers, ffn 4096: what BASELINE.json names)") +
-                         ", 256 samples (64 x ([4,1024] source, [4,62] target)), 30 candidates, learn-scale 3 epochs")
-    else:
-        cfg = T.RobertaConfig(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, num_labels=3,
-                              hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-        fp = T.RobertaForSequenceClassification(cfg).eval().to(dev)
-        batches = masked_batches(2 if SHORT else 8, 32, 128, 50265, 8)
-        w_q = NS(quantizer="FixedFakeQuantize", observer="MSEFastObserver", bit=4, symmetric=True, ch_axis=0)
-        a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMSEFastObserver", bit=6, symmetric=False, ch_axis=-1)
-        from outlier_suppression_amd.quantization.fake_quant import QuantizeBase
-        def run_once():
-            model = quantize_model(fp, w_q, a_q).to(dev)
-            phases = {}
-            sync()
-            t_start = t0 = time.perf_counter()
-            fwd = lambda m, b: m(**b)
-            # SITES are dealt over the ranks (calibration.calibrate_owned_sites): every rank runs every forward, an observer
-            # is searched by its owner only -- all its batches in order, bit-identical to one process -- and one all-gather
-            # hands every rank every site's final statistics / scale / zero_point
-            enable_calibration_woquantization(model, quantizer_type="weight_fake_quant")
-            info_w = calibration.calibrate_owned_sites(model, batches[:1], fwd, select=lambda n: "weight_fake_quant" in n)
-            sync(); phases["weight_calibration_msefast_per_channel"] = time.perf_counter() - t0; t0 = time.perf_counter()
-            enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
-            info_a = calibration.calibrate_owned_sites(model, batches, fwd)
-            sync(); phases["activation_calibration_msefast_per_tensor"] = time.perf_counter() - t0
-            return time.perf_counter() - t_start, phases, info_w, info_a, model
-
-        if SHORT:
-            wall, phases, info_w, info_a, model = run_once()
-            return {"config": "configs[3] SHORT (profiling only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
-        first_wall = run_once()[0]    # the second run is the steady state (code objects loaded, allocator grown, communicator built)
-        wall, phases, info_w, info_a, model = run_once()
-        # The default adds every per-tensor loss in the reference's one-thread order (outlier_suppression_amd.set_strict, ON by
-        # default): rounds of one launch per loss evaluation of ALL the forward's searches.  The order-free tier
-        # (set_strict(False): exact sums, one resident launch per group of searches) beside it: its wall-clock and how far
-        # its results are from the default's.
-        if os.environ.get("OSQ_BENCH_NO_STRICT") == "1":      # profiling runs of the DEFAULT flow (tools/collect_calibration_profiles.sh)
-            return {"config": "configs[3] (default flow only)", "wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()}}
-        import outlier_suppression_amd as osq
-        prev_width = _ops_order()                             # 8 / 16: the tier this process runs in (0: OSQ_STRICT=0, then this run repeats it)
-        osq.set_strict(False)
-        try:
-            free_wall, free_phases, _, _, free_model = run_once()
-        finally:
-            osq.set_strict(bool(prev_width), prev_width or 8)
-        order_free = {"wall_s": round(free_wall, 3), "phases_s": {k: round(v, 3) for k, v in free_phases.items()},
-                      "what": "set_strict(False): MSEFast losses as exact (order-free) sums, searches resident in one persistent launch per "
-                              "group of sites; the default above adds them in ATen's one-thread order (bit-equal to the reference run on a "
-                              "one-thread host, tests/test_gpu_strict_order.py); per-channel rows follow that order in either tier"}
-        # how far the two tiers' results are apart: relative difference of every activation quantizer's scale
-        d = [abs(a.scale.item() - b.scale.item()) / abs(b.scale.item())
-             for (_, a), (_, b) in zip([(n, m) for n, m in free_model.named_modules() if isinstance(m, QuantizeBase) and "act" in n],
-                                       [(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n])]
-        d.sort()
-        order_free["activation_scale_rel_diff_vs_default"] = {"median": d[len(d) // 2], "max": d[-1], "equal": sum(1 for v in d if v == 0.0), "sites": len(d)}
-        del free_model
-        mine_w = [q for (n, q), r in zip([(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "weight_fake_quant" in n],
-                                         info_w["owner"] or [0] * 10 ** 6) if r == rank]
-        rows = sum(int(q.observer.min_val.numel()) for q in mine_w)
-        evals = sum(int(q.observer.last_nfev.sum().item()) for q in mine_w if q.observer.last_nfev is not None)
-        act_q = [(n, m) for n, m in model.named_modules() if isinstance(m, QuantizeBase) and "act" in n]
-        mine_a = [q for (n, q), r in zip(act_q, info_a["owner"] or [0] * 10 ** 6) if r == rank]
-        act_evals = sum(int(q.observer.last_nfev.sum().item()) for q in mine_a if q.observer.last_nfev is not None)
-        return {"config": "configs[3]: RoBERTa-base MNLI W4A6, per-channel weights + MSEFast, 256 samples (8 x [32,128])",
-                "wall_s": round(wall, 3), "first_run_wall_s": round(first_wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
-                "collective_s": round(info_w["collective_s"] + info_a["collective_s"], 4),
-                "collective_phases_s": {"weight_calibration_msefast_per_channel": round(info_w["collective_s"], 4),
-                                        "activation_calibration_msefast_per_tensor": round(info_a["collective_s"], 4)},
-                "exchange_check": quantizer_exchange_check(model, world, share, dev), "order_free": order_free,
-                "weight_rows_searched_on_rank0": rows, "weight_loss_evaluations_on_rank0": evals,
-                "activation_sites": len(act_q), "activation_sites_on_rank0": len(mine_a),
-                "activation_loss_evaluations_last_batch_on_rank0": act_evals, "n_gpus": world,
-                "sharding": ("one process" if world == 1 else
-                             f"sites dealt over {world} ranks (calibration.calibrate_owned_sites: every rank runs every forward, each "
-                             "observer is searched by its owner over all batches in order; one all-gather of the final states)")}
-
-    TWC.task_type, TWC.model_type = task, mtype
-    n_batches = len(batches)
-    mine = calibration.shard_batches(n_batches, rank, world)
-    model = quantize_model(fp, twc_w, twc_a).to(dev)
-    clock = CollectiveClock(world).__enter__()
-    try:
-        def targets(bs):
-            res = []
-            with torch.no_grad():
-                for b in bs:
-                    o = model(**b)
-                    if task == "squad":
-                        keep = b["attention_mask"] == 1
-                        res.append([o[0][keep].detach(), o[1][keep].detach()])
-                    else:
-                        res.append(o[0][b["decoder_attention_mask"] == 1, :].detach())
-            return res
-        sync()
-        t_start = t0 = time.perf_counter()
-        fp_output = targets(batches)           # every rank: FP targets of all batches (cheap next to the search)
-        sync(); phases["fp_outputs"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("fp_outputs")
-        m = delay_ln(model, NS(a_qconfig=twc_a, w_qconfig=twc_w), NS(model_type=mtype, task_type=task))
-        sync(); phases["gamma_migration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("gamma_migration")
-        enable_calibration_woquantization(m, quantizer_type="weight_fake_quant")
-        with torch.no_grad():
-            m(**batches[0])
-        disable_all(m)
-        set_observer_name(m)
-        sync(); phases["weight_calibration"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("weight_calibration")
-        ratio = TWC.find_ratio_cached(NS(model=m), [batches[b] for b in mine], [fp_output[b] for b in mine], grid, n_batches=n_batches)
-        sync(); phases["twc_grid_search"] = time.perf_counter() - t0; t0 = time.perf_counter(); clock.mark("twc_grid_search")
-        if which == 2:        # ptq_qa_quant.py:262-267: smaller batches for the fine stage, targets recomputed with everything off
-            disable_all(m)
-            model = m
-            small = []
-            for b in batches:
-                for i in range(0, 32, 8):
-                    small.append({k: v[i:i + 8] for k, v in b.items()})
-            learn_in, learn_out = small, targets(small)
-        else:
-            learn_in, learn_out = batches, fp_output
-        TWC.learn_scale_sharded(NS(model=m), learn_in, learn_out, {"lr": 1e-5, "epoch": 1 if SHORT else 3})
-        sync(); phases["learn_scale"] = time.perf_counter() - t0; clock.mark("learn_scale")
-        wall = time.perf_counter() - t_start
-        out.update({"wall_s": round(wall, 3), "phases_s": {k: round(v, 3) for k, v in phases.items()},
-                    **clock.report(), "exchange_check": quantizer_exchange_check(m, world, share, dev),
-                    "best_percentile": ratio, "twc_candidates": grid["iters"],
-                    "search": "cached per-token extrema, one re-threshold launch per candidate and geometry group, sharded over ranks",
-                    "learn_scale": ("sequential Adam, one process" if world == 1 else
-                                    ("sequential Adam, every step data-parallel inside the batch (kept-token targets sliced per rank, gradients summed)"
-                                     if all(next(iter(b.values())).shape[0] % world == 0 for b in learn_in)
-                                     else ("sequential Adam, the batch's samples on the first ranks, one each, zero gradients from the others"
-                                           if all(world % next(iter(b.values())).shape[0] == 0 for b in learn_in)
-                                           else "sequential Adam, replicated on every rank (the batch does not divide over the ranks)"))),
-                    "n_gpus": world})
-        return out
-    finally:
-        clock.__exit__()
-        TWC.task_type, TWC.model_type = "glue", "bert"
-
-
-def quantized_forward_times(dev):
-    """BERT-base, every weight and activation quantizer frozen and on (the PTQ evaluation state, ptq_glue_quant.py:251):
-    one [32,128] forward with the weights fake-quantised per operator on every forward, as the reference does (77 launches,
-    quantized_module.py:71-72,97-100), against the kept result (no launch) and the one-launch refresh."""
-    from types import SimpleNamespace as NS
-    from transformers import BertConfig, BertForSequenceClassification
-    from outlier_suppression_amd.quant_model import quantize_model
-    from outlier_suppression_amd.quantization import enable_calibration_woquantization, enable_quantization, disable_all
-    from outlier_suppression_amd.quantization import weight_cache as WC
-    from outlier_suppression_amd import _hip
-    torch.manual_seed(0)
-    a_q = NS(quantizer="FixedFakeQuantize", observer="AvgMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    w_q = NS(quantizer="FixedFakeQuantize", observer="MinMaxObserver", bit=6, symmetric=True, ch_axis=0)
-    fp = BertForSequenceClassification(BertConfig(num_labels=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)).eval().to(dev)
-    model = quantize_model(fp, w_q, a_q).to(dev)
-    L = torch.randint(8, 129, (32,))
-    mask = (torch.arange(128)[None, :] < L[:, None]).long()
-    batch = {"input_ids": (torch.randint(1000, 30000, (32, 128)) * mask).to(dev), "attention_mask": mask.to(dev),
-             "token_type_ids": torch.zeros(32, 128, dtype=torch.long, device=dev)}
-    enable_calibration_woquantization(model)
-    with torch.no_grad():
-        model(**batch)
-    disable_all(model)
-    enable_quantization(model)
-
-    def timed(n=20):
-        with torch.no_grad():
-            for _ in range(3):
-                model(**batch)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                model(**batch)
-            torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
-    WC.enabled = False
-    per_op = timed()
-    WC.enabled = True
-    kept = timed()
-    for k in WC.stats:
-        WC.stats[k] = 0
-    WC.invalidate(model)
-    torch.cuda.synchronize()
-    with torch.no_grad():                  # the frozen-model state: nothing wants a gradient
-        WC.prepare_weights(model)          # builds the pointer table (once per model)
-        WC.invalidate(model)               # drops the results AND the table ...
-        WC.prepare_weights(model)
-        for m in model.modules():          # ... so stale results only: the table stays
-            WC._CACHE.pop(m, None)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = WC.prepare_weights(model)
-        torch.cuda.synchronize()
-    refresh = (time.perf_counter() - t0) * 1e3
-    # the launch alone (the wall-clock above is mostly the host walking 77 modules and comparing their keys)
-    _, w_table, w_ends, w_views, w_rows = WC._PLAN[model]
-    w_lib, w_ts = _hip.load(), []
-    for _ in range(9):
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record()
-        _hip.check(w_lib.osq_fake_quant_weights_multi(w_table.data_ptr(), w_ends.data_ptr(), len(w_views), w_rows, _hip.stream_ptr(dev)), "weights_multi")
-        eb.record()
-        torch.cuda.synchronize()
-        w_ts.append(ea.elapsed_time(eb) * 1e3)
-    w_us = sorted(w_ts)[len(w_ts) // 2]
-    w_bytes = 8 * sum(v.numel() for v in w_views)
-    # observer pass (token_wise_clipping.py:12-19, 29-47: observers on, fake-quant off) of one [32,128] batch: every
-    # masked site its own two launches, against the sites of the forward recorded and reduced together
-    from outlier_suppression_amd import token_wise_clipping as TWC
-    from outlier_suppression_amd.quantization.deferred import deferred_observation
-    from outlier_suppression_amd.quantization.state import set_observer_name
-    tw_a = NS(quantizer="LSQPlusFakeQuantize", observer="AvgPruneMinMaxObserver", bit=6, symmetric=False, ch_axis=-1)
-    obs_model = quantize_model(fp, w_q, tw_a).to(dev)
-    set_observer_name(obs_model)
-    TWC.set_ratio(obs_model, 0.95)
-
-    def observer_pass(defer, n=20):
-        info = {}
-        with torch.no_grad():
-            for rep in range(2):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                if defer:
-                    with deferred_observation() as sites:
-                        for _ in range(n):
-                            obs_model(**batch)
-                            sites.flush()
-                    info = {"launches_per_forward": sites.launches / n, "sites_per_forward": sites.flushed_sites / n}
-                else:
-                    for _ in range(n):
-                        obs_model(**batch)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / n * 1e3
-        return dt, info
-    each_ms, _ = observer_pass(False)
-    defer_ms, info = observer_pass(True)
-    n_sites = info.get("sites_per_forward", 0) or 1
-    return {"model": "BERT-base, W6A6, [32,128] batch, every quantizer frozen and on",
-            "observer_pass_site_by_site_ms": round(each_ms, 3), "observer_launches_per_masked_site_then": 2,
-            "observer_pass_deferred_ms": round(defer_ms, 3), "masked_sites_per_forward": n_sites,
-            "observer_launches_per_masked_site_now": round(info.get("launches_per_forward", 0) / n_sites, 4),
-            "weight_fake_quant_per_operator_every_forward_ms": round(per_op, 3), "weight_launches_per_forward_then": 77,
-            "weights_kept_ms": round(kept, 3), "weight_launches_per_forward_now": 0,
-            "one_launch_refresh_of_all_weights_ms": round(refresh, 3), "tensors_in_that_launch": n,
-            "that_launch_us": round(w_us, 1), "that_launch_MB": round(w_bytes / 1e6, 1), "that_launch_frac_of_8TBps": round(w_bytes / w_us / 1e6 / 8.0, 3)}
+from benchlib.common import SHAPE, HBM_PEAK_GBS, COPY_RATE_GBS, GIB, SHORT, make_inputs, make_quantizer, _ops_order, device_identity  # noqa: E402
+from benchlib import line as bench_line  # noqa: E402
 
 
 def self_launch(n):
@@ -964,6 +72,9 @@ def main():
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
                     help="how the K timed module calls are issued: one hipGraph replay, the eager loop, or (auto) whichever of the two "
                          "measures faster in untimed K-step regions directly before the timed one")
+    ap.add_argument("--regions", type=int, default=5, help="consecutive timed regions of exactly K steps each; ms_per_step is their median (min / max reported beside it)")
+    ap.add_argument("--kernel-launches", type=int, default=1000, help="launches of the step's kernel timed by HIP events on their dispatch packets for `roofline` (a sustained back-to-back run, the regime rocprofv3 --kernel-trace averages over)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-calib", action="store_true", help="skip the 256-sample calibration wall-clock section")
@@ -1176,18 +287,25 @@ def main():
         # idles AND when it has been busy for tens of milliseconds; a short run-up is the state the path's launches meet
         for _ in range(max(3, int(0.012 / (args.steps * 40e-6)))):
             y = issue(pick)
-    dt, host_dt, gathered, y = region(pick, exchange=True)
+    # ---- the timed regions: `--regions` CONSECUTIVE regions (default 5) of exactly K steps each, every one bracketed by barrier +
+    # synchronize on both sides and (N > 1) closed by the path's exchange; per region the MAX over ranks; `ms_per_step` and
+    # `value` are the MEDIAN region (min / max and every region's figure ride beside it: round 5 reported one region)
+    region_s, gathered = [], None
+    for _ in range(max(1, args.regions)):
+        dt_r, host_dt, gathered, y = region(pick, exchange=True)
+        region_s.append(dt_r)
     gc.enable()
+    if world > 1:
+        t = torch.tensor(region_s, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        region_s = t.tolist()
+    dt = sorted(region_s)[len(region_s) // 2]
     probe_stats = {m: {"median": round(sorted(v)[len(v) // 2] / args.steps * 1e6, 3), "min": round(min(v) / args.steps * 1e6, 3),
                        "max": round(max(v) / args.steps * 1e6, 3), "regions": len(v)} for m, v in probes.items() if v}
     launch_mode = ("hipGraph replay of %d captured module calls" % args.steps if pick == "graph" else "eager loop of %d module calls" % args.steps) + graph_note
     if len(modes) > 1:
         launch_mode += "; chosen by untimed probes of both (median of 5 regions, us per step: " + \
                        ", ".join(f"{m} {med[m] / args.steps * 1e6:.2f}" for m in modes) + ")"
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
     exchange_check = None
     if world > 1:
         # What the exchange is FOR: every rank replays the gathered rows in global batch order and must end up with the
@@ -1249,10 +367,15 @@ def main():
     del y
     check_status()
 
-    # ---- roofline of the step's kernel, OUTSIDE the timed region: HIP events that ride on the dispatch packet of
-    # each launch (hipExtLaunchKernelGGL inside the library, on the stream the kernel runs on): elapsed(start, stop)
-    # is the kernel's own run time, the figure rocprofv3 --kernel-trace reports.  Same loop shape as the timed one.
-    n_probe = max(args.steps, 50)
+    # ---- roofline of the step's kernel: HIP events that ride on the dispatch packet of each launch (hipExtLaunchKernelGGL
+    # inside the library, on the stream the kernel runs on): elapsed(start, stop) is the kernel's own run time, the figure
+    # rocprofv3 --kernel-trace reports.  A SUSTAINED run: --kernel-launches (1000) module calls back to back, every launch
+    # timed, none dropped -- the host enqueues a call in ~15 us against ~38 us of GPU work, so from the third call on the
+    # launches run back to back exactly as in the timed regions.  (Round 5 timed 50 launches that started on an idle GPU and
+    # read 36.8 us where the trace of the same command averaged 38.6 us over its 7813 dispatches: the first launches after an
+    # idle gap meet an empty memory system and boosted clocks.  `roofline` now prices the kernel in the regime the timed
+    # regions and the committed trace are in.)
+    n_probe = max(args.steps, args.kernel_launches)
     pairs = []
     for _ in range(n_probe):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
@@ -1265,13 +388,13 @@ def main():
             lib.osq_time_next_launch(probe_family, *pairs[i])
             q(xs[i % len(xs)], lengths, 1)
     torch.cuda.synchronize()
-    k_ms = []
+    k_seq = []
     for a, b in pairs:
         us = ctypes.c_float()
         _hip.check(lib.osq_timing_elapsed_us(a, b, ctypes.byref(us)), "timing_elapsed_us")
-        k_ms.append(us.value * 1e-3)
+        k_seq.append(us.value * 1e-3)
         lib.osq_timing_events_destroy(a, b)
-    k_ms.sort()
+    k_ms = sorted(k_seq)
     k_avg_ms = sum(k_ms) / len(k_ms)
     probe_bytes = bytes_step if fused_on else 8 * n_elem
     achieved = probe_bytes / (k_avg_ms * 1e-3) / 1e9
@@ -1279,7 +402,7 @@ def main():
     # rocprofv3 passes: tools/collect_profiles.sh).  Counters cannot be read from inside this process, so the figure comes
     # from the committed profile -- but only while that profile was taken from the SAME kernel sources: the file carries the
     # hash of the sources it measured, and a mismatch reports null with the reason instead of a number that went stale
-    traffic, traffic_source = None, None
+    traffic, traffic_source, rocprof_avg_us = None, None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -1288,8 +411,10 @@ def main():
             table_j = json.load(open(tpath))
             now, then = kernel_sources_sha256(), table_j.get("_kernel_sources_sha256")
             if then == now:
-                traffic = next((v.get("hbm_bytes_per_launch") for k, v in table_j.items()
-                                if k.startswith("observe_fq_fused_kernel" if fused_on else "fq_tensor_vec_kernel") and isinstance(v, dict)), None)
+                entry = next((v for k, v in table_j.items()
+                              if k.startswith("observe_fq_fused_kernel" if fused_on else "fq_tensor_vec_kernel") and isinstance(v, dict)), {})
+                traffic = entry.get("hbm_bytes_per_launch")
+                rocprof_avg_us = round(entry["avg_us_kernel_trace"], 2) if entry.get("avg_us_kernel_trace") else None
                 traffic_source = (f"profiles/roofline_traffic.json ({table_j.get('_profile_tag', '?')}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
                                   f"same command; kernel sources sha256 {now[:12]} = the ones built here)")
             else:
@@ -1314,6 +439,7 @@ def main():
     ops.set_tuning("fused_step", 1)
 
     value = bytes_step * args.steps * world / dt / GIB
+    per_step_us = [round(r / args.steps * 1e6, 3) for r in region_s]
     out = {
         "metric": "fake-quant+observer GiB/s (% HBM peak)",
         "value": round(value, 2),
@@ -1328,13 +454,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "collective": dict(collective, exchange_check=exchange_check),
-        "config": {"workload": "BERT-base activation [256,128,768] fp32, AvgPruneMinMaxObserver(p=0.95, lengths randint(8,129)) "
-                               "-> running average -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]; configs[1] site shape",
+        "config": {"workload": "configs[1] site at the metric's size: BERT-base activation [256,128,768] fp32, AvgPruneMinMaxObserver(p=0.95, "
+                               "lengths randint(8,129)) -> running mean -> qparams -> LSQ+ fake-quant W6A6 asym [0,63]",
                    "launches_per_step": 1 if fused_on else 3, "buffers_cycled": len(xs),
                    "algorithmic_bytes_per_step": bytes_step, "valid_token_fraction": round(valid_elem / n_elem, 4),
                    "hbm_bytes_per_step": 8 * n_elem,
                    "launch": launch_mode, "launch_picked": pick,
-                   # the untimed probe regions that decided how the timed region is issued (five K-step regions per mode, alternating),
+                   # ms_per_step is the MEDIAN of `timed_regions` consecutive K-step regions; their spread, and every region
+                   "timed_regions": len(region_s), "ms_per_step_min": round(min(region_s) / args.steps * 1e3, 5),
+                   "ms_per_step_max": round(max(region_s) / args.steps * 1e3, 5), "ms_per_step_regions": [round(u * 1e-3, 5) for u in per_step_us],
+                   # the untimed probe regions that decided how the timed regions are issued (five K-step regions per mode, alternating),
                    # as numbers: median / min / max microseconds per step of each mode (null: that mode was not probed)
                    "graph_us_per_step": probe_stats.get("graph", {}).get("median"), "eager_us_per_step": probe_stats.get("eager", {}).get("median"),
                    "probe_regions_us_per_step": probe_stats,
@@ -1344,14 +473,17 @@ def main():
                    "host_enqueue_ms_per_step": round(eager_host / args.steps * 1e3, 5),
                    "three_launch_path_ms_per_step": round(three_ms, 5),
                    "pct_hbm_peak": round(100.0 * value * GIB / 1e9 / (HBM_PEAK_GBS * world), 2)},
-        "roofline": {"bound": "hbm", "kernel": ("observe_fq_fused_kernel<3> (per-token extrema + token-wise clipping + running mean + "
-                                                "qparams + fake-quant, one persistent launch; 4 B per observed elem + 8 B per elem)")
+        "roofline": {"bound": "hbm", "kernel": ("observe_fq_fused_kernel<3>: per-token extrema + token-wise clipping + running mean + qparams + "
+                                                "fake-quant, ONE launch")
                      if fused_on else "fq_tensor_vec_kernel (fake-quant forward of the three-launch path, 8 B per elem)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "duration_source": f"HIP events on the dispatch packets of {len(k_ms)} back-to-back launches in this run, all averaged",
+                     # the committed rocprofv3 --kernel-trace average of the same kernel (same sources, by hash): must agree with avg_launch_us
+                     "rocprof_avg_launch_us": rocprof_avg_us,
                      # the same launch priced by the bytes that physically cross HBM (PMC): x is read once and y written
                      # once because the tensor stays on chip between the reduction and the quantisation -- `frac` counts
-                     # the ALGORITHMIC 12 B per element of SURVEY 8d, `frac_physical` the 8 B that move
+                     # the ALGORITHMIC 4 B per observed + 8 B per element of SURVEY 8d, `frac_physical` the 8 B that move
                      "achieved_physical": round(traffic / (k_avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                      "frac_physical": round(traffic / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                      # what a float4 copy kernel reaches on this part (MI355X_MICROARCH.md, chip-level parameters: 6.29 TB/s
@@ -1359,27 +491,55 @@ def main():
                      "copy_rate": COPY_RATE_GBS,
                      "frac_physical_of_copy_rate": round(traffic / (k_avg_ms * 1e-3) / 1e9 / COPY_RATE_GBS, 4) if traffic else None,
                      "avg_launch_us": round(k_avg_ms * 1e3, 2), "median_launch_us": round(k_ms[len(k_ms) // 2] * 1e3, 2),
+                     "min_launch_us": round(k_ms[0] * 1e3, 2), "max_launch_us": round(k_ms[-1] * 1e3, 2),
+                     "first_50_launches_avg_us": round(sum(k_seq[:50]) / len(k_seq[:50]) * 1e3, 2),
                      "launches_timed": len(k_ms), "algorithmic_bytes_per_launch": probe_bytes},
+        "detail_file": os.path.basename(args.detail_file),
     }
+
+    def emit(final=False):
+        """rank 0: the detail file (rewritten as sections arrive: a later crash keeps what was measured) and, at the end, the
+        detail lines followed by THE line -- the last thing on stdout."""
+        if rank != 0:
+            return
+        try:
+            with open(args.detail_file, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {args.detail_file}: {e}", file=sys.stderr)
+        if final:
+            for ln in bench_line.detail_lines(out):
+                print(ln)
+            text = bench_line.dumps_line(out)
+            bench_line.check_line(text)
+            print(text, flush=True)
+
+    emit()
     if rank == 0 and not args.no_kernel_table:
+        from benchlib.kernels import kernel_table
         try:          # a failure in the per-kernel table must not cost the headline line
             out["kernels"] = kernel_table(dev, xs, lengths)
         except Exception as e:
             out["kernels"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        emit()
     if not args.no_calib:
+        from benchlib.calibration_flows import calibration_plain, calibration_wall_clock, calibration_extra, quantized_forward_times
         wanted = {int(c) for c in args.calib_configs.split(",") if c.strip()}
         if 0 in wanted:
             try:
                 out["calibration_config0"] = calibration_plain(dev, rank, world)
             except Exception as e:
+                if world > 1:
+                    raise          # the other ranks are inside its collectives: fail the job rather than hang it
                 out["calibration_config0"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if 1 in wanted:
             try:
                 out["calibration"] = calibration_wall_clock(dev, rank, world, args.calib_search)
             except Exception as e:
                 if world > 1:
-                    raise          # the other ranks are inside its collectives: fail the job rather than hang it
+                    raise
                 out["calibration"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        emit()
         for which in (2, 3, 4, 5):
             if which not in wanted:
                 continue
@@ -1390,6 +550,7 @@ def main():
                     raise          # see above: never leave the other ranks waiting in a collective
                 out["calibration_config4_bart_base" if which == 5 else f"calibration_config{which}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+            emit()
         # Metric 2 in one place: wall-clock and the collective's share of every measured config at the launched N
         out["calibration_summary"] = {
             "n_gpus": world,
@@ -1403,17 +564,18 @@ def main():
             except Exception as e:
                 out["quantized_forward"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from benchlib.cpu import cpu_baseline
         try:
             out["cpu_baseline"] = cpu_baseline(1234, args.cpu_budget)
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    emit(final=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
     main()
+

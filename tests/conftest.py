@@ -26,14 +26,40 @@ def golden():
     return load
 
 
+def f32_bits(a):
+    """uint32 view of an fp32 array with every NaN mapped to one canonical pattern (NaN payloads / signs are not part of the
+    contract: torch, NumPy and the device produce different quiet NaNs for inf - inf)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    bits = a.view(np.uint32).copy()
+    bits[np.isnan(a)] = np.uint32(0x7FC00000)
+    return bits
+
+
 def same_f32(a, b):
-    """Bit-for-bit equality of two fp32 arrays, treating NaN == NaN and -0.0 == +0.0."""
+    """BIT-for-bit equality of two fp32 arrays: compared as uint32 words, so -0.0 and +0.0 DIFFER (the
+    reference dequantizes -0.0 to +0.0 -- a sign-of-zero slip must show); NaN equals NaN whatever its payload.  Until round 5
+    this was `a == b`, which let the sign of a zero through."""
     a = np.asarray(a, dtype=np.float32)
     b = np.asarray(b, dtype=np.float32)
     if a.shape != b.shape:
         return False
-    both_nan = np.isnan(a) & np.isnan(b)
-    return bool(np.all(both_nan | (a == b)))
+    return bool(np.array_equal(f32_bits(a), f32_bits(b)))
+
+
+def bits_equal(a, b, equal_nan=True):
+    """np.array_equal made a BIT comparison for floating-point arrays (words compared, -0.0 != +0.0, NaN == NaN); integer,
+    bool and mixed arrays go to np.array_equal.  The `-m gpu` tests compare the device's results with the oracle through this."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if a.dtype == np.float32 and b.dtype == np.float32:
+        return same_f32(a, b)
+    if a.dtype == np.float64 and b.dtype == np.float64:
+        ab, bb = np.ascontiguousarray(a).view(np.uint64).copy(), np.ascontiguousarray(b).view(np.uint64).copy()
+        ab[np.isnan(a)] = np.uint64(0x7FF8000000000000)
+        bb[np.isnan(b)] = np.uint64(0x7FF8000000000000)
+        return bool(np.array_equal(ab, bb))
+    return bool(np.array_equal(a, b, equal_nan=equal_nan and a.dtype.kind == "f" and b.dtype.kind == "f"))
 
 
 @pytest.fixture(scope="session")

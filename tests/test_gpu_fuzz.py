@@ -7,6 +7,7 @@ import os
 from types import SimpleNamespace as NS
 
 import numpy as np
+from conftest import bits_equal
 import pytest
 import torch
 
@@ -62,6 +63,15 @@ def _draw_values(rng, shape, pattern):
         x *= np.float32(1e-6)
     elif pattern == "huge":
         x *= np.float32(1e6)
+    elif pattern == "signed_zeros":
+        # -0.0 / +0.0 entries, and small values of either sign whose quotient rounds to -0 / +0: the reference's
+        # (x.round() - x).detach() + x and its "+ zp ... - zp" chain decide the sign of the zero that comes out
+        # (util_quant.py:4-15; SURVEY 8a quirk 14: -0.0 dequantizes to +0.0) -- compared as bits
+        pick = rng.integers(0, 5, shape)
+        x = np.where(pick == 0, np.float32(-0.0), x)
+        x = np.where(pick == 1, np.float32(0.0), x)
+        x = np.where(pick == 2, -np.abs(x) * np.float32(1e-4), x)
+        x = np.where(pick == 3, np.abs(x) * np.float32(1e-4), x).astype(np.float32)
     return x
 
 
@@ -109,7 +119,7 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
         st.percentile = percentile
         tag = (case, kind, shape, seq_pos, observer, quantizer, bit, sym, percentile, masked)
         for it in range(int(rng.integers(1, 4))):
-            pattern = str(rng.choice(["normal", "outlier", "positive", "negative", "constant", "duplicates", "tiny", "huge"]))
+            pattern = str(rng.choice(["normal", "outlier", "positive", "negative", "constant", "duplicates", "tiny", "huge", "signed_zeros"]))
             x_np = _draw_values(rng, shape, pattern)
             x, how = _as_view(rng, x_np, kind, dev)
             seen.add((kind, how, pattern))
@@ -155,6 +165,38 @@ def test_quantizer_calls_vs_oracle(eq32, dev):
     assert kinds == {"bth", "bhtd", "bhdt", "bh", "probs", "probs3d"} and {h for _, h, _ in seen} == {"dense", "permuted", "offset"}
 
 
+def test_sign_of_zero_vs_oracle(eq32, dev):
+    """-0.0, +0.0 and values whose quotient rounds to -0, through every per-tensor quantizer form, symmetric (zp = 0, where
+    nothing is added that could wash the sign out) and asymmetric: y and dx as BITS against the oracle (which is pinned to
+    the reference bit for bit on the CPU, tests/test_oracle_vs_reference_live.py).  util_quant.py:4-15,48-55."""
+    from oracle import fake_quant_oracle as FQ
+    from outlier_suppression_amd import ops
+    rng = np.random.default_rng(606 + SEED)
+    base = np.float32([-0.0, 0.0, -1e-9, 1e-9, -0.2, 0.2, -0.5, 0.5, -0.49999997, 0.49999997, -1.0, 1.0, -1.5, 1.5, -2.5, 2.5,
+                       -1e-38, 1e-38, -31.5, 31.5, -32.5, 32.5, -100.0, 100.0])
+    for scale in (np.float32(1.0), np.float32(0.37), np.float32(1e-8), np.float32(3.0)):
+        x_np = np.concatenate([base * scale, base, rng.standard_normal(4096 - 2 * base.size).astype(np.float32) * np.float32(0.3) * scale])
+        x_np[100:140] = np.float32(-0.0)
+        gy_np = rng.standard_normal(x_np.shape).astype(np.float32)
+        gy_np[::7] = np.float32(-0.0)
+        for (qmin, qmax, zp) in ((-32, 31, 0.0), (0, 63, 0.0), (0, 63, 31.0), (0, 63, 63.0), (-8, 7, 0.0), (0, 255, 128.0)):
+            x = torch.from_numpy(x_np).to(dev)
+            s_t, z_t = torch.tensor([scale], device=dev), torch.tensor([zp], device=dev)
+            tag = (float(scale), qmin, qmax, zp)
+            # Fixed: Python scalars in the reference (fake_quant.py:124), int32 zero-point buffer
+            _, ref = FQ.fake_quantize_per_tensor_affine(x_np, scale, np.float32(zp), qmin, qmax)
+            y = ops.fake_quant_per_tensor(x, s_t, torch.tensor([int(zp)], dtype=torch.int32, device=dev), qmin, qmax, ops.PARAM_FIXED, 0.0)
+            assert eq32(y.cpu().numpy(), ref), (tag, "fixed y")
+            # LSQ+: tensor operands, grad_scale forms
+            g = FQ.lsqplus_grad_factor(x_np.size, qmax)
+            _, ref = FQ.fake_quantize_learnableplus_per_tensor(x_np, scale, np.float32(zp), qmin, qmax, g)
+            y = ops.fake_quant_per_tensor(x, s_t, z_t, qmin, qmax, ops.PARAM_LSQPLUS, g)
+            assert eq32(y.cpu().numpy(), ref), (tag, "lsq+ y")
+            dx_ref, _, _ = FQ.lsqplus_backward_per_tensor(x_np, gy_np, np.float32([scale]), np.float32([zp]), qmin, qmax, g)
+            dx = ops.lsq_backward_per_tensor(x, torch.from_numpy(gy_np).to(dev), s_t, z_t, qmin, qmax, ops.PARAM_LSQPLUS, g)[0]
+            assert eq32(dx.cpu().numpy(), dx_ref), (tag, "lsq+ dx")
+
+
 def test_weight_operators_vs_oracle(eq32, dev):
     """Per-channel side: Quantizer(nn.Linear / nn.Conv2d / nn.Embedding) with MinMaxObserver on ch_axis 0 (odd row lengths,
     one-row and one-column weights, 4-D kernels), both symmetries, and the functional per-channel fake-quant on an inner
@@ -190,7 +232,7 @@ def test_weight_operators_vs_oracle(eq32, dev):
         scale, zp = st.qparams()
         tag = (case, kind, w_np.shape, bit, sym)
         assert eq32(fq.observer.min_val.cpu().numpy(), st.min_val) and eq32(fq.observer.max_val.cpu().numpy(), st.max_val), tag
-        assert eq32(fq.scale.cpu().numpy(), scale) and np.array_equal(fq.zero_point.cpu().numpy(), zp), tag
+        assert eq32(fq.scale.cpu().numpy(), scale) and bits_equal(fq.zero_point.cpu().numpy(), zp), tag
         _, ref = FQ.fake_quantize_per_channel_affine(w_np, scale, zp, 0, fq.quant_min, fq.quant_max)
         assert eq32(wq.cpu().numpy(), ref), tag
         # inner channel axis, functional form
@@ -222,8 +264,8 @@ def test_msefast_rows_vs_oracle(dev):
         st = OB.ObserverState(bit=bit, symmetric=sym, ch_axis=0)
         OB.observe_msefast(st, w_np)
         got_min, got_max = ob.min_val.cpu().numpy(), ob.max_val.cpu().numpy()
-        assert np.array_equal(got_min.astype(np.float32), np.asarray(st.min_val, dtype=np.float32)) and \
-            np.array_equal(got_max.astype(np.float32), np.asarray(st.max_val, dtype=np.float32)), (case, bit, sym, rows, cols, got_min, st.min_val)
+        assert bits_equal(got_min.astype(np.float32), np.asarray(st.min_val, dtype=np.float32)) and \
+            bits_equal(got_max.astype(np.float32), np.asarray(st.max_val, dtype=np.float32)), (case, bit, sym, rows, cols, got_min, st.min_val)
 
 
 def test_token_selection_vs_oracle(eq32, dev):
@@ -382,7 +424,7 @@ def test_other_observers_vs_oracle(eq32, dev, sum_tier):
                         np.testing.assert_allclose(got_min, want_min.astype(np.float64), rtol=3e-2, atol=0, err_msg=str(tag))
                         np.testing.assert_allclose(got_max, want_max.astype(np.float64), rtol=3e-2, atol=0, err_msg=str(tag))
                 else:
-                    assert np.array_equal(got_min, want_min.astype(np.float64)) and np.array_equal(got_max, want_max.astype(np.float64)), \
+                    assert bits_equal(got_min, want_min.astype(np.float64)) and bits_equal(got_max, want_max.astype(np.float64)), \
                         (tag, got_min, want_min, got_max, want_max)
                     if np.float64 in (want_min.dtype, want_max.dtype):      # the public method on float64 statistics: float64 arithmetic
                         s_g, z_g = ob.calculate_qparams(ob.min_val, ob.max_val)
@@ -459,7 +501,7 @@ def test_deferred_forwards_vs_oracle(eq32, dev, sum_tier):
                                 np.testing.assert_allclose(got[0], want[0], rtol=3e-2, err_msg=str(tag))
                                 np.testing.assert_allclose(got[1], want[1], rtol=3e-2, err_msg=str(tag))
                         else:
-                            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), str((tag, None if L_np is None else L_np.tolist(), q.bit, q.observer.symmetric, len(sites), got, want))
+                            assert bits_equal(got[0], want[0]) and bits_equal(got[1], want[1]), str((tag, None if L_np is None else L_np.tolist(), q.bit, q.observer.symmetric, len(sites), got, want))
                         continue
                     fns[observer](st, x_np, L_np, seq_pos)
                     assert eq32(q.observer.min_val.cpu().numpy(), st.min_val) and eq32(q.observer.max_val.cpu().numpy(), st.max_val), tag

@@ -12,6 +12,7 @@ import sys
 from types import SimpleNamespace as NS
 
 import numpy as np
+from conftest import bits_equal
 import pytest
 import torch
 
@@ -93,9 +94,9 @@ def test_ln_site_matches_reference(golden, form, case, dev):
         bar = 1e-5 * max(1.0, float(np.abs(ref_ln).max()))
         assert np.abs(y_obs[:FLOAT_SAMPLES].cpu().numpy() - ref_ln).max() <= bar, (name, form)
         if cls == "QuantizedSplitLayerNorm":
-            assert np.array_equal(mod.bias.data.cpu().numpy(), g[name + "_split_bias"])
+            assert bits_equal(mod.bias.data.cpu().numpy(), g[name + "_split_bias"])
         np.testing.assert_allclose(q.scale.detach().cpu().numpy().reshape(-1), g[name + "_scale"], rtol=1e-5)
-        assert np.array_equal(q.zero_point.detach().cpu().numpy().reshape(-1).astype(np.float32), g[name + "_zp"])
+        assert bits_equal(q.zero_point.detach().cpu().numpy().reshape(-1).astype(np.float32), g[name + "_zp"])
         # quantized pass with the REFERENCE's parameters: only the normalisation is being compared
         q.disable_observer(); q.enable_fake_quant()
         rs, rz = float(g[name + "_scale"][0]), float(g[name + "_zp"][0])

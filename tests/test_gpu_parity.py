@@ -8,6 +8,7 @@ float sums (LSQ+ dscale / dzero_point) to 2e-5 relative.
 from types import SimpleNamespace as NS
 
 import numpy as np
+from conftest import bits_equal
 import pytest
 import torch
 
@@ -198,7 +199,7 @@ def test_lsq_backward_determinism_and_size(dev):
     for dx, ds, dz in outs[1:]:
         assert torch.equal(dx, outs[0][0]) and torch.equal(ds, outs[0][1]) and torch.equal(dz, outs[0][2])
     dx_o, ds_o, dz_o = FQ.lsqplus_backward_per_tensor(x.numpy(), gy.numpy(), F32(0.07), F32(31.4), 0, 63, gf)
-    assert np.array_equal(N(outs[0][0]), dx_o)
+    assert bits_equal(N(outs[0][0]), dx_o)
     np.testing.assert_allclose(N(outs[0][1])[0], ds_o, rtol=2e-5)
     np.testing.assert_allclose(N(outs[0][2])[0], dz_o, rtol=2e-5)
 
@@ -328,7 +329,7 @@ def test_config_site_shapes_vs_oracle(shape, seq_pos, n_mask, name, eq32, dev):
         assert eq32(N(ob.min_val), st.min_val) and eq32(N(ob.max_val), st.max_val), (shape, it, N(ob.min_val), st.min_val, N(ob.max_val), st.max_val)
     scale, zp = ob.calculate_qparams(ob.min_val, ob.max_val)
     s_o, z_o = st.qparams()
-    assert eq32(N(scale), s_o) and np.array_equal(N(zp), z_o)
+    assert eq32(N(scale), s_o) and bits_equal(N(zp), z_o)
 
 
 def test_flat_and_channel_observers_vs_oracle(eq32, dev):
@@ -355,7 +356,7 @@ def test_flat_and_channel_observers_vs_oracle(eq32, dev):
         assert eq32(N(ob.min_val), st.min_val) and eq32(N(ob.max_val), st.max_val), shape
         scale, zp = ob.calculate_qparams(ob.min_val, ob.max_val)
         s_o, z_o = st.qparams()
-        assert eq32(N(scale), s_o) and np.array_equal(N(zp), z_o)
+        assert eq32(N(scale), s_o) and bits_equal(N(zp), z_o)
 
 
 def test_nan_poisons_statistics(dev):
@@ -569,7 +570,7 @@ def test_quantized_operators_forward(eq32, dev):
         st = OB.ObserverState(bit=6, symmetric=True, ch_axis=0)
         OB.observe_minmax(st, W)
         scale, zp = st.qparams()
-        assert eq32(N(wq.scale), scale) and np.array_equal(N(wq.zero_point), zp)
+        assert eq32(N(wq.scale), scale) and bits_equal(N(wq.zero_point), zp)
         _, Wq = FQ.fake_quantize_per_channel_affine(W, scale, zp, 0, -32, 31)
         Wq_t = torch.from_numpy(Wq).to(dev)
         with torch.no_grad():
@@ -715,7 +716,7 @@ def test_msefast_equals_oracle(dev, sum_tier):
         st = OB.ObserverState(bit=bit, symmetric=True, ch_axis=0)
         counter = [0]
         OB.observe_msefast(st, w.numpy(), counter=counter)
-        assert np.array_equal(N(ob.max_val), st.max_val) and np.array_equal(N(ob.min_val), st.min_val), (cols, bit)
+        assert bits_equal(N(ob.max_val), st.max_val) and bits_equal(N(ob.min_val), st.min_val), (cols, bit)
         assert int(ob.last_nfev.sum().item()) == counter[0], (cols, bit)
     # one-sided weights (post-ReLU style rows) and asymmetric per-channel (nested search per row)
     w = torch.rand(12, 256, generator=gen) * 0.3
@@ -724,7 +725,7 @@ def test_msefast_equals_oracle(dev, sum_tier):
         ob(data.to(dev))
         st = OB.ObserverState(bit=4, symmetric=sym, ch_axis=0)
         OB.observe_msefast(st, data.numpy())
-        assert np.array_equal(N(ob.max_val), st.max_val) and np.array_equal(N(ob.min_val), st.min_val)
+        assert bits_equal(N(ob.max_val), st.max_val) and bits_equal(N(ob.min_val), st.min_val)
     x = torch.randn(8, 32, 96, generator=gen)
     x[..., 3] *= 12
     L = torch.randint(4, 33, (8,), generator=gen)
@@ -840,15 +841,15 @@ def test_mse_grid_equals_oracle(dev):
                     else:
                         ob(xi.to(dev))
                         OB.observe_mse(st, xi.numpy(), average=cls.startswith("Avg"))
-                    assert np.array_equal(N(ob.min_val), np.asarray(st.min_val, dtype=np.float32)) and \
-                        np.array_equal(N(ob.max_val), np.asarray(st.max_val, dtype=np.float32)), (cls, sym, masked, it, N(ob.min_val), st.min_val, N(ob.max_val), st.max_val)
+                    assert bits_equal(N(ob.min_val), np.asarray(st.min_val, dtype=np.float32)) and \
+                        bits_equal(N(ob.max_val), np.asarray(st.max_val, dtype=np.float32)), (cls, sym, masked, it, N(ob.min_val), st.min_val, N(ob.max_val), st.max_val)
     w = torch.randn(12, 96, generator=gen) * 0.05
     for sym, data in ((True, w), (False, w), (False, w.abs())):
         ob = ObserverDict["MSEObserver"](bit=4, symmetric=sym, ch_axis=0).to(dev)
         st = OB.ObserverState(bit=4, symmetric=sym, ch_axis=0)
         ob(data.to(dev))
         OB.observe_mse(st, data.numpy())
-        assert np.array_equal(N(ob.min_val), st.min_val) and np.array_equal(N(ob.max_val), st.max_val), (sym,)
+        assert bits_equal(N(ob.min_val), st.min_val) and bits_equal(N(ob.max_val), st.max_val), (sym,)
 
 
 def test_msefast_resident_search_equals_launch_per_evaluation(dev):
@@ -1019,8 +1020,8 @@ def test_msefast_tensor_equals_reference_in_its_summation_order(golden, dev):
                 ob(torch.from_numpy(x[r] if reps > 1 else x).to(dev))
                 evals += int(ob.last_nfev.sum().item())
                 got_min, got_max = N(ob.min_val).reshape(-1), N(ob.max_val).reshape(-1)
-                assert np.array_equal(got_min.astype(np.float64), g[f"c{k}_min"][r].reshape(-1).astype(np.float64)) and \
-                    np.array_equal(got_max.astype(np.float64), g[f"c{k}_max"][r].reshape(-1).astype(np.float64)), \
+                assert bits_equal(got_min.astype(np.float64), g[f"c{k}_min"][r].reshape(-1).astype(np.float64)) and \
+                    bits_equal(got_max.astype(np.float64), g[f"c{k}_max"][r].reshape(-1).astype(np.float64)), \
                     (k, cls, r, got_min, g[f"c{k}_min"][r], got_max, g[f"c{k}_max"][r])
             assert evals == nfev, (k, cls, evals, nfev)
     finally:
@@ -1044,8 +1045,8 @@ def test_msefast_masked_tensor_equals_reference_in_its_summation_order(golden, d
             for r in range(3):
                 ob(torch.from_numpy(g[f"c{k}_x"][r]).to(dev), torch.from_numpy(g[f"c{k}_len"][r]).to(dev), int(seq_pos))
                 evals += int(ob.last_nfev.sum().item())
-                assert np.array_equal(N(ob.min_val).reshape(-1).astype(np.float64), g[f"c{k}_min"][r].reshape(-1)) and \
-                    np.array_equal(N(ob.max_val).reshape(-1).astype(np.float64), g[f"c{k}_max"][r].reshape(-1)), \
+                assert bits_equal(N(ob.min_val).reshape(-1).astype(np.float64), g[f"c{k}_min"][r].reshape(-1)) and \
+                    bits_equal(N(ob.max_val).reshape(-1).astype(np.float64), g[f"c{k}_max"][r].reshape(-1)), \
                     (k, cls, r, N(ob.min_val), g[f"c{k}_min"][r], N(ob.max_val), g[f"c{k}_max"][r])
             assert evals == int(nfev), (k, cls, evals, nfev)
     finally:
@@ -1104,7 +1105,7 @@ def test_msefast_rows_equal_reference_in_its_summation_order(golden, name, dev):
     ob = MSEFastObserver(bit=bit, symmetric=True, ch_axis=0).to(dev)
     ob(w)
     torch.cuda.synchronize()
-    assert np.array_equal(N(ob.max_val), g[name + "_max"]) and np.array_equal(N(ob.min_val), g[name + "_min"])
+    assert bits_equal(N(ob.max_val), g[name + "_max"]) and bits_equal(N(ob.min_val), g[name + "_min"])
     assert int(ob.last_nfev.sum().item()) == ref_nfev
     s_a, z_a = ob.calculate_qparams(ob.min_val, ob.max_val)
     s_b, z_b = ob.calculate_qparams(T(g[name + "_min"], dev), T(g[name + "_max"], dev))
@@ -1129,7 +1130,7 @@ def test_msefast_through_quantizer(dev):
     st = OB.ObserverState(bit=4, symmetric=True, ch_axis=0)
     OB.observe_msefast(st, lin.weight.detach().numpy())
     s_o, _ = st.qparams()
-    assert np.array_equal(N(fq.observer.max_val), st.max_val) and np.array_equal(N(fq.scale), s_o)
+    assert bits_equal(N(fq.observer.max_val), st.max_val) and bits_equal(N(fq.scale), s_o)
     assert fq.scale.shape == (10,) and fq.zero_point.dtype == torch.int32
 
 
@@ -1364,7 +1365,7 @@ def test_select_large_problems_match_oracle(dev):
                     assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (B, T_, kind, masked, p, a, b)
                     lo, up = OB.prune_thresholds(tmin[valid].numpy(), tmax[valid].numpy(), p)
                     want = np.array([up if lo > up else lo, up], dtype=np.float32)
-                    assert np.array_equal(a.numpy().view(np.int32), want.view(np.int32)), (B, T_, kind, masked, p, a, want)
+                    assert bits_equal(a.numpy().view(np.int32), want.view(np.int32)), (B, T_, kind, masked, p, a, want)
                     n_cases += 1
     assert n_cases == 6 * 6 * 2 * 9
 

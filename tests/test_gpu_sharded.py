@@ -8,6 +8,7 @@ import sys
 from types import SimpleNamespace as NS
 
 import numpy as np
+from conftest import bits_equal
 import pytest
 import torch
 
@@ -117,9 +118,9 @@ def test_one_rank_rccl_group_equals_no_group(tmp_path):
     mp.spawn(_run, args=(1, 29741, str(tmp_path), "nccl"), nprocs=1, join=True)
     one, rccl = np.load(tmp_path / "w1_r0.npz"), np.load(tmp_path / "nccl1_r0.npz")
     for k in ("ratio", "losses", "scale", "zp", "mn", "cnt"):
-        assert np.array_equal(one[k], rccl[k]), k
+        assert bits_equal(one[k], rccl[k]), k
     l1, lr = np.load(tmp_path / "learn_w1_r0.npz"), np.load(tmp_path / "learn_nccl1_r0.npz")
-    assert np.array_equal(l1["scale"], lr["scale"]) and np.array_equal(l1["zp"], lr["zp"])
+    assert bits_equal(l1["scale"], lr["scale"]) and bits_equal(l1["zp"], lr["zp"])
 
 
 def test_two_ranks_equal_one(tmp_path):
@@ -133,19 +134,19 @@ def test_two_ranks_equal_one(tmp_path):
     for world, r in ((2, 0), (2, 1), (4, 0), (4, 3)):
         two = np.load(tmp_path / f"w{world}_r{r}.npz")
         assert float(two["ratio"]) == float(one["ratio"])
-        assert np.array_equal(two["losses"], one["losses"])
-        assert np.array_equal(two["scale"], one["scale"]) and np.array_equal(two["zp"], one["zp"])
-        assert np.array_equal(two["mn"], one["mn"]) and np.array_equal(two["cnt"], one["cnt"])
+        assert bits_equal(two["losses"], one["losses"])
+        assert bits_equal(two["scale"], one["scale"]) and bits_equal(two["zp"], one["zp"])
+        assert bits_equal(two["mn"], one["mn"]) and bits_equal(two["cnt"], one["cnt"])
     assert int(one["cnt"][0]) == 4
     # learn-scale: same mathematics, per-rank partial sums -> float-rounding agreement; ranks identical to each other
     base = np.load(tmp_path / "w1_r0.npz")
     l1 = np.load(tmp_path / "learn_w1_r0.npz")
     l2 = [np.load(tmp_path / f"learn_w2_r{r}.npz") for r in (0, 1)]
-    assert np.array_equal(l2[0]["scale"], l2[1]["scale"]) and np.array_equal(l2[0]["zp"], l2[1]["zp"])
+    assert bits_equal(l2[0]["scale"], l2[1]["scale"]) and bits_equal(l2[0]["zp"], l2[1]["zp"])
     l4 = [np.load(tmp_path / f"learn_w4_r{r}.npz") for r in range(4)]
-    assert all(np.array_equal(l4[0]["scale"], l["scale"]) and np.array_equal(l4[0]["zp"], l["zp"]) for l in l4[1:])
+    assert all(bits_equal(l4[0]["scale"], l["scale"]) and bits_equal(l4[0]["zp"], l["zp"]) for l in l4[1:])
     np.testing.assert_allclose(l4[0]["scale"], l1["scale"], rtol=5e-5, atol=0)
-    assert not np.array_equal(l1["scale"], base["scale"])          # the parameters did move
+    assert not bits_equal(l1["scale"], base["scale"])          # the parameters did move
     np.testing.assert_allclose(l2[0]["scale"], l1["scale"], rtol=2e-5, atol=0)
     np.testing.assert_allclose(l2[0]["zp"], l1["zp"], rtol=2e-5, atol=2e-5)
     moved = np.abs(l1["scale"] - base["scale"]).max()
@@ -242,12 +243,12 @@ def test_masked_learn_scale_two_ranks_equal_one(tmp_path, task, port):
         mp.spawn(_run_masked, args=(8, port + 4, str(tmp_path), task), nprocs=8, join=True)
         worlds = (2, 4, 8)
     one = np.load(tmp_path / f"{task}_w1_r0.npz")
-    assert not np.array_equal(one["scale"], one["before"])
+    assert not bits_equal(one["scale"], one["before"])
     moved = np.abs(one["scale"] - one["before"]).max()
     for world in worlds:
         rs = [np.load(tmp_path / f"{task}_w{world}_r{r}.npz") for r in range(world)]
-        assert all(np.array_equal(rs[0]["scale"], r["scale"]) and np.array_equal(rs[0]["zp"], r["zp"]) for r in rs[1:])
-        assert np.array_equal(rs[0]["before"], one["before"])
+        assert all(bits_equal(rs[0]["scale"], r["scale"]) and bits_equal(rs[0]["zp"], r["zp"]) for r in rs[1:])
+        assert bits_equal(rs[0]["before"], one["before"])
         assert np.abs(rs[0]["scale"] - one["scale"]).max() <= 0.02 * moved, (world, np.abs(rs[0]["scale"] - one["scale"]).max(), moved)
         # Adam normalises every gradient by its own running magnitude: a parameter whose gradient is rounding noise moves by
         # a fraction of lr either way, so the bound is in steps (6 steps of lr = 1e-3), not relative to the value
@@ -330,7 +331,7 @@ def test_site_sharded_msefast_equals_one_process(tmp_path):
         for k in one.files:
             a, b = got[k], one[k]
             assert a.dtype == b.dtype and a.shape == b.shape, (world, r, k, a.dtype, b.dtype, a.shape, b.shape)
-            assert np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), (world, r, k)
+            assert bits_equal(a, b, equal_nan=(a.dtype.kind == "f")), (world, r, k)
 
 
 def test_bench_self_launch_two_ranks():
@@ -348,9 +349,12 @@ def test_bench_self_launch_two_ranks():
                         "--no-calib", "--no-kernel-table", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0], r.stdout[-2000:]      # ONE line, and it is the last
+    from benchlib import line as BL
+    BL.check_line(lines[0])                                  # under the size cap, contract keys present
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert out["config"]["timed_regions"] == 5 and out["config"]["ms_per_step_min"] <= out["ms_per_step"] <= out["config"]["ms_per_step_max"]
     assert out["collective"]["ranks_seen"] == 2 and out["collective"]["world_size"] == 2
     # the exchange moved the rows the timed steps recorded, and they replay to the one-process statistic on every rank
     chk = out["collective"]["exchange_check"]
@@ -379,22 +383,26 @@ def test_bench_self_launch_eight_ranks_with_sharded_calibration():
                         "--calib-configs", "2", "--no-kernel-table", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0], r.stdout[-2000:]
+    from benchlib import line as BL
+    BL.check_line(lines[0])
+    out, detail = BL.parse_stdout(r.stdout)                  # the compact line; the sections printed before it
     assert out["n_gpus"] == 8 and out["collective"]["ranks_seen"] == 8
     chk = out["collective"]["exchange_check"]
     assert chk["rows_gathered"] == 32 and chk["replay_equals_one_process_loop"] and chk["same_bits_on_every_rank"] and chk["own_rows_intact"], chk
-    cal = out["calibration_config2"]
+    assert out["calibration_summary"]["calibration_config2"]["wall_s"] == detail["calibration_config2"]["wall_s"]
+    cal = detail["calibration_config2"]
     assert "error" not in cal, cal
     assert cal["n_gpus"] == 8 and cal["wall_s"] > 0 and cal["collective_s"] >= 0, cal
     # round 5: the collective's share per phase, and every rank ending the calibration with the same parameter bits
     assert set(cal["collective_phases_s"]) >= {"twc_grid_search", "learn_scale"} and cal["collective_calls"] > 0, cal
     assert cal["exchange_check"]["ranks"] == 8 and cal["exchange_check"]["same_bits_on_every_rank"], cal["exchange_check"]
-    summary = out["calibration_summary"]["configs"]["calibration_config2"]
+    summary = detail["calibration_summary"]["configs"]["calibration_config2"]
     assert summary["same_parameters_on_every_rank"] is True and summary["collective_s"] == cal["collective_s"], summary
     # the probe regions that chose how the timed region is issued, as numbers
-    cfg = out["config"]
+    cfg = detail["config"]
     assert cfg["launch_picked"] in ("graph", "eager") and isinstance(cfg["probe_regions_us_per_step"], dict), cfg
+    assert out["config"]["launch_picked"] == cfg["launch_picked"]
 
 
 def test_bench_refuses_two_ranks_on_one_device():

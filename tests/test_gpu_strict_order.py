@@ -14,6 +14,7 @@ below is compared BIT FOR BIT:
     outputs; three batches, so the float64 calls are covered; statistics after every call and the evaluation counts).
 """
 import numpy as np
+from conftest import bits_equal
 import pytest
 import torch
 
@@ -67,7 +68,7 @@ def test_ordered_backward_equals_oracle_at_any_length(dev, width):
             z = torch.tensor([zp], device=dev)
             dx, ds, dz = ops.lsq_backward_per_tensor(xd, gd, s, z, 0, 63, ops.PARAM_LSQPLUS, gf)
             rdx, rds, rdz = FQ.lsqplus_backward_per_tensor_reference_order(x, gy, scale, zp, 0, 63, gf, vec=width)
-            assert np.array_equal(N(dx), rdx), n
+            assert bits_equal(N(dx), rdx), n
             assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (n, width, ds.item(), rds, dz.item(), rdz)
     finally:
         ops.set_tuning("bwd_sum_order", 0)      # the default tier
@@ -107,8 +108,8 @@ def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
                 ob(torch.from_numpy(x).to(dev))
                 evals += int(ob.last_nfev.sum().item())
                 OB.observe_msefast(st, x, average=False, counter=counter)
-                assert np.array_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
-                    np.array_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (n, r, N(ob.max_val), st.max_val)
+                assert bits_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
+                    bits_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (n, r, N(ob.max_val), st.max_val)
             assert evals == counter[0], (n, evals, counter[0])
         # (shape, seq_pos, symmetric, view): "split" = [B,h,T,d] seen through [B,T,h,d] memory (quant_bert.py:128-150);
         # "zip" = BART's 3-D probabilities [B*h, T, S] masked with B lengths: remove_padding's zip keeps the first B rows (observer.py:82)
@@ -128,8 +129,8 @@ def test_ordered_msefast_equals_oracle_at_any_length(dev, width):
                 ob(torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), seq_pos)
                 evals += int(ob.last_nfev.sum().item())
                 OB.observe_msefast(st, x, lengths, seq_pos, average=True, counter=counter)
-                assert np.array_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
-                    np.array_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (shape, r, N(ob.min_val), st.min_val)
+                assert bits_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
+                    bits_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (shape, r, N(ob.min_val), st.min_val)
             assert evals == counter[0], (shape, evals, counter[0])
     finally:
         OB.MEAN_LIKE_TORCH = None
@@ -172,7 +173,7 @@ def test_lsqplus_site_size_gradients_equal_reference_in_its_summation_order(gold
     x, gy, scale, zp, gf = bwd_case(shape, kind, seed)
     if [checksum(x), checksum(gy)] != [int(v) for v in g[f"{name}_xsum"]]:
         pytest.skip("the seeded input differs from the fixture's (torch's CPU generator on this host)")
-    assert np.array_equal(scale.numpy(), g[f"{name}_scale"]) and np.array_equal(zp.numpy(), g[f"{name}_zp"])
+    assert bits_equal(scale.numpy(), g[f"{name}_scale"]) and bits_equal(zp.numpy(), g[f"{name}_zp"])
     xd = x.to(dev).requires_grad_(True)
     s = scale.to(dev).requires_grad_(True)
     z = zp.to(dev).requires_grad_(True)
@@ -180,7 +181,7 @@ def test_lsqplus_site_size_gradients_equal_reference_in_its_summation_order(gold
     y.backward(gy.to(dev))
     assert checksum(y) == int(g[f"{name}_ysum"][0])
     assert checksum(xd.grad) == int(g[f"{name}_dxsum"][0])
-    assert np.array_equal(N(s.grad), g[f"{name}_dscale"]) and np.array_equal(N(z.grad), g[f"{name}_dzp"]), \
+    assert bits_equal(N(s.grad), g[f"{name}_dscale"]) and bits_equal(N(z.grad), g[f"{name}_dzp"]), \
         (name, N(s.grad), g[f"{name}_dscale"], N(z.grad), g[f"{name}_dzp"])
 
 
@@ -231,8 +232,8 @@ def test_ordered_rounds_equal_search_by_search(dev, simd_width):
             assert len(sites.mse) == len(cases)
             sites.flush()
     for a, b in zip(one_by_one, rounds):
-        assert np.array_equal(N(a.min_val), N(b.min_val)) and np.array_equal(N(a.max_val), N(b.max_val))
-        assert np.array_equal(N(a.last_nfev), N(b.last_nfev))
+        assert bits_equal(N(a.min_val), N(b.min_val)) and bits_equal(N(a.max_val), N(b.max_val))
+        assert bits_equal(N(a.last_nfev), N(b.last_nfev))
 
 
 @pytest.mark.parametrize("round_groups", [1, 3, 40, 64])
@@ -265,7 +266,7 @@ def test_rounds_do_not_depend_on_the_workgroups_share_of_chunk_groups(dev, stric
 
     want, got = run(8), run(round_groups)
     for sh, a, b in zip(shapes, want, got):
-        assert all(np.array_equal(u, v) for u, v in zip(a, b)), (sh, round_groups, a, b)
+        assert all(bits_equal(u, v) for u, v in zip(a, b)), (sh, round_groups, a, b)
 
 
 def test_tensors_beyond_the_ordered_capacity_keep_order_free_sums(dev):
@@ -367,9 +368,9 @@ def test_small_sites_in_every_layout_equal_oracle_lone_and_in_rounds(dev):
                     OB.observe_msefast(st, x_np, L_np, seq_pos, average=True)
                     want = (np.asarray(st.min_val, dtype=np.float64), np.asarray(st.max_val, dtype=np.float64))
                     tag = (case, r, kind, shape, sym, positive, how, None if L_np is None else L_np.tolist())
-                    assert np.array_equal(N(lone.min_val).astype(np.float64), want[0]) and np.array_equal(N(lone.max_val).astype(np.float64), want[1]), \
+                    assert bits_equal(N(lone.min_val).astype(np.float64), want[0]) and bits_equal(N(lone.max_val).astype(np.float64), want[1]), \
                         str(("lone", tag, N(lone.min_val), N(lone.max_val), want))
-                    assert np.array_equal(N(inround.min_val).astype(np.float64), want[0]) and np.array_equal(N(inround.max_val).astype(np.float64), want[1]), \
+                    assert bits_equal(N(inround.min_val).astype(np.float64), want[0]) and bits_equal(N(inround.max_val).astype(np.float64), want[1]), \
                         str(("rounds", tag, N(inround.min_val), N(inround.max_val), want))
     finally:
         OB.MEAN_LIKE_TORCH = old
@@ -393,7 +394,7 @@ def test_backward_on_a_dense_permuted_input_follows_memory_order(dev, strict):
         dx, ds, dz = ops.lsq_backward_per_tensor(x, gy_logical, s, z, 0, 63, ops.PARAM_LSQPLUS, gf)
         rdx, rds, rdz = FQ.lsqplus_backward_per_tensor_reference_order(mem.reshape(-1), gmem.reshape(-1), scale, zp, 0, 63, gf, vec=8)
         assert dx.stride() == x.stride()
-        assert np.array_equal(N(dx.permute(0, 3, 1, 2).contiguous()).reshape(-1), rdx.reshape(-1)), (B, T, h, d)
+        assert bits_equal(N(dx.permute(0, 3, 1, 2).contiguous()).reshape(-1), rdx.reshape(-1)), (B, T, h, d)
         assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (B, T, h, d, ds.item(), rds, dz.item(), rdz)
 
 
@@ -437,4 +438,4 @@ def test_lean_float64_term_equals_the_full_chain(dev, strict):
             ops.set_tuning("mse_lean", 1)
     assert len(results[1]) == len(results[0])
     for i, (a, b) in enumerate(zip(results[1], results[0])):
-        assert all(np.array_equal(u, v) for u, v in zip(a, b)), (i, a, b)
+        assert all(bits_equal(u, v) for u, v in zip(a, b)), (i, a, b)

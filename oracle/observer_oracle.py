@@ -133,10 +133,49 @@ def torch_quantile_linear(values, q):
     return fma_f32(F32(w - F32(1)), diff, b)
 
 
+# ---- zero extrema --------------------------------------------------------------------------------------------------
+# torch's CPU min / max of data that holds BOTH -0.0 and +0.0 returns whichever zero sits in the winning SIMD lane
+# (`_mm256_min_ps` keeps its second operand when both are zero; the tree over a row depends on its length and the lane
+# the zeros fall in) -- the reference itself has no defined answer, and its hard-coded `.cuda()` path has yet another.
+# The restatement therefore fixes the one thing the reference leaves open with the IEEE 754-2019 minimum / maximum rule,
+# -0 < +0: a minimum that is zero is -0.0 if any -0.0 took part, a maximum that is zero is +0.0 if any +0.0 took part.
+# The device follows the same rule (v_min_f32 / v_max_f32 order the zeros that way), so statistics compare as BITS.
+# Everywhere the data holds zeros of one sign only -- every fixture captured from the reference -- nothing changes.
+
+def zmin(a, axis=None):
+    a = np.asarray(a)
+    r = np.asarray(a.min(axis=axis))
+    neg0 = np.asarray(((a == 0) & np.signbit(a)).any(axis=axis))
+    out = np.where((r == 0) & neg0, a.dtype.type(-0.0), np.where(r == 0, a.dtype.type(0.0), r)).astype(a.dtype)
+    return out if out.ndim else out.reshape(())[()]
+
+
+def zmax(a, axis=None):
+    a = np.asarray(a)
+    r = np.asarray(a.max(axis=axis))
+    pos0 = np.asarray(((a == 0) & ~np.signbit(a)).any(axis=axis))
+    out = np.where((r == 0) & ~pos0, a.dtype.type(-0.0), np.where(r == 0, a.dtype.type(0.0), r)).astype(a.dtype)
+    return out if out.ndim else out.reshape(())[()]
+
+
+def zminimum(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    r = np.minimum(a, b)
+    both0 = (a == 0) & (b == 0)
+    return np.where(both0, np.where(np.signbit(a) | np.signbit(b), r.dtype.type(-0.0), r.dtype.type(0.0)), r).astype(r.dtype)
+
+
+def zmaximum(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    r = np.maximum(a, b)
+    both0 = (a == 0) & (b == 0)
+    return np.where(both0, np.where(np.signbit(a) & np.signbit(b), r.dtype.type(-0.0), r.dtype.type(0.0)), r).astype(r.dtype)
+
+
 def token_min_max(value):
     """observer.py:64-65: per-token max and min over the feature axis of ``[N_tok, F]``."""
     value = np.asarray(value, dtype=F32)
-    return value.min(axis=1), value.max(axis=1)
+    return zmin(value, axis=1), zmax(value, axis=1)
 
 
 def prune_thresholds(token_min, token_max, percentile):
@@ -147,8 +186,8 @@ def prune_thresholds(token_min, token_max, percentile):
     """
     upper = torch_quantile_linear(np.abs(token_max), percentile)
     lower = -torch_quantile_linear(np.abs(token_min), percentile)
-    up = token_max[token_max <= upper].max()
-    lo = token_min[token_min >= lower].min()
+    up = zmax(token_max[token_max <= upper])
+    lo = zmin(token_min[token_min >= lower])
     return F32(lo), F32(up)
 
 
@@ -165,7 +204,7 @@ def prune_token(value, percentile, name=""):
 
 def aminmax(x):
     x = np.asarray(x, dtype=F32)
-    return F32(x.min()), F32(x.max())
+    return F32(zmin(x)), F32(zmax(x))
 
 
 def _to_channel_rows(x, ch_axis):
@@ -216,8 +255,8 @@ class ObserverState:
 
     # observer.py:143-144 (also 535-536)
     def _running_update(self, cur_min, cur_max):
-        self.min_val = np.minimum(self.min_val, cur_min)
-        self.max_val = np.maximum(self.max_val, cur_max)
+        self.min_val = zminimum(self.min_val, cur_min)
+        self.max_val = zmaximum(self.max_val, cur_max)
 
 
 def _prepare(x, lengths, seq_pos):
@@ -241,7 +280,7 @@ def observe_minmax(st, x, lengths=None, seq_pos=-1):
         cur_min, cur_max = aminmax(x)
     else:
         rows = _to_channel_rows(x, st.ch_axis)
-        cur_min, cur_max = rows.min(axis=1), rows.max(axis=1)
+        cur_min, cur_max = zmin(rows, axis=1), zmax(rows, axis=1)
     st._running_update(cur_min, cur_max)
 
 
@@ -425,7 +464,7 @@ def observe_msefast(st, x, lengths=None, seq_pos=-1, average=False, counter=None
         best_min, best_max = np.asarray(best_min), np.asarray(best_max)
     else:
         rows = _to_channel_rows(x, st.ch_axis)
-        best_min, best_max = rows.min(axis=1), rows.max(axis=1)
+        best_min, best_max = zmin(rows, axis=1), zmax(rows, axis=1)
         global MEAN_LIKE_TORCH
         row_order = MEAN_LIKE_TORCH is None and ROW_SUM_VEC is not None and rows.shape[1] < 32768 and rows.dtype == F32
         if row_order:

@@ -20,7 +20,7 @@ CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 _CONFIG_KEEP = ("workload", "launches_per_step", "buffers_cycled", "algorithmic_bytes_per_step", "hbm_bytes_per_step",
                 "valid_token_fraction", "launch_picked", "graph_us_per_step", "eager_us_per_step", "timed_regions",
                 "ms_per_step_min", "ms_per_step_max", "ms_per_step_regions", "pct_hbm_peak", "three_launch_path_ms_per_step")
-_ROOFLINE_KEEP = ROOFLINE_KEYS + ("kernel", "avg_launch_us", "median_launch_us", "launches_timed", "duration_source",
+_ROOFLINE_KEEP = ROOFLINE_KEYS + ("kernel", "avg_launch_us", "isolated_launch_us", "launches_timed", "duration_source",
                                   "algorithmic_bytes_per_launch", "frac_physical", "copy_rate", "frac_physical_of_copy_rate",
                                   "rocprof_avg_launch_us")
 _CPU_KEEP = CPU_KEYS + ("host_cores", "full_tensor_GiB_per_s")

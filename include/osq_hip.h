@@ -35,7 +35,7 @@ typedef void* osq_stream;
 /* Bumped whenever a signature or the workspace layout changes; the Python host refuses a library whose
  * osq_abi_version() differs from the number it was written against (a stale libosq_hip.so must be rebuilt).
  * 5: the LSQ / LSQ+ backward takes its summation order as an argument (`lanes` / `sum_lanes`). */
-#define OSQ_ABI_VERSION 5
+#define OSQ_ABI_VERSION 6
 
 typedef enum osq_status {
     OSQ_OK = 0,
@@ -60,7 +60,11 @@ typedef enum osq_param_mode {
      * zero_point.clamp_(quant_min, quant_max)), then quantise with the repaired values -- the same
      * result as osq_lsq_sanitize followed by the plain call, in one launch.  These entry points therefore take
      * `scale` / `zero_point` without a const qualifier; without the flag they only read them. */
-    OSQ_PARAM_SANITIZE = 16
+    OSQ_PARAM_SANITIZE = 16,
+    /* flag for osq_observe_tokens_fake_quant, OR-ed into `mode`: this call must not use the one-launch PERSISTENT form
+     * (a grid of one workgroup per CU whose workgroups wait for each other: it needs the whole device) --
+     * three ordinary launches instead, same results.  The per-call counterpart of osq_set_tuning("fused_step", 0). */
+    OSQ_PARAM_NO_PERSISTENT = 32
 } osq_param_mode;
 
 /* running-statistic rule applied after a batch's (min, max) is known */
@@ -88,25 +92,36 @@ const char* osq_last_error(void);
 int         osq_abi_version(void);
 size_t      osq_workspace_bytes(void);
 
-/* Performance / path-selection knobs (results never change):
- *   "fq_unroll" 2|4|8 independent 16-byte loads per lane, "fq_max_blocks" grid cap, "fq_nt" bit0/bit1 =
- *   streaming loads/stores of the dense fake-quant; "bwd_blocks" grid cap of the dense LSQ backward, "ln_blocks" of the LayerNorm site;
- *   "obs_blocks" grid cap of osq_observe_flat (768: power-of-two grids put a thread's strided loads on the
- *   same memory channels); "tok_nt" streaming loads in osq_token_minmax; "final_fast" 0 = token range
- *   finaliser without the two-workgroup kernel; "select_shortcut" 0 = that kernel always runs its register
- *   threshold pass; "select_hint" 0 = the selectors of the one-launch observe + fake-quant step do not pre-histogram a window around the
- *   observer's running statistic while the per-token extrema arrive (a hint moves time, never a result);
- *   "mse_sum_order" 8 | 16 = the MSEFast losses (rows and per-tensor searches of any length, osq_msefast_tensor_evals_ordered) are added in ATen's one-thread CPU
- *   order for 8- / 16-lane SIMD (oracle/aten_sum.py): results equal to the reference run on a one-thread host bit for bit.  The C library starts at 0; the Python host
- *   sets 8 when it loads the library (its default tier; OSQ_STRICT=0 keeps 0).  With the order set, per-tensor searches go through osq_msefast_tensor_evals_ordered
- *   (one launch per evaluation) or osq_msefast_ordered_multi_* (rounds: one launch per evaluation of up to 128 searches).  (The other whole-tensor sum of the path, the
- *   parameter gradients of the LSQ / LSQ+ backward, takes its order as an ARGUMENT: osq_lsq_backward_per_tensor_ordered(lanes), osq_lsq_backward_per_channel(sum_lanes).)
- *   "mse_round_groups" n / "bwd_order_chunks" n: chunk groups / level-1
- *   chunks a workgroup of those launches takes (4 / 4); "mse_sum_order" 64 = per-tensor sums as double-doubles, i.e. order-independent (test mode; one launch per evaluation); 0 = off;
- *   "mse_resident" 0 = per-tensor MSEFast searches run one launch per loss evaluation instead
- *   of the one-launch resident form (the last three exist so that tests can drive every implementation);
- *   "fused_spin_limit" / "mse_spin_limit" n: bound of the cross-workgroup waits of the two persistent launch families
- *   (0 = the default, ~2 s; n > 0 = n - 1 polls, so 1 makes every wait give up at once: tests force the time-out path). */
+/* Process-wide switches.  The RELEASE library accepts exactly these keys (atomic words, each read once per launch):
+ *   summation order (picks WHICH rounding of a whole-tensor sum is returned):
+ *     "mse_sum_order" 0 | 8 | 16 | 64   MSEFast losses: 8 / 16 = ATen's one-thread CPU order for 8- / 16-lane SIMD
+ *                                       (oracle/aten_sum.py; bit-equal to the reference run on a one-thread host), 64 = double-doubles
+ *                                       (order-independent; test mode), 0 = order-free.  The C library starts at 0; the Python
+ *                                       host sets 8 when it loads the library (its default tier; OSQ_STRICT=0 keeps 0).  With the
+ *                                       order set, per-tensor searches go through osq_msefast_tensor_evals_ordered (one launch per
+ *                                       evaluation) or osq_msefast_ordered_multi_* (rounds).
+ *     "mse_rows_order" 0 | 8 | 16       the per-channel rows' losses likewise (default 8).
+ *     (The other whole-tensor sum of the path, the parameter gradients of the LSQ / LSQ+ backward, takes its order as an
+ *     ARGUMENT: osq_lsq_backward_per_tensor_ordered(lanes), osq_lsq_backward_per_channel(sum_lanes).)
+ *   path selection (results equal; tests drive every implementation through them):
+ *     "fused_step" 0     osq_observe_tokens_fake_quant never uses its one-launch persistent form (per call:
+ *                        OSQ_PARAM_NO_PERSISTENT in `mode`; per process also OSQ_FUSED_STEP=0 in the environment);
+ *     "mse_resident" 0   per-tensor MSEFast searches of the order-free tier run one launch per evaluation instead of the
+ *                        persistent resident form;
+ *     "final_fast" 0     the token range finaliser without the two-workgroup kernel; "select_shortcut" 0: that kernel always
+ *                        runs its register threshold pass;
+ *   robustness:
+ *     "fused_spin_limit" / "mse_spin_limit" n   bound of the cross-workgroup waits of the two persistent launch families
+ *                        (0 = the default, ~2 s; n > 0 = n - 1 polls, so 1 makes every wait give up at once: tests force the
+ *                        time-out path).
+ * Performance A/B knobs -- "fq_unroll", "fq_max_blocks", "fq_nt", "fq_headsplit", "stream_wt", "bwd_blocks", "bwd_order_chunks",
+ * "ln_blocks", "obs_blocks", "tok_nt", "fused_gate", "fused_grid", "select_hint", "mse_round_groups" (8), "mse_lean" (1),
+ * "mse_grid_all" -- are compile-time constants (the measured winners) in the release library, which answers
+ * OSQ_ERR_INVALID_ARGUMENT for them; only the -DOSQ_TUNABLE development build (`make dbg`: libosq_hip_dbg.so) keeps them as
+ * variables.  osq_build_flags(): bit 0 = that build, bit 1 = phase timestamps compiled in (-DOSQ_FINAL_TIMING). */
+#define OSQ_BUILD_TUNABLE 1
+#define OSQ_BUILD_FINAL_TIMING 2
+int osq_build_flags(void);
 int osq_set_tuning(const char* key, int value);
 
 /* Measurement aid (bench.py).  The events given to osq_time_next_launch ride on the dispatch packet of the

@@ -199,7 +199,7 @@ def prune_token(value, percentile, name=""):
     tmin, tmax = token_min_max(value)
     lo, up = prune_thresholds(tmin, tmax, percentile)
     # torch.clip(value, min=lo, max=up) == min(max(value, lo), up)
-    return np.minimum(np.maximum(value, lo), up)
+    return zminimum(zmaximum(value, lo), up)       # zero signs by the rule above (torch.clip leaves them to the lane)
 
 
 def aminmax(x):

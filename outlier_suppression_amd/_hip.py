@@ -18,14 +18,14 @@ LIB_PATH = os.environ.get("OSQ_HIP_LIBRARY") or os.path.join(_HERE, "libosq_hip.
 # zero-point storage / parameter mode / update rule (mirrors include/osq_hip.h)
 ZP_INT32, ZP_FLOAT32 = 0, 1
 PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS = 0, 1, 2
-PARAM_MODE_MASK, PARAM_SANITIZE = 3, 16
+PARAM_MODE_MASK, PARAM_SANITIZE, PARAM_NO_PERSISTENT = 3, 16, 32
 TIME_FAKE_QUANT, TIME_LSQ_BACKWARD, TIME_OBSERVE_FLAT, TIME_TOKEN_MINMAX, TIME_TOKEN_SELECT = 1, 2, 3, 4, 5
 TIME_LAYERNORM, TIME_FUSED_STEP = 6, 7
 TIME_FAKE_QUANT_STRIDED, TIME_FAKE_QUANT_CHANNEL, TIME_OBSERVE_CHANNELS, TIME_TOKEN_MINMAX_MULTI, TIME_MSEFAST_ROWS = 8, 9, 10, 11, 12
 TIME_OBSERVE_TOKENS = 13
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
-ABI_VERSION = 5               # OSQ_ABI_VERSION of include/osq_hip.h this file was written against
+ABI_VERSION = 6               # OSQ_ABI_VERSION of include/osq_hip.h this file was written against
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -63,6 +63,7 @@ class SiteDesc(ctypes.Structure):
 SIGNATURES = {
     "osq_last_error": (ctypes.c_char_p, []),
     "osq_abi_version": (_I, []),
+    "osq_build_flags": (_I, []),
     "osq_workspace_bytes": (ctypes.c_size_t, []),
     "osq_set_tuning": (_I, [ctypes.c_char_p, _I]),
     "osq_timing_events_create": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P)]),

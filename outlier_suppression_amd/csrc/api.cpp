@@ -68,4 +68,14 @@ extern "C" int osq_timing_elapsed_us(void* start, void* stop, float* us) {
 
 extern "C" const char* osq_last_error(void) { return osq::g_error; }
 extern "C" int osq_abi_version(void) { return OSQ_ABI_VERSION; }
+extern "C" int osq_build_flags(void) {
+    int f = 0;
+#ifdef OSQ_TUNABLE
+    f |= OSQ_BUILD_TUNABLE;
+#endif
+#ifdef OSQ_FINAL_TIMING
+    f |= OSQ_BUILD_FINAL_TIMING;
+#endif
+    return f;
+}
 extern "C" size_t osq_workspace_bytes(void) { return osq::kWsHeaderBytes + osq::kWsScratchBytes + osq::kWsWideBytes + osq::kWsMeetBytes + osq::kWsFusedBytes + osq::kWsResidentBytes; }

@@ -19,14 +19,14 @@ constexpr int kUnroll = 4;   // float4 loads in flight per lane (per-channel ker
 
 // tuning knobs of the dense per-tensor kernel (osq_set_tuning): loads in flight per lane, grid cap, and
 // whether loads / stores carry the non-temporal hint
-static int g_fq_unroll = 2;          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
-static int g_bwd_ord_chunks = 4;     // osq_set_tuning("bwd_order_chunks", n): level-1 chunks per workgroup of the reference-order backward
+OSQ_AB_KNOB(int, g_fq_unroll, 2);          // tools/fq_sweep.py on MI355X: (2, 8192, nt loads+stores) best median, all within ~10 %
+OSQ_AB_KNOB(int, g_bwd_ord_chunks, 4);     // osq_set_tuning("bwd_order_chunks", n): level-1 chunks per workgroup of the reference-order backward
 // the summation order of the LSQ / LSQ+ backward (ATen's one-thread CPU order on 8- / 16-lane vectors, lsq_bwd_tensor_ordered_kernel) is an ARGUMENT of the entry points, not library state
-static int g_fq_max_blocks = 8192;
-static int g_fq_headsplit = 1;       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
-static int g_fq_nt = 5;          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
-static int g_stream_wt = 1;      // osq_set_tuning("stream_wt", 0): nt stores instead of write-through ones in the LSQ backward and the GELU fake-quant (measured no gain, or a loss, in the LayerNorm site)
-static int g_bwd_blocks = 1792;   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n)); tools/bwd_ab.py on MI355X, [256,128,768]:
+OSQ_AB_KNOB(int, g_fq_max_blocks, 8192);
+OSQ_AB_KNOB(int, g_fq_headsplit, 1);       // osq_set_tuning("fq_headsplit", 0): the head-split views run the generic strided kernel (A/B; results are equal)
+OSQ_AB_KNOB(int, g_fq_nt, 5);          // bit 0: nt loads, bit 1: nt stores, 4 / 5: write-through (sc1) stores without / with nt loads
+OSQ_AB_KNOB(int, g_stream_wt, 1);      // osq_set_tuning("stream_wt", 0): nt stores instead of write-through ones in the LSQ backward and the GELU fake-quant (measured no gain, or a loss, in the LayerNorm site)
+OSQ_AB_KNOB(int, g_bwd_blocks, 1792);   // grid cap of the dense LSQ backward (osq_set_tuning("bwd_blocks", n)); tools/bwd_ab.py on MI355X, [256,128,768]:
                                   // 2048 (every wave slot of the chip): 60.3 us, 1792 (7 workgroups per CU): 53.1, 1536: 53.7, 1024: 55.0, 512: 65.2
 
 template <bool WRITE_Q>
@@ -1029,17 +1029,27 @@ extern "C" int osq_fake_quant_weights_multi(const osq_weight_desc* descs, const 
 extern "C" int osq_set_tuning(const char* key, int value) {
     OSQ_REQUIRE(key, "set_tuning: null key");
     const std::string k(key);
-    if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
+    if (false) { }
+#ifdef OSQ_TUNABLE
+    else if (k == "fq_unroll") { OSQ_REQUIRE(value == 2 || value == 4 || value == 8, "fq_unroll must be 2, 4 or 8"); osq::g_fq_unroll = value; }
     else if (k == "bwd_order_chunks") { OSQ_REQUIRE(value >= 1 && value <= 64, "bwd_order_chunks must be 1..64"); osq::g_bwd_ord_chunks = value; }
     else if (k == "fq_headsplit") { osq::g_fq_headsplit = value != 0; }
     else if (k == "fq_max_blocks") { OSQ_REQUIRE(value >= 1, "fq_max_blocks must be positive"); osq::g_fq_max_blocks = value; }
     else if (k == "bwd_blocks") { OSQ_REQUIRE(value >= 1 && value <= kMaxBlocks, "bwd_blocks must be 1..2048"); osq::g_bwd_blocks = value; }
     else if (k == "stream_wt") { osq::g_stream_wt = value != 0; }
     else if (k == "fq_nt") { OSQ_REQUIRE(value >= 0 && value <= 5, "fq_nt must be 0..5"); osq::g_fq_nt = value; }
+#endif
     else if (osq::set_observer_tuning(key, value)) { }
     else if (osq::set_msefast_tuning(key, value)) { }
     else if (osq::set_layernorm_tuning(key, value)) { }
     else if (osq::set_extra_tuning(key, value)) { }
-    else { osq::set_error("set_tuning: unknown key %s", key); return OSQ_ERR_INVALID_ARGUMENT; }
+    else {
+#ifdef OSQ_TUNABLE
+        osq::set_error("set_tuning: unknown key %s", key);
+#else
+        osq::set_error("set_tuning: unknown key %s (performance A/B knobs exist only in the -DOSQ_TUNABLE build, `make dbg`)", key);
+#endif
+        return OSQ_ERR_INVALID_ARGUMENT;
+    }
     return OSQ_OK;
 }

@@ -23,7 +23,7 @@ namespace osq {
 
 constexpr int kLnThreads = 256;
 constexpr int kLnWaves = kLnThreads / OSQ_WAVE;
-static int g_ln_blocks = 1024;      // grid cap (osq_set_tuning("ln_blocks", n)); rows are grid-strided above it.  tools/bwd_ab.py on MI355X,
+OSQ_AB_KNOB(int, g_ln_blocks, 1024);      // grid cap (osq_set_tuning("ln_blocks", n)); rows are grid-strided above it.  tools/bwd_ab.py on MI355X,
                                     // [256,128,768]: one row per wave (8192 workgroups) 58.2 us, 2048: 51.6, 1024: 51.2, 768: 51.1, 512: 60.0; [32,384,768]: 23.6 -> 21.1
 
 template <int CTRL>
@@ -135,7 +135,9 @@ __global__ __launch_bounds__(kLnThreads) void residual_layernorm_fq_kernel(LnArg
 }
 
 bool set_layernorm_tuning(const char* key, int value) {
+#ifdef OSQ_TUNABLE
     if (std::string(key) == "ln_blocks" && value >= 1) { g_ln_blocks = value; return true; }
+#endif
     return false;
 }
 

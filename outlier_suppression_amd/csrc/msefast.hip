@@ -1003,11 +1003,11 @@ constexpr int kResWaves = kResThreads / OSQ_WAVE;
 constexpr int kResMaxSlots = 32;                     // float4 per lane
 constexpr int kResMaxBatch = kResThreads;            // prefix sums of the lengths: one sample per thread
 constexpr unsigned int kResSpinLimit = 1u << 22;
-static int g_mse_rows_order = 8;                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
-static int g_mse_dbg = 0;                            // -DOSQ_MSE_DBG builds only (tools/mse_dbg_probe.py): 1 = generated values instead of data loads, 2 = a conversion instead of the term; WRONG results, timing probes
-static int g_mse_lean = 1;                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
-static int g_mse_sum_order = 0;                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
-static unsigned int g_res_spin_limit = 0;            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
+OSQ_SWITCH(int, g_mse_rows_order, 8);                     // osq_set_tuning("mse_rows_order", 0 | 8 | 16): the per-channel rows' loss in ATen's CPU order (8 lanes: x86 torch), 0 = order-free
+OSQ_AB_KNOB(int, g_mse_dbg, 0);                            // -DOSQ_MSE_DBG builds only (tools/mse_dbg_probe.py): 1 = generated values instead of data loads, 2 = a conversion instead of the term; WRONG results, timing probes
+OSQ_AB_KNOB(int, g_mse_lean, 1);                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
+OSQ_SWITCH(int, g_mse_sum_order, 0);                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
+OSQ_SWITCH(unsigned int, g_res_spin_limit, 0u);            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
     unsigned int epoch, pad0[15];                        // tags handed out so far
@@ -1651,7 +1651,7 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     return check_launch("msefast_tensor_evals_ordered");
 }
 
-static int g_ord_groups = 8;          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
+OSQ_AB_KNOB(int, g_ord_groups, 8);          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
     // site table, ticket counters, block -> site map (one byte per workgroup of a round, at most kMaxBlocks per site)
@@ -1725,15 +1725,17 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
 
 // osq_set_tuning("mse_resident", 0), or OSQ_FUSED_STEP=0 in the environment (the switch for processes that SHARE a GPU:
 // persistent grids of two processes cannot be ordered against each other): per-tensor searches run one launch per evaluation
-static int g_mse_resident = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
+static std::atomic<int> g_mse_resident{[] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }()};
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
+#ifdef OSQ_TUNABLE
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
 #ifdef OSQ_MSE_DBG
     if (std::string(key) == "mse_dbg") { g_mse_dbg = value & 3; return true; }
+#endif
 #endif
     if (std::string(key) == "mse_spin_limit") { if (value < 0) return false; g_res_spin_limit = static_cast<unsigned int>(value); return true; }
     return false;

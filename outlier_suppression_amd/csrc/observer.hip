@@ -891,20 +891,20 @@ namespace osq {
 // each is dominated by launch + dependent-load latency, not work) -- so the wide path only takes over
 // above the register-cache limit of the single-workgroup kernel, where that kernel would re-read the
 // arrays from L2 in every pass (~25 us per pass at 65536 slots).  osq_set_wide_min_slots() overrides.
-static int64_t g_wide_min_slots = 32769;
+OSQ_SWITCH(int64_t, g_wide_min_slots, 32769);
 // Grid cap of observe_flat (osq_set_tuning("obs_blocks", n), <= kMaxBlocks).  The four loads of a thread are
 // gridDim.x * 4 KB apart: power-of-two grids (1024, 2048) put them on the same memory channels and measured
 // 21.2 us on the [256,128,768] tensor against 18.8 us at 768 (tools/obs_sweep.py).
-static int g_obs_blocks = 768;
-static int g_tok_nt = 1;              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
-static int g_select_shortcut = 1;     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
-static int g_final_fast = 1;          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
+OSQ_AB_KNOB(int, g_obs_blocks, 768);
+OSQ_AB_KNOB(int, g_tok_nt, 1);              // osq_set_tuning("tok_nt", 0): per-token kernel loads without the streaming hint
+OSQ_SWITCH(int, g_select_shortcut, 1);     // osq_set_tuning("select_shortcut", 0): always run the register threshold pass (tests)
+OSQ_SWITCH(int, g_final_fast, 1);          // osq_set_tuning("final_fast", 0) forces the single-workgroup kernel (tests)
 // osq_set_tuning("fused_step", 0) or OSQ_FUSED_STEP=0 in the environment: observe + fake-quant as three launches
-static int g_fused_step = [] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_fused_gate = 2;          // osq_set_tuning("fused_gate", 0|1|2): which padded loads wait for the selectors (fused_step.h, phase A2)
-static int g_select_hint = 1;          // osq_set_tuning("select_hint", 0|1): the fused step's selectors histogram a window around the running statistic while the extrema arrive (token_select.h, HINT)
-static unsigned int g_fused_spin_limit = 0;     // osq_set_tuning("fused_spin_limit", n): 0 = kFusedSpinLimit, n > 0 = n - 1 polls (1: every wait gives up at once -- tests force the time-out path with it)
-static int g_fused_grid = 0;          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
+static std::atomic<int> g_fused_step{[] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }()};
+OSQ_AB_KNOB(int, g_fused_gate, 2);          // osq_set_tuning("fused_gate", 0|1|2): which padded loads wait for the selectors (fused_step.h, phase A2)
+OSQ_AB_KNOB(int, g_select_hint, 1);          // osq_set_tuning("select_hint", 0|1): the fused step's selectors histogram a window around the running statistic while the extrema arrive (token_select.h, HINT)
+OSQ_SWITCH(unsigned int, g_fused_spin_limit, 0u);     // osq_set_tuning("fused_spin_limit", n): 0 = kFusedSpinLimit, n > 0 = n - 1 polls (1: every wait gives up at once -- tests force the time-out path with it)
+OSQ_AB_KNOB(int, g_fused_grid, 0);          // osq_set_tuning("fused_grid", n): workgroups of the fused launch (0 = one per CU)
 constexpr int kWideThreads = 256;
 constexpr int kWideSlotsPerBlock = 512;
 constexpr int kCoarseShift = 20;
@@ -1311,13 +1311,15 @@ bool set_observer_tuning(const char* key, int value) {
     const std::string k(key);
     if (k == "final_fast") { g_final_fast = value != 0; return true; }
     if (k == "fused_step") { g_fused_step = value != 0; return true; }
+    if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
+    if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
+#ifdef OSQ_TUNABLE
     if (k == "fused_gate") { if (value < 0 || value > 2) return false; g_fused_gate = value; return true; }
     if (k == "fused_grid") { if (value != 0 && value < 3) return false; g_fused_grid = value; return true; }
-    if (k == "fused_spin_limit") { if (value < 0) return false; g_fused_spin_limit = static_cast<unsigned int>(value); return true; }
     if (k == "tok_nt") { g_tok_nt = value != 0; return true; }
-    if (k == "select_shortcut") { g_select_shortcut = value != 0; return true; }
     if (k == "select_hint") { g_select_hint = value != 0; return true; }
     if (k == "obs_blocks") { if (value < 1 || value > kMaxBlocks) return false; g_obs_blocks = value; return true; }
+#endif
     return false;
 }
 
@@ -1639,7 +1641,11 @@ extern "C" int osq_observe_tokens_fake_quant(const float* x, const osq_token_vie
     const bool dense_rows = v.feat_outer == 1 && v.stride_inner == 1 && v.stride_token == v.feat_inner &&
                             v.stride_batch == v.tokens * v.feat_inner && n == slots * v.feat_inner;
     const int64_t nv = v.feat_inner / 256;
-    if (g_fused_step && workspace && token_min && token_max && dense_rows && v.feat_inner % 256 == 0 &&
+    // OSQ_PARAM_NO_PERSISTENT in `mode`: THIS call runs as three ordinary launches whatever the process-wide switch says (a
+    // caller with several streams or tenants on the device: the one-launch form wants every CU for itself)
+    const bool want_persistent = g_fused_step && !(mode & OSQ_PARAM_NO_PERSISTENT);
+    mode &= ~OSQ_PARAM_NO_PERSISTENT;
+    if (want_persistent && workspace && token_min && token_max && dense_rows && v.feat_inner % 256 == 0 &&
         (nv == 3 || nv == 4 || nv == 12 || nv == 16) && v.batch >= 1 && v.batch <= kFusedMaxBatch && v.tokens >= 1 &&
         (slots & 3) == 0 && slots <= 4 * 8 * kSelThreads && n * 4 < (1ll << 32) && aligned16(x) && aligned16(y) && aligned16(token_min) && aligned16(token_max)) {
         const char* why = "";

@@ -669,10 +669,12 @@ extern "C" int osq_selftest_division(const float* x, const float* s, int64_t n, 
     return check_launch("selftest_division");
 }
 
-static int g_mse_grid_all = 1;       // osq_set_tuning("mse_grid_all", 0): the per-tensor MSE grid as one launch per 32 candidates (A/B, tests)
+OSQ_AB_KNOB(int, g_mse_grid_all, 1);       // osq_set_tuning("mse_grid_all", 0): the per-tensor MSE grid as one launch per 32 candidates (A/B, tests)
 namespace osq {
 bool set_extra_tuning(const char* key, int value) {
+#ifdef OSQ_TUNABLE
     if (std::string(key) == "mse_grid_all") { g_mse_grid_all = value != 0; return true; }
+#endif
     return false;
 }
 }  // namespace osq

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/osq_hip.h"
 
 namespace osq {
@@ -24,6 +25,20 @@ constexpr int kResidentMaxBlocks = 512;              // workgroups of the reside
 constexpr int kResidentMaxSites = 16;                // searches one multi-site launch can hold (one polling wave each)
 constexpr size_t kWsResidentBytes = 128 + 2 * static_cast<size_t>(kResidentMaxSites) * kResidentMaxBlocks * 2 * 8;   // its epoch / status words + two buffers of partial-sum granules per site
 
+
+// Process-wide state behind osq_set_tuning comes in two kinds:
+//   OSQ_SWITCH   what SHIPS: switches that select a summation order, a path (persistent launch or not, which finaliser) or
+//                the bound of a cross-workgroup wait.  std::atomic, relaxed: a thread that flips one while another launches
+//                is a race on a word, not undefined behaviour; every launch reads each switch once.
+//   OSQ_AB_KNOB  performance A/B knobs (grid caps, unroll factors, cache hints, pipeline depths).  The measured winners are
+//                compile-time constants in the release library; only a -DOSQ_TUNABLE build (`make dbg`, libosq_hip_dbg.so)
+//                keeps them as variables and accepts their keys -- osq_build_flags() tells the two apart.
+#define OSQ_SWITCH(type, name, value) static std::atomic<type> name{value}
+#ifdef OSQ_TUNABLE
+#define OSQ_AB_KNOB(type, name, value) static type name = value
+#else
+#define OSQ_AB_KNOB(type, name, value) static constexpr type name = value
+#endif
 
 void set_error(const char* fmt, ...);
 bool set_observer_tuning(const char* key, int value);   // observer.hip: knobs reached through osq_set_tuning

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import (PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, PARAM_MODE_MASK, PARAM_SANITIZE, UPDATE_AVERAGE,  # noqa: F401
+from ._hip import (PARAM_FIXED, PARAM_LSQ, PARAM_LSQPLUS, PARAM_MODE_MASK, PARAM_SANITIZE, PARAM_NO_PERSISTENT, UPDATE_AVERAGE,  # noqa: F401
                    UPDATE_NONE, UPDATE_RUNNING, ZP_FLOAT32, ZP_INT32)
 
 
@@ -352,6 +352,12 @@ _wide_min_slots = 32769
 _tuning = {}          # what set_tuning has been given (the summation-order switches decide which entry point a call takes)
 
 
+def tunable_build():
+    """True when the loaded library is the -DOSQ_TUNABLE development build (`make dbg`), whose osq_set_tuning also accepts
+    the performance A/B knobs; the release library holds their measured winners as compile-time constants."""
+    return bool((_hip._lib or _hip.load()).osq_build_flags() & 1)
+
+
 def set_tuning(key, value, lib=None):
     """Performance / path-selection knobs of the library (osq_set_tuning).  Results never change -- except for the two
     summation-order switches ("mse_sum_order", "bwd_sum_order": 8 / 16 = the reference's one-thread CPU order, see
@@ -519,10 +525,14 @@ def observe_tokens(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, m
 
 
 def observe_tokens_fake_quant(x, seq_pos, lengths, prune, percentile, rule, cnt, min_val, max_val, quant_min, quant_max,
-                              symmetric, scale, zero_point, mode, grad_factor, cur=None):
+                              symmetric, scale, zero_point, mode, grad_factor, cur=None, persistent=True):
     """A whole quantizer call (observe the masked activation, refresh scale / zero_point, fake-quantise) behind ONE
     call of the binding.  x: dense fp32 on the device.  cur: 2-float device slot that also receives this batch's own
-    (min, max) while the running statistic moves as usual.  Returns (y, batch, tokens, lengths_int64)."""
+    (min, max) while the running statistic moves as usual.  persistent=False: THIS call runs as three ordinary launches
+    instead of the one-launch persistent form (a grid that needs every CU of the device for itself -- a caller that shares the
+    GPU across streams or tenants opts out per call; same results).  Returns (y, batch, tokens, lengths_int64)."""
+    if not persistent:
+        mode = mode | PARAM_NO_PERSISTENT
     lib = _hip._lib or _hip.load()
     if not (lengths.is_cuda and scale.is_cuda and zero_point.is_cuda and min_val.is_cuda):
         _hip.require_device(x, lengths, scale, zero_point, min_val, max_val)

@@ -18,6 +18,10 @@ class QuantizeBase(nn.Module):
     """fake_quant.py:15-97."""
 
     param_mode = PARAM_FIXED
+    # False (on the class, a module, or per call: forward(..., persistent=False)): the calibrate-and-quantize call never takes
+    # its one-launch persistent form, which needs every CU of the device for itself (INTEGRATION.md, "persistent launches") --
+    # for callers that run several streams or tenants on one GPU.  Results are the same either way.
+    persistent = True
 
     def __init__(self, observer=MinMaxObserver, bit=8, symmetric=False, ch_axis=-1):
         super().__init__()
@@ -97,10 +101,11 @@ class QuantizeBase(nn.Module):
             ops.calculate_qparams(obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric,
                                   scale_out=scale, zero_point_out=zero_point)
 
-    def _observe_and_quantize(self, X, observation_mask, seq_pos):
+    def _observe_and_quantize(self, X, observation_mask, seq_pos, persistent=None):
         """Both flags on, masked per-tensor activation, no gradient wanted: the whole call (per-token extrema, range
         selection, running statistic, qparams, fake-quant) is ONE call of the binding.  Returns None when the
-        general two-step path has to run."""
+        general two-step path has to run.  persistent (None: the module's `persistent` attribute, default True): False
+        keeps this call off the one-launch persistent form (ops.observe_tokens_fake_quant)."""
         obs = self.observer
         if (observation_mask is None or self.ch_axis != -1 or not X.is_cuda or X.dtype != torch.float32
                 or not X.is_contiguous() or X.numel() == 0 or X.dim() not in (3, 4)
@@ -118,7 +123,7 @@ class QuantizeBase(nn.Module):
         y, batch, tokens, lengths = ops.observe_tokens_fake_quant(
             X, seq_pos, observation_mask, prune, getattr(obs, "percentile", 1.0), obs.update_rule, obs._counter(),
             obs.min_val, obs.max_val, self.quant_min, self.quant_max, self.symmetric, scale, zero_point, self.param_mode, gf,
-            obs.__dict__.get("_record"))
+            obs.__dict__.get("_record"), persistent=self.persistent if persistent is None else persistent)
         object.__setattr__(obs, "_last_site", ("tokens", batch, tokens, lengths))
         obs._bump()
         return y
@@ -177,9 +182,9 @@ class FixedFakeQuantize(QuantizeBase):
         self.register_buffer("scale", torch.tensor([1.0], dtype=torch.float))
         self.register_buffer("zero_point", torch.tensor([0], dtype=torch.int))
 
-    def forward(self, X, observation_mask=None, seq_pos=-1):
+    def forward(self, X, observation_mask=None, seq_pos=-1, persistent=None):
         if self.observer_enabled == 1 and self.fake_quant_enabled == 1:
-            y = self._observe_and_quantize(X, observation_mask, seq_pos)
+            y = self._observe_and_quantize(X, observation_mask, seq_pos, persistent)
             if y is not None:
                 return y
         if self.observer_enabled == 1:
@@ -206,10 +211,10 @@ class _LearnableFakeQuantize(QuantizeBase):
             raise RuntimeError("outlier_suppression_amd: quantizer parameters are not on a HIP device; "
                                "move the model with .cuda() (there is no CPU path)")
 
-    def forward(self, X, observation_mask=None, seq_pos=-1):
+    def forward(self, X, observation_mask=None, seq_pos=-1, persistent=None):
         flags = 0
         if self.observer_enabled == 1 and self.fake_quant_enabled == 1:
-            y = self._observe_and_quantize(X, observation_mask, seq_pos)
+            y = self._observe_and_quantize(X, observation_mask, seq_pos, persistent)
             if y is not None:
                 return y
         if self.observer_enabled == 1:

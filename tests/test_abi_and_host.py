@@ -44,6 +44,54 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"percentile" in lib.osq_last_error()
 
 
+SHIPPED_SWITCHES = {"mse_sum_order": (0, 8), "mse_rows_order": (8, 8), "fused_step": (0, 1), "mse_resident": (0, 1), "final_fast": (0, 1),
+                    "select_shortcut": (0, 1), "fused_spin_limit": (5, 0), "mse_spin_limit": (5, 0)}
+AB_KNOBS = ("fq_unroll", "fq_max_blocks", "fq_nt", "fq_headsplit", "stream_wt", "bwd_blocks", "bwd_order_chunks", "ln_blocks",
+            "obs_blocks", "tok_nt", "fused_gate", "fused_grid", "select_hint", "mse_round_groups", "mse_lean", "mse_grid_all", "mse_dbg")
+
+
+def test_release_library_accepts_only_the_shipped_switches():
+    """osq_set_tuning of the RELEASE library: the summation-order, path-selection and wait-bound switches only; the
+    performance A/B knobs are compile-time constants there (their keys are refused) and variables only in the
+    -DOSQ_TUNABLE build (`make dbg`), which osq_build_flags() identifies."""
+    from outlier_suppression_amd import _hip
+    lib = _hip.load()
+    if os.environ.get("OSQ_HIP_LIBRARY"):
+        pytest.skip("another build was asked for through OSQ_HIP_LIBRARY")
+    assert lib.osq_build_flags() == 0, "the in-tree libosq_hip.so must be the release build"
+    prev = {}
+    from outlier_suppression_amd import ops
+    for key, (probe, back) in SHIPPED_SWITCHES.items():
+        assert lib.osq_set_tuning(key.encode(), probe) == 0, (key, lib.osq_last_error())
+        prev[key] = ops._tuning.get(key, back)
+        assert lib.osq_set_tuning(key.encode(), prev[key]) == 0, key
+    for key in AB_KNOBS:
+        assert lib.osq_set_tuning(key.encode(), 1) == -1, f"{key}: an A/B knob must not be settable in the release library"
+        assert b"unknown key" in lib.osq_last_error()
+    assert lib.osq_set_tuning(b"no_such_key", 1) == -1
+    # what the header documents is what the library does
+    header = open(os.path.join(ROOT, "include", "osq_hip.h")).read()
+    for key in list(SHIPPED_SWITCHES) + [k for k in AB_KNOBS if k != "mse_dbg"]:
+        assert f'"{key}"' in header, f"{key} is not documented at osq_set_tuning in include/osq_hip.h"
+
+
+def test_per_call_escape_from_persistent_launches_is_part_of_the_module_api():
+    """QuantizeBase.forward(..., persistent=False) / the `persistent` attribute / ops.observe_tokens_fake_quant(persistent=)
+    reach OSQ_PARAM_NO_PERSISTENT (include/osq_hip.h): a multi-stream caller keeps one call off the whole-GPU launch without a
+    process-global switch."""
+    import inspect
+    from outlier_suppression_amd import _hip, ops
+    from outlier_suppression_amd.quantization.fake_quant import FixedFakeQuantize, LSQPlusFakeQuantize, QuantizeBase
+    header = open(os.path.join(ROOT, "include", "osq_hip.h")).read()
+    assert re.search(r"OSQ_PARAM_NO_PERSISTENT\s*=\s*32", header) and _hip.PARAM_NO_PERSISTENT == 32
+    assert QuantizeBase.persistent is True
+    for cls in (FixedFakeQuantize, LSQPlusFakeQuantize):
+        sig = inspect.signature(cls.forward)
+        assert list(sig.parameters)[:4] == ["self", "X", "observation_mask", "seq_pos"]          # the reference's signature first
+        assert sig.parameters["persistent"].default is None
+    assert inspect.signature(ops.observe_tokens_fake_quant).parameters["persistent"].default is True
+
+
 def test_no_cpu_fallback():
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization import Quantizer

@@ -77,6 +77,49 @@ def test_fused_step_vs_oracle(shape, eq32, dev):
     assert fused_status(dev) == 0
 
 
+def test_per_call_escape_from_the_persistent_launch(eq32, dev):
+    """forward(..., persistent=False) (and the module attribute) keeps ONE call off the whole-GPU one-launch form
+    (OSQ_PARAM_NO_PERSISTENT, include/osq_hip.h): the dispatch events armed for the fused kernel family stay unrecorded, the
+    results -- output, statistics, parameters -- are the one-launch form's bit for bit, and the next plain call is
+    persistent again."""
+    import ctypes
+    from outlier_suppression_amd import _hip
+    lib = _hip.load()
+    gen = torch.Generator().manual_seed(77)
+    x = [torch.randn(8, 64, 768, generator=gen).to(dev) * (1 + i) for i in range(3)]
+    L = torch.randint(1, 65, (8,), generator=gen).to(dev)
+
+    def fused_launch_seen(call):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _hip.check(lib.osq_timing_events_create(ctypes.byref(a), ctypes.byref(b)), "events")
+        lib.osq_time_next_launch(_hip.TIME_FUSED_STEP, a, b)
+        y = call()
+        torch.cuda.synchronize()
+        us = ctypes.c_float()
+        seen = lib.osq_timing_elapsed_us(a, b, ctypes.byref(us)) == 0        # unrecorded events: error, nothing of that family ran
+        lib.osq_time_next_launch(0, None, None)
+        lib.osq_timing_events_destroy(a, b)
+        return seen, y
+
+    qa, qb, qc = (make(dev, "LSQPlusFakeQuantize", "AvgPruneMinMaxObserver", False) for _ in range(3))
+    qc.persistent = False
+    with torch.no_grad():
+        for i in range(3):
+            seen_a, ya = fused_launch_seen(lambda: qa(x[i], L, 1))
+            seen_b, yb = fused_launch_seen(lambda: qb(x[i], L, 1, persistent=False))
+            seen_c, yc = fused_launch_seen(lambda: qc(x[i], L, 1))
+            assert seen_a and not seen_b and not seen_c, (i, seen_a, seen_b, seen_c)
+            for q, y in ((qb, yb), (qc, yc)):
+                assert eq32(y.cpu().numpy(), ya.cpu().numpy()), i
+                assert eq32(q.scale.detach().cpu().numpy(), qa.scale.detach().cpu().numpy())
+                assert eq32(q.zero_point.detach().cpu().numpy(), qa.zero_point.detach().cpu().numpy())
+                assert eq32(q.observer.min_val.cpu().numpy(), qa.observer.min_val.cpu().numpy())
+                assert eq32(q.observer.max_val.cpu().numpy(), qa.observer.max_val.cpu().numpy())
+        seen, _ = fused_launch_seen(lambda: qb(x[0], L, 1))
+        assert seen, "a plain call after an escaped one takes the one-launch form again"
+    assert fused_status(dev) == 0
+
+
 @pytest.mark.parametrize("shape,lengths", [((256, 128, 768), "bench"), ((256, 128, 768), "full"), ((256, 128, 768), "zeros"),
                                            ((256, 128, 1024), "bench")])
 def test_fused_step_vs_oracle_at_the_headline_shape(shape, lengths, eq32, dev):

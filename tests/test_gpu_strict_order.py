@@ -245,6 +245,9 @@ def test_rounds_do_not_depend_on_the_workgroups_share_of_chunk_groups(dev, stric
     from outlier_suppression_amd import ops
     from outlier_suppression_amd.quantization.deferred import deferred_observation
     from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
+    if not ops.tunable_build():
+        pytest.skip("'mse_round_groups' is a compile-time constant in the release library; tests/test_gpu_tunable_build.py runs this "
+                    "test against the -DOSQ_TUNABLE build (libosq_hip_dbg.so) in a subprocess")
     g = torch.Generator().manual_seed(11)
     shapes = [(32, 128, 768), (5, 77, 211), (3, 4097, 31), (36, 128, 2048)]                # 3.1 M; 81 K (odd chunks, open rows); 381 K; 9.4 M (S = 32)
     batches = [[(torch.randn(*sh, generator=g) * (1 + 0.3 * b)).to(dev) for sh in shapes] for b in range(2)]
@@ -398,14 +401,7 @@ def test_backward_on_a_dense_permuted_input_follows_memory_order(dev, strict):
         assert np.float32(ds.item()) == rds and np.float32(dz.item()) == rdz, (B, T, h, d, ds.item(), rds, dz.item(), rdz)
 
 
-def test_lean_float64_term_equals_the_full_chain(dev, strict):
-    """csrc/msefast.hip, sq_err_f64_lean (round 5): from a site's second call on the reference-order evaluations take the
-    integer level from a guarded fp32 quotient (6 fp32 + 6 float64 operations per element instead of 15 float64 ones); an
-    element within 5e-4 of a rounding tie takes the exact float64 chain.  osq_set_tuning("mse_lean", 0) runs the full chain
-    everywhere: statistics and evaluation counts of every batch must be EQUAL -- on ordinary activations and on data built
-    to sit on and next to the ties of plausible candidate scales, far outside the clamp range, tiny, and of mixed sign."""
-    from outlier_suppression_amd import ops
-    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+def _lean_cases():
     g = torch.Generator().manual_seed(505)
     cases = []
     base = torch.randn(8, 64, 96, generator=g)
@@ -420,6 +416,49 @@ def test_lean_float64_term_equals_the_full_chain(dev, strict):
     adv = torch.cat([tie, pad])[torch.randperm(4 * 32 * 64, generator=g)].reshape(4, 32, 64)
     cases.append([adv, adv.flip(0), adv * 1.003])
     cases.append([torch.randn(2, 16, 8, generator=g), torch.randn(2, 16, 8, generator=g) * 5, torch.randn(2, 16, 8, generator=g)])
+    return cases
+
+
+def test_lean_float64_term_equals_the_oracles_full_chain(dev, strict):
+    """csrc/msefast.hip, sq_err_f64_lean: from a site's second call on the reference-order evaluations take the integer
+    level from a guarded fp32 quotient (6 fp32 + 5 float64 operations per element instead of 15 float64 ones); an element
+    within 1e-4 of a rounding tie takes the exact float64 chain.  The ORACLE knows only the full chain (observer.py:420-432
+    in float64 once min_val has turned float64): statistics and evaluation counts of every batch must be EQUAL -- on ordinary
+    activations and on data built to sit on and next to the ties of plausible candidate scales (both sides of the guard), far
+    outside the clamp range, tiny, and of mixed sign.  Runs against the release library (the lean term is what ships)."""
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+    from oracle import observer_oracle as OB
+    old = OB.MEAN_LIKE_TORCH
+    OB.MEAN_LIKE_TORCH = _oracle_order_mean(8)
+    try:
+        for ci, batches in enumerate(_lean_cases()):
+            for cls, bit, sym, avg in ((AvgMSEFastObserver, 6, False, True), (MSEFastObserver, 4, True, False), (AvgMSEFastObserver, 8, False, True)):
+                ob = cls(bit=bit, symmetric=sym).to(dev)
+                st = OB.ObserverState(bit=bit, symmetric=sym, ch_axis=-1)
+                L = torch.full((batches[0].shape[0],), batches[0].shape[1], dtype=torch.int64)
+                L[0] = max(1, batches[0].shape[1] // 2)
+                counter, evals = [0], 0
+                for r, x in enumerate(batches):
+                    ob(x.to(dev), L.to(dev), 1)
+                    evals += int(ob.last_nfev.sum().item())
+                    OB.observe_msefast(st, x.numpy(), L.numpy(), 1, average=avg, counter=counter)
+                    assert bits_equal(N(ob.min_val).astype(np.float64), np.asarray(st.min_val, dtype=np.float64)) and \
+                        bits_equal(N(ob.max_val).astype(np.float64), np.asarray(st.max_val, dtype=np.float64)), (ci, cls.__name__, bit, r, N(ob.min_val), st.min_val)
+                assert evals == counter[0], (ci, cls.__name__, bit, evals, counter[0])
+    finally:
+        OB.MEAN_LIKE_TORCH = old
+
+
+def test_lean_float64_term_equals_the_full_chain(dev, strict):
+    """The same property inside the library: osq_set_tuning("mse_lean", 0) runs the full float64 chain everywhere, and
+    statistics and evaluation counts of every batch must equal the lean form's.  'mse_lean' is a compile-time constant (1) in
+    the release library: this form of the test runs against the -DOSQ_TUNABLE build (tests/test_gpu_tunable_build.py)."""
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver, MSEFastObserver
+    if not ops.tunable_build():
+        pytest.skip("'mse_lean' is a compile-time constant in the release library (see test_lean_float64_term_equals_the_oracles_full_chain); "
+                    "tests/test_gpu_tunable_build.py runs this test against libosq_hip_dbg.so in a subprocess")
+    cases = _lean_cases()
     results = {}
     for lean in (1, 0):
         ops.set_tuning("mse_lean", lean)

@@ -6,7 +6,13 @@
 tag=$1; pat=$2; shift 2
 export TMPDIR=/tmp
 out=/tmp/osq_pmc_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $out -o r -- "$@" > $out/run.log 2>&1 || tail -5 $out/run.log
+# PMC_COUNTERS="A B C ..." picks another set (at most 8 SQ counters per pass)
+counters=${PMC_COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU}
+# keep the counters this part has (an unknown name fails the whole pass); the list is cached for the box's lifetime
+[ -s /tmp/osq_pmc_avail.txt ] || rocprofv3 -L > /tmp/osq_pmc_avail.txt 2>&1
+have=""; for c in $counters; do if grep -qw "$c" /tmp/osq_pmc_avail.txt; then have="$have $c"; else echo "   (counter $c not available on this part)"; fi; done
+counters=$have
+rocprofv3 --pmc $counters -d $out -o r -- "$@" > $out/run.log 2>&1 || tail -5 $out/run.log
 python - "$out" "$pat" <<'PY'
 import glob, sqlite3, sys
 db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]

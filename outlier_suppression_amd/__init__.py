@@ -63,9 +63,8 @@ def reset_tier(_lib=None):
         set_strict(True, width, backward=False, _lib=_lib)
     else:
         set_strict(strict != "0", width, _lib=_lib)
-    fast = os.environ.get("OSQ_FAST", "")
-    if fast != "":
-        set_fast(fast != "0")
+    # unset: the default (one-launch LayerNorm site ON) -- a set_fast(False) of an earlier caller or test does not leak
+    set_fast(os.environ.get("OSQ_FAST", "") != "0")
 
 
 _apply_environment = reset_tier

@@ -59,6 +59,7 @@ extern "C" int osq_timing_elapsed_us(void* start, void* stop, float* us) {
     float ms = 0.f;
     if (hipEventSynchronize(static_cast<hipEvent_t>(stop)) != hipSuccess ||
         hipEventElapsedTime(&ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) != hipSuccess) {
+        (void)hipGetLastError();      // the runtime's last-error word is sticky: the next launch check must not report THIS failure
         osq::set_error("timing_elapsed_us: events not recorded");
         return OSQ_ERR_HIP;
     }

@@ -189,6 +189,9 @@ template <> __device__ __forceinline__ void cascade_rotate<float>(float& cur, co
 // NCS >= 0: the caller knows log2(NC) at compile time (it branched on it): a thread's R loads are then ONE 64-bit address
 // and R immediate offsets (k * NC elements apart), not R address computations.
 constexpr int kCascadeHold = 16;
+// LDS values (of T) cascade_chunks_pipelined<T, NS, P, THREADS> needs at least: two tiles + one group's block sums
+template <int NS, int P, int THREADS>
+constexpr bool cascade_lds_fits(const int lds_values) { return lds_values >= 2 * NS * THREADS + NS * (THREADS >> P); }
 template <typename T, int NS, int P, int THREADS, typename Raw, typename Load, typename Eval, int NCS = -1>
 __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T* __restrict__ part, T* lds, Load load, Eval eval,
                                                          const unsigned int bid, const unsigned int nblk_grid, const int lds_values) {
@@ -207,6 +210,10 @@ __device__ __forceinline__ void cascade_chunks_pipelined(const CascadeGeom& g, T
     const int cols = G << nc_shift;                         // block sums a group leaves, per sum
     // block sums held back in LDS behind the two tiles: pub[hold][NS * cols]
     const int room = (lds_values - 2 * NS * THREADS) / (NS * cols);
+    // pub[] lives BEHIND the two tiles: an array that ends before one group's block sums fit (the old contract asked for the
+    // tiles only) would be written past its end.  cols <= THREADS / S, so cascade_lds_fits<...>() -- which every caller
+    // static_asserts on its compile-time capacity -- implies room >= 1; the trap is for a caller that did not.
+    if (room < 1) __builtin_trap();
     // NS > 1 is the LSQ+ backward, whose eval stores dx element by element: its loop is not store-free whatever happens to the
     // block sums, and a batch of one measured 2-8 % ahead there (same-box A/B)
     const int hold = NS > 1 ? 1 : (room > kCascadeHold ? kCascadeHold : (room < 1 ? 1 : room));

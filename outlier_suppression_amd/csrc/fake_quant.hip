@@ -569,6 +569,7 @@ __global__ __launch_bounds__(kBwdOrdThreads, 4) void lsq_bwd_tensor_ordered_kern
             t[2] = g_in;
             t[3] = -g_mul;
         };
+        static_assert(cascade_lds_fits<4, 4, kBwdOrdThreads>(kBwdOrdLdsBytes / 4), "kBwdOrdLdsBytes: two tiles + one group's block sums");
         if (geom.P == 4) cascade_chunks_pipelined<float, 4, 4, kBwdOrdThreads, Pair>(geom, part, lds, load, eval, blockIdx.x, gridDim.x, kBwdOrdLdsBytes / 4);
         else cascade_chunks_pipelined<float, 4, 5, kBwdOrdThreads, Pair>(geom, part, lds, load, eval, blockIdx.x, gridDim.x, kBwdOrdLdsBytes / 4);
         if (blockIdx.x == gridDim.x - 1) cascade_units<float, 4, kBwdOrdThreads>(geom, part, lds, term, 0u, 1u, geom.chunks);     // the open unit: the workgroup with the fewest chunks

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kFusedThreads) void observe_fq_fused_kernel(FusedAr
             z = old_z;
         } else {
             const float up = __uint_as_float(static_cast<unsigned int>(g0)), lo = -__uint_as_float(static_cast<unsigned int>(g1));
-            float cur_min = (lo > up) ? up : lo;           // aminmax(clip(value, lo, up)), observer.py:68,227
+            float cur_min = clipped_min(lo, up);           // aminmax(clip(value, lo, up)), observer.py:68,227
             float cur_max = up;
             if (((g0 | g1) >> 32) & 1ull) { cur_min = __builtin_nanf(""); cur_max = cur_min; }
             float mn = cur_min, mx = cur_max;

@@ -705,6 +705,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
                 auto eval = [=](float xf, int64_t, double (&t)[1]) {
                     t[0] = dbg_trivial ? static_cast<double>(xf) : sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
                 };
+                static_assert(cascade_lds_fits<1, 4, kOrdThreads>(kOrdLdsBytes / 8) && cascade_lds_fits<1, 4, kOrdThreads>(kOrdLdsBytes / 4), "kOrdLdsBytes: two tiles + one group's block sums");
                 if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
                 else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             } else {

@@ -853,7 +853,7 @@ __global__ __launch_bounds__(kFinalThreads) void token_finalize_kernel(const flo
         __syncthreads();
         const float lo_sel = from_ordered_bits(s_omin), up_sel = from_ordered_bits(s_omax);
         // aminmax(clip(value, lo, up)) (observer.py:68,227): (lo, up), or (up, up) if lo > up
-        cur_min = (lo_sel > up_sel) ? up_sel : lo_sel;
+        cur_min = clipped_min(lo_sel, up_sel);
         cur_max = up_sel;
         OSQ_STAMP(5);
     }
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_select_kernel(WideArgs a, F
             } else {
                 const float lo_sel = from_ordered_bits(~peek(&a.ws->thr_omin_inv));
                 const float up_sel = from_ordered_bits(peek(&a.ws->thr_omax));
-                cmin = (lo_sel > up_sel) ? up_sel : lo_sel;     // aminmax(clip(value, lo, up)), observer.py:68,227
+                cmin = clipped_min(lo_sel, up_sel);     // aminmax(clip(value, lo, up)), observer.py:68,227
                 cmax = up_sel;
             }
             finish_entry(fin, 0, cmin, cmax);

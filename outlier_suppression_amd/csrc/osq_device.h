@@ -127,6 +127,15 @@ __device__ __forceinline__ void qparams_from_range(float mn, float mx, int quant
     *zp_out = zp;
 }
 
+// Minimum of clip(value, lo, up) (observer.py:68,227: aminmax of the clipped tensor) from the two selected bounds: lo, or up when
+// lo > up.  Bounds that are zeros of DIFFERENT sign clip every element to a zero whose sign the reference leaves to the SIMD lane
+// (oracle/observer_oracle.py, "zero extrema"): by the IEEE minimum rule, -0 < +0, the minimum is -0.0 -- the OR of the two words.
+__device__ __forceinline__ float clipped_min(const float lo, const float up) {
+    if (lo > up) return up;
+    if (lo == up) return __uint_as_float(__float_as_uint(lo) | __float_as_uint(up));
+    return lo;
+}
+
 __device__ __forceinline__ void store_zp(void* zp_out, int zp_type, int64_t idx, float zp) {
     if (zp_type == OSQ_ZP_FLOAT32) static_cast<float*>(zp_out)[idx] = zp;
     else static_cast<int32_t*>(zp_out)[idx] = static_cast<int32_t>(zp);

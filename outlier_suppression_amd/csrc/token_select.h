@@ -585,7 +585,7 @@ __device__ __forceinline__ bool meet_sides(unsigned long long* word, const int s
     const bool poisoned = r.bad || ((other >> 32) & 1ull);
     const float up = side ? theirs : r.value;
     const float lo = -(side ? r.value : theirs);
-    *cur_min = (lo > up) ? up : lo;
+    *cur_min = clipped_min(lo, up);
     *cur_max = up;
     if (poisoned) { *cur_min = __builtin_nanf(""); *cur_max = *cur_min; }
     return true;

@@ -1,4 +1,4 @@
-"""Losses of the task-model wrappers and the placement check.
+"""Losses of the task-model wrappers (part of their forward contract: SURVEY 8f N2).
 
 The reference's task models return the loss in front of their outputs when ``labels`` (or ``start_positions`` /
 ``end_positions``) are given (model/quant_bert.py:656-680, 744-765, quant_bart.py:1104-1111, 1248-1274, 1376-1392); an
@@ -51,11 +51,3 @@ def lm_loss(logits, labels, vocab_size):
 
 def with_loss(loss, outputs):
     return outputs if loss is None else (loss,) + tuple(outputs)
-
-
-def require_academic(backend):
-    """'academic' and 'tensorrt' (the reference's extra residual-branch sites, quant_bert.py:204-216, quant_bart.py:305-307,
-    401-404) are the placements the reference's model files know; anything else is refused rather than silently treated
-    as 'academic'."""
-    if backend not in ("academic", "tensorrt"):
-        raise NotImplementedError(f"backend={backend!r}: the quantizer placements are 'academic' and 'tensorrt'")

@@ -21,7 +21,7 @@ as in the reference driver (ptq_summ_quant.py:137-153).
 import torch
 from torch import nn
 
-from ..quant_model_checks import classification_loss, lm_loss, span_loss, with_loss
+from .losses import classification_loss, lm_loss, span_loss, with_loss
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
                               qkv_heads_fake_quant, residual_layernorm, split_heads_fake_quant)
@@ -156,21 +156,14 @@ class QuantizedBartEncoderLayer(QuantizedModule):
         self.before_final_layer_norm_residual = GammaResidual()
         self.final_layer_norm = QuantizedLayerNorm(org_module.final_layer_norm, w_qconfig, a_qconfig, qoutput=qoutput,
                                                    backend=backend)
-        if self.backend == "tensorrt":       # quant_bart.py:305-307: the residual branches are quantizer sites too
-            self.self_attn_post_act_fake_quantize = Quantizer(None, a_qconfig)
-            self.fc2_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def _drop(self, x, p):
         return nn.functional.dropout(x, p=p, training=self.training)
-
-    def _branch(self, name, h, observation_mask):
-        return getattr(self, name)(h, observation_mask, 1) if self.backend == "tensorrt" else h
 
     def forward(self, hidden_states, attention_mask, observation_mask=None):
         residual = hidden_states
         h = self._drop(self.self_attn(hidden_states, attention_mask=attention_mask, observation_mask=observation_mask),
                        self.dropout)
-        h = self._branch("self_attn_post_act_fake_quantize", h, observation_mask)
         h = residual_layernorm(self.before_self_attn_layer_norm_residual, self.self_attn_layer_norm, residual, h, observation_mask)
         residual = h
         if self.training and self.activation_dropout > 0:
@@ -178,7 +171,7 @@ class QuantizedBartEncoderLayer(QuantizedModule):
             h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
         else:
             h = activation_fake_quant(self.activation_fn, self.fc1_act_fn_post_act_fake_quantize, self.fc1(h), observation_mask)
-        h = self._branch("fc2_post_act_fake_quantize", self._drop(self.fc2(h), self.dropout), observation_mask)
+        h = self._drop(self.fc2(h), self.dropout)
         return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 
 
@@ -205,30 +198,21 @@ class QuantizedBartDecoderLayer(QuantizedModule):
         self.before_final_layer_norm_residual = GammaResidual()
         self.final_layer_norm = QuantizedLayerNorm(org_module.final_layer_norm, w_qconfig, a_qconfig, qoutput=qoutput,
                                                    backend=backend)
-        if self.backend == "tensorrt":       # quant_bart.py:401-404
-            self.self_attn_post_act_fake_quantize = Quantizer(None, a_qconfig)
-            self.encoder_attn_post_act_fake_quantize = Quantizer(None, a_qconfig)
-            self.fc2_post_act_fake_quantize = Quantizer(None, a_qconfig)
 
     def _drop(self, x, p):
         return nn.functional.dropout(x, p=p, training=self.training)
-
-    def _branch(self, name, h, observation_mask):
-        return getattr(self, name)(h, observation_mask, 1) if self.backend == "tensorrt" else h
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 observation_mask=None):
         residual = hidden_states
         h = self._drop(self.self_attn(hidden_states, attention_mask=attention_mask, observation_mask=observation_mask),
                        self.dropout)
-        h = self._branch("self_attn_post_act_fake_quantize", h, observation_mask)
         h = residual_layernorm(self.before_self_attn_layer_norm_residual, self.self_attn_layer_norm, residual, h, observation_mask)
         if encoder_hidden_states is not None:
             residual = h
             h = self._drop(self.encoder_attn(h, key_value_states=encoder_hidden_states,
                                              attention_mask=encoder_attention_mask, observation_mask=observation_mask),
                            self.dropout)
-            h = self._branch("encoder_attn_post_act_fake_quantize", h, observation_mask)
             h = residual_layernorm(self.before_encoder_attn_layer_norm_residual, self.encoder_attn_layer_norm, residual, h, observation_mask)
         residual = h
         if self.training and self.activation_dropout > 0:
@@ -236,7 +220,7 @@ class QuantizedBartDecoderLayer(QuantizedModule):
             h = self.fc1_act_fn_post_act_fake_quantize(h, observation_mask, 1)
         else:
             h = activation_fake_quant(self.activation_fn, self.fc1_act_fn_post_act_fake_quantize, self.fc1(h), observation_mask)
-        h = self._branch("fc2_post_act_fake_quantize", self._drop(self.fc2(h), self.dropout), observation_mask)
+        h = self._drop(self.fc2(h), self.dropout)
         return residual_layernorm(self.before_final_layer_norm_residual, self.final_layer_norm, residual, h, observation_mask)
 
 

@@ -18,7 +18,7 @@ import math
 import torch
 from torch import nn
 
-from ..quant_model_checks import classification_loss, span_loss, with_loss
+from .losses import classification_loss, span_loss, with_loss
 
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import (GammaResidual, QuantizedLayerNorm, activation_fake_quant, merge_heads_fake_quant,
@@ -108,15 +108,11 @@ class _DenseResidualNorm(QuantizedModule):
         self.qoutput = qoutput
         self.dense = Quantizer(org_module.dense, w_qconfig)
         self.dropout = org_module.dropout
-        if self.backend == "tensorrt":       # quant_bert.py:204-205, 291-292: the residual branch is a quantizer site too
-            self.output_post_act_fake_quantize = Quantizer(None, a_qconfig)
         self.before_LayerNorm_residual = GammaResidual()
         self.LayerNorm = QuantizedLayerNorm(org_module.LayerNorm, w_qconfig, a_qconfig, qoutput=qoutput, backend=backend)
 
     def forward(self, hidden_states, input_tensor, observation_mask=None):
         hidden_states = self.dropout(self.dense(hidden_states))
-        if self.backend == "tensorrt":
-            hidden_states = self.output_post_act_fake_quantize(hidden_states, observation_mask, 1)
         return residual_layernorm(self.before_LayerNorm_residual, self.LayerNorm, input_tensor, hidden_states, observation_mask)
 
 

@@ -10,7 +10,7 @@ Sub-module names follow the reference (``roberta.*``, ``classifier.dense`` ...),
 """
 import torch
 
-from ..quant_model_checks import classification_loss, span_loss, with_loss
+from .losses import classification_loss, span_loss, with_loss
 from ..quantization import QuantizedModule, Quantizer
 from ..util_layernorm import QuantizedLayerNorm
 from . import quant_bert as B

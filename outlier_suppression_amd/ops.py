@@ -789,13 +789,15 @@ def msefast_ordered_groups(searches, two_d):
     return out
 
 
-def _ordered_group_prepare(group):
-    """Lay out the masked sites of a group (remove_padding order), build the group's table; on the CURRENT stream."""
+def _ordered_group_prepare(group, launch_stream=None):
+    """Lay out the masked sites of a group (remove_padding order) and build the group's table.  Every ALLOCATION (gathered
+    copies, scratch, table) and its zero fill happens on the CURRENT stream -- the caller's: the blocks come from, and go back
+    to, the pool the rest of the calibration allocates from, not a side stream's private pool --; the gathers and the table's
+    preparation are launched on `launch_stream` (default: the current one), which first waits for those fills."""
     lib = _hip.load()
     n_sites = len(group)
     assert 0 < n_sites <= ORDERED_GROUP_SITES
     dev = group[0].x.device
-    st = _hip.stream_ptr(dev)
     flats, ns, n_devs = [], [], []
     for r in group:
         if r.view is None:
@@ -804,13 +806,9 @@ def _ordered_group_prepare(group):
             n_devs.append(None)
         else:
             n = r.view.batch * r.view.tokens * r.view.feat_outer * r.view.feat_inner
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-            n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-            _hip.check(lib.osq_gather_valid_tokens(_hip.ptr(r.x), ctypes.byref(r.view), _hip.ptr(r.lengths), _hip.ptr(flat),
-                                                   _hip.ptr(n_dev), st), "gather_valid_tokens")
-            flats.append(flat)
+            flats.append(torch.empty(n, dtype=torch.float32, device=dev))
             ns.append(n)
-            n_devs.append(n_dev)
+            n_devs.append(torch.zeros(1, dtype=torch.int64, device=dev))
     sizes = [int(lib.osq_ordered_sum_scratch_bytes(int(n), 1)) for n in ns]
     offs, total = [], 0
     for b in sizes:
@@ -819,18 +817,36 @@ def _ordered_group_prepare(group):
     scratch = torch.empty(total, dtype=torch.uint8, device=dev)
     table_bytes = int(lib.osq_msefast_ordered_multi_bytes(n_sites))
     table = torch.zeros(table_bytes, dtype=torch.uint8, device=dev)
-    vp = ctypes.c_void_p
-    states = (vp * n_sites)(*[_hip.ptr(r.state) for r in group])
-    xs = (vp * n_sites)(*[_hip.ptr(f) for f in flats])
-    n_arr = (ctypes.c_int64 * n_sites)(*ns)
-    nd_arr = (vp * n_sites)(*[_hip.ptr(t) for t in n_devs])
-    sc_arr = (vp * n_sites)(*[scratch.data_ptr() + o for o in offs])
-    sb_arr = (ctypes.c_size_t * n_sites)(*sizes)
-    blocks = ctypes.c_int(0)
-    _hip.check(lib.osq_msefast_ordered_multi_prepare(_hip.ptr(table), table_bytes, states, xs, n_arr, nd_arr, sc_arr, sb_arr, n_sites,
-                                                     ctypes.byref(blocks), st), "msefast_ordered_multi_prepare")
     done = torch.zeros(1, dtype=torch.int32, device=dev)
-    return {"table": table, "n_sites": n_sites, "blocks": blocks.value, "done": done, "keep": (flats, n_devs, scratch, group), "launched": 0}
+    ctx = {"table": table, "n_sites": n_sites, "blocks": 0, "done": done, "keep": (flats, n_devs, scratch, group), "launched": 0}
+
+    def launches():
+        st = _hip.stream_ptr(dev)
+        for r, flat, n_dev in zip(group, flats, n_devs):
+            if r.view is not None:
+                _hip.check(lib.osq_gather_valid_tokens(_hip.ptr(r.x), ctypes.byref(r.view), _hip.ptr(r.lengths), _hip.ptr(flat),
+                                                       _hip.ptr(n_dev), st), "gather_valid_tokens")
+        vp = ctypes.c_void_p
+        states = (vp * n_sites)(*[_hip.ptr(r.state) for r in group])
+        xs = (vp * n_sites)(*[_hip.ptr(f) for f in flats])
+        n_arr = (ctypes.c_int64 * n_sites)(*ns)
+        nd_arr = (vp * n_sites)(*[_hip.ptr(t) for t in n_devs])
+        sc_arr = (vp * n_sites)(*[scratch.data_ptr() + o for o in offs])
+        sb_arr = (ctypes.c_size_t * n_sites)(*sizes)
+        blocks = ctypes.c_int(0)
+        _hip.check(lib.osq_msefast_ordered_multi_prepare(_hip.ptr(table), table_bytes, states, xs, n_arr, nd_arr, sc_arr, sb_arr, n_sites,
+                                                         ctypes.byref(blocks), st), "msefast_ordered_multi_prepare")
+        ctx["blocks"] = blocks.value
+
+    if launch_stream is None:
+        launches()
+    else:
+        filled = torch.cuda.Event()
+        filled.record(torch.cuda.current_stream(dev))
+        launch_stream.wait_event(filled)
+        with torch.cuda.stream(launch_stream):
+            launches()
+    return ctx
 
 
 def _ordered_group_rounds(ctx, chunk):
@@ -859,9 +875,14 @@ _side_streams = {}
 
 
 def msefast_tensor_run_ordered_groups(groups, chunk=64):
-    """Several groups of strict searches CONCURRENTLY, one stream each (see msefast_ordered_groups for why): the side streams
-    start behind everything the caller's stream has been given, the caller's stream continues behind all of them.  The
-    records of `groups` must stay referenced by the caller until then (they are: the flush commits them afterwards)."""
+    """Several groups of strict searches CONCURRENTLY (see msefast_ordered_groups for why), at most ORDERED_STREAMS + 1 at a
+    time: a group is prepared -- its gathered copies of masked sites, scratch and table allocated -- only when a stream is
+    free, and dropped as soon as its searches have converged, so ORDERED_GROUP_BYTES bounds the memory of
+    ORDERED_STREAMS + 1 groups, not of a whole flush (a flush that the byte cap splits into many groups used to hold all of
+    them at once).  The side streams start behind everything the caller's stream has been given; the caller's stream
+    continues behind all of them -- ALSO when a launch, a prepare or a read-back raises: the records' tensors must not be
+    freed under rounds that are still queued.  The records of `groups` must stay referenced by the caller until then (they
+    are: the flush commits them afterwards)."""
     groups = [g for g in groups if g]
     if not groups:
         return 0
@@ -871,30 +892,41 @@ def msefast_tensor_run_ordered_groups(groups, chunk=64):
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
     start.record(main)
-    runs = []
-    for i, g in enumerate(groups):
+    lanes = min(len(groups), ORDERED_STREAMS + 1)
+    streams = []
+    for i in range(lanes):
         key = (_hip._device_index(dev), i)
         s = _side_streams.get(key)
         if s is None:
             s = _side_streams[key] = torch.cuda.Stream(device=dev)
         s.wait_event(start)
-        with torch.cuda.stream(s):
-            runs.append((s, _ordered_group_prepare(g)))
-    pending = list(runs)
-    while pending:
-        for s, ctx in pending:                   # every unfinished group gets its next rounds before anybody waits
-            with torch.cuda.stream(s):
-                _ordered_group_rounds(ctx, chunk)
-        still = []
-        for s, ctx in pending:
-            with torch.cuda.stream(s):
-                finished = int(ctx["done"].item())
-            if not finished and ctx["launched"] <= 500 * 500:
-                still.append((s, ctx))
-        pending = still
-    for s, _ in runs:
-        main.wait_stream(s)
-    return sum(ctx["launched"] for _, ctx in runs)
+        streams.append(s)
+    queue = list(groups)
+    free = list(streams)
+    pending, launched = [], 0
+    try:
+        while queue or pending:
+            while queue and free:                    # a free stream takes the next group: allocations on the caller's stream
+                s = free.pop(0)
+                pending.append((s, _ordered_group_prepare(queue.pop(0), launch_stream=s)))
+            for s, ctx in pending:                   # every unfinished group gets its next rounds before anybody waits
+                with torch.cuda.stream(s):
+                    _ordered_group_rounds(ctx, chunk)
+            still = []
+            for s, ctx in pending:
+                with torch.cuda.stream(s):
+                    finished = int(ctx["done"].item())      # synchronises with s: the group's rounds so far are complete
+                if not finished and ctx["launched"] <= 500 * 500:
+                    still.append((s, ctx))
+                else:
+                    launched += ctx["launched"]
+                    ctx.clear()                      # the group's copies, scratch and table go back to the pool now
+                    free.append(s)
+            pending = still
+    finally:
+        for s in streams:                            # normal end or exception: nothing the caller frees is still in use
+            main.wait_stream(s)
+    return launched
 
 
 def msefast_tensor_run_group(group):

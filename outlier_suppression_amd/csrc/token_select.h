@@ -62,6 +62,7 @@ struct alignas(16) SelShared {            // LDS of one selecting workgroup (the
     unsigned int list[kListCap];
     // per-wave partials of pass 0: plain stores, nothing to initialise, no atomics; every thread folds the sixteen entries
     unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves], w_below[kSelWaves];
+    unsigned int w_near[kSelWaves];                   // keys between the hinted window's start and the pre-listed (narrow) window's start
     alignas(16) unsigned int pick[4];                 // what the owner of the wanted rank leaves: bin, keys below it, keys in it
     alignas(16) unsigned int s_found[2];              // keys at ranks floor / ceil ...
     unsigned int s_next, s_pos;                       // ... the smallest key above the bin, sign facts: read as ONE 16-byte word
@@ -106,6 +107,24 @@ __device__ __forceinline__ SelWindow hint_window(const float hint, const int pru
     return w;
 }
 
+// PRE-LIST (round 6).  The wide window above still costs a scan of its 2048 bins, a pass that compacts the chosen bin into
+// the list and the barriers between them AFTER the last value is in -- 3-6 us on the critical path of the one-launch step
+// (last arrival -> scale).  The running statistic predicts the threshold far better than to an octave: batch after batch it
+// moves by a fraction of a percent.  So the gathering pass also keeps every value whose key lies within hint * (1 -+ 1/32) in
+// the list directly (a few hundred of 32768: the LDS atomics are rare) and counts the keys below that narrow window.  If
+// both wanted ranks turn out to lie inside it and the list did not overflow, the selection goes from the fold of the counts
+// straight to the ranking -- no histogram level, no compaction.  Otherwise nothing is lost but the appends: the wide
+// window's histogram (or the full range) decides as before.  Exactness never depends on the hint.
+__device__ __forceinline__ SelWindow near_window(const float hint, const SelWindow& wide) {
+    SelWindow w{false, 0u, 0u, 0u};
+    if (wide.on) {
+        w.on = true;
+        w.lo = __float_as_uint(hint * (1.0f - 1.0f / 32.0f));
+        w.wd = __float_as_uint(hint * (1.0f + 1.0f / 32.0f)) - w.lo + 1u;
+    }
+    return w;
+}
+
 struct SelPass0 {         // what the gathering pass leaves (all uniform)
     unsigned int N;           // valid values
     bool have_range;          // false: kmin / kmax / plain_o are computed from the registers if a path needs them
@@ -114,6 +133,9 @@ struct SelPass0 {         // what the gathering pass leaves (all uniform)
     bool any_bad;             // a NaN among them
     SelWindow win;            // win.on: S.hist holds the window's histogram, n_below keys lie below it
     unsigned int n_below;
+    SelWindow near;           // near.on: S.list holds the n_listed values whose keys lie in the narrow window (if n_listed <= kListCap:
+    unsigned int n_near_below;//   all of them), n_near_below keys lie below it
+    unsigned int n_listed;
 };
 
 // Per-wave partials of the gathering pass -> LDS -> (one barrier) -> every thread folds the sixteen entries.
@@ -137,7 +159,7 @@ __device__ __forceinline__ SelPass0 fold_pass0(SelShared& S, unsigned int n, con
         S.w_plain[wv] = ordered_bits(plain);
     }
     lds_barrier();                           // also: the LDS set-up of the caller is complete
-    SelPass0 p{0u, true, 0xffffffffu, 0u, 0u, false, win, 0u};
+    SelPass0 p{0u, true, 0xffffffffu, 0u, 0u, false, win, 0u, SelWindow{false, 0u, 0u, 0u}, 0u, 0u};
     unsigned int any_bad_u = 0u;
     if (win.on) {
 #pragma unroll
@@ -238,9 +260,14 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         const unsigned int k_lo = static_cast<unsigned int>(rlo);
         const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
         const float w = rank - rlo;
+        // the narrow window's list serves directly if the lower wanted rank lies inside it (the upper one may lie just behind:
+        // the smallest key above the list is then found as for any listed bin)
+        const bool prelisted = p0.near.on && p0.n_listed <= static_cast<unsigned int>(kListCap) && p0.n_near_below <= k_lo &&
+                               k_lo - p0.n_near_below < p0.n_listed;
+        if (p0.near.on && !prelisted && tid == 0) S.s_fill = 0u;     // the appends of the gathering pass are void (barriers follow before the list is filled again)
         // a window histogrammed during the gathering pass serves as level 0 if the wanted rank lies inside it
-        bool prehist = p0.win.on && p0.n_below <= k_lo;
-        if (!prehist && !have_range) {
+        bool prehist = !prelisted && p0.win.on && p0.n_below <= k_lo;
+        if (!prehist && !prelisted && !have_range) {
             range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
             have_range = true;
         }
@@ -250,7 +277,10 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         // histogram when that was not built during the gathering pass.
         unsigned int sel_lo, sel_width, sel_rank, sel_shift, sel_le, sel_count = N;
         bool sel_done = false;
-        if (prehist) {
+        if (prelisted) {
+            sel_lo = p0.near.lo; sel_width = p0.near.wd; sel_rank = k_lo - p0.n_near_below; sel_shift = 0u; sel_le = p0.n_near_below;
+            sel_count = p0.n_listed;
+        } else if (prehist) {
             sel_lo = p0.win.lo; sel_width = p0.win.wd; sel_rank = k_lo - p0.n_below; sel_shift = p0.win.sh; sel_le = p0.n_below;
         } else {
             sel_lo = kmin; sel_width = kmax - kmin + 1u; sel_rank = k_lo; sel_shift = level_shift(sel_width); sel_le = 0u;
@@ -261,9 +291,9 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         }
         OSQ_SSTAMP(7);
         // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
-        bool listed = false;
+        bool listed = prelisted;
         for (int level = 0; level < 3; ++level) {
-            if (sel_done) break;
+            if (sel_done || prelisted) break;
             if (level > 0) {
                 if (sel_count <= kListCap) { listed = true; break; }
                 for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;      // everybody read its bins before the last barrier
@@ -351,11 +381,13 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
             // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
             const unsigned int lo = sel_lo, wd = sel_width;
             const bool need_next = (k_hi != k_lo) && (sel_rank + 1u >= sel_count);
+            if (!prelisted) {                      // pre-listed: the gathering pass has filled the list
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                if (sel_used<PERIOD, MAINS>(i, n_tail)) {
-                    const unsigned int key = abs_key(v[i]);
-                    if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
+                for (int i = 0; i < R; ++i) {
+                    if (sel_used<PERIOD, MAINS>(i, n_tail)) {
+                        const unsigned int key = abs_key(v[i]);
+                        if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
+                    }
                 }
             }
             if (need_next) {

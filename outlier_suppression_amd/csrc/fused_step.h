@@ -127,8 +127,6 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
     const unsigned int qv = V / nwg, rv = V - qv * nwg;              // ... and holds qv + (g < rv) valid values
     const unsigned int flip = side ? 0x80000000u : 0u;               // side 1 works on -token_min
     const SelWindow win = hint_window(__uint_as_float(uniform(__float_as_uint(hint))), prune);
-    const SelWindow near = near_window(__uint_as_float(uniform(__float_as_uint(hint))), win);
-    const unsigned int near_off = near.lo - win.lo;                  // the narrow window inside the wide one (hint / 2 < hint * 31 / 32)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, static_cast<int>(total * 4u), 0x00020000);
     OSQ_SSTAMP(0);
 
@@ -171,7 +169,7 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
         const unsigned int g = wv + static_cast<unsigned int>(NC * i);
         if (g < nwg && qv + (g < rv ? 1u : 0u) > 0u) want |= 1u << i;
     }
-    unsigned int gdone = 0u, below = 0u, nearb = 0u;                  // groups that are in; keys below the wide window; keys from its start to the narrow one's
+    unsigned int gdone = 0u, below = 0u;                              // groups that are in
 #pragma unroll
     for (int j = 0; j < NG; ++j)
         if (((want >> (GC * j)) & kGroupMask) == 0u) gdone |= 1u << j;      // nothing to wait for
@@ -190,11 +188,6 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
             const unsigned int key = abs_key(x), d = key - win.lo;                                     \
             below += key < win.lo ? 1u : 0u;                                                           \
             if (d < win.wd) atomicAdd(&S.hist[d >> win.sh], 1u);                                       \
-            nearb += d < near_off ? 1u : 0u;                                                           \
-            if (d - near_off < near.wd) {          /* PRE-LIST: the few values round the predicted threshold */ \
-                const unsigned int at_ = atomicAdd(&S.s_fill, 1u);                                     \
-                if (at_ < static_cast<unsigned int>(kListCap)) S.list[at_] = __float_as_uint(x);       \
-            }                                                                                          \
         }                                                                                              \
     } while (0)
     // Software-pipelined: the poll of round n + 1 is issued right behind the data loads of round n.
@@ -278,25 +271,20 @@ __device__ __attribute__((noinline)) void fused_select(const float* src_, const 
     {
         const bool wbad = wave_any(bad);
         below = wave_inclusive_scan_u32(below);
-        nearb = wave_inclusive_scan_u32(nearb);
-        if (lane == OSQ_WAVE - 1) { S.w_below[wv] = below; S.w_near[wv] = nearb; }
+        if (lane == OSQ_WAVE - 1) S.w_below[wv] = below;
         if (lane == 0) S.w_bad[wv] = wbad ? 1u : 0u;
     }
     lds_barrier();
-    SelPass0 p0{V, false, 0u, 0u, 0u, false, win, 0u, near, 0u, 0u};
+    SelPass0 p0{V, false, 0u, 0u, 0u, false, win, 0u};
     {
-        unsigned int nb = 0u, nn = 0u, anyb = 0u;
+        unsigned int nb = 0u, anyb = 0u;
 #pragma unroll
         for (int k = 0; k < kSelWaves; k += 4) {
             const uint4 a4 = *reinterpret_cast<const uint4*>(&S.w_below[k]), b4 = *reinterpret_cast<const uint4*>(&S.w_bad[k]);
-            const uint4 c4 = *reinterpret_cast<const uint4*>(&S.w_near[k]);
             nb += a4.x + a4.y + a4.z + a4.w;
-            nn += c4.x + c4.y + c4.z + c4.w;
             anyb |= b4.x | b4.y | b4.z | b4.w;
         }
         p0.n_below = uniform(nb);
-        p0.n_near_below = p0.n_below + uniform(nn);
-        p0.n_listed = uniform(S.s_fill);           // every append is behind the barrier above
         p0.any_bad = uniform(anyb) != 0u;
     }
     OSQ_SSTAMP(2);

@@ -62,7 +62,6 @@ struct alignas(16) SelShared {            // LDS of one selecting workgroup (the
     unsigned int list[kListCap];
     // per-wave partials of pass 0: plain stores, nothing to initialise, no atomics; every thread folds the sixteen entries
     unsigned int w_n[kSelWaves], w_bad[kSelWaves], w_kmin[kSelWaves], w_kmax[kSelWaves], w_plain[kSelWaves], w_below[kSelWaves];
-    unsigned int w_near[kSelWaves];                   // keys between the hinted window's start and the pre-listed (narrow) window's start
     alignas(16) unsigned int pick[4];                 // what the owner of the wanted rank leaves: bin, keys below it, keys in it
     alignas(16) unsigned int s_found[2];              // keys at ranks floor / ceil ...
     unsigned int s_next, s_pos;                       // ... the smallest key above the bin, sign facts: read as ONE 16-byte word
@@ -107,24 +106,6 @@ __device__ __forceinline__ SelWindow hint_window(const float hint, const int pru
     return w;
 }
 
-// PRE-LIST (round 6).  The wide window above still costs a scan of its 2048 bins, a pass that compacts the chosen bin into
-// the list and the barriers between them AFTER the last value is in -- 3-6 us on the critical path of the one-launch step
-// (last arrival -> scale).  The running statistic predicts the threshold far better than to an octave: batch after batch it
-// moves by a fraction of a percent.  So the gathering pass also keeps every value whose key lies within hint * (1 -+ 1/32) in
-// the list directly (a few hundred of 32768: the LDS atomics are rare) and counts the keys below that narrow window.  If
-// both wanted ranks turn out to lie inside it and the list did not overflow, the selection goes from the fold of the counts
-// straight to the ranking -- no histogram level, no compaction.  Otherwise nothing is lost but the appends: the wide
-// window's histogram (or the full range) decides as before.  Exactness never depends on the hint.
-__device__ __forceinline__ SelWindow near_window(const float hint, const SelWindow& wide) {
-    SelWindow w{false, 0u, 0u, 0u};
-    if (wide.on) {
-        w.on = true;
-        w.lo = __float_as_uint(hint * (1.0f - 1.0f / 32.0f));
-        w.wd = __float_as_uint(hint * (1.0f + 1.0f / 32.0f)) - w.lo + 1u;
-    }
-    return w;
-}
-
 struct SelPass0 {         // what the gathering pass leaves (all uniform)
     unsigned int N;           // valid values
     bool have_range;          // false: kmin / kmax / plain_o are computed from the registers if a path needs them
@@ -133,9 +114,6 @@ struct SelPass0 {         // what the gathering pass leaves (all uniform)
     bool any_bad;             // a NaN among them
     SelWindow win;            // win.on: S.hist holds the window's histogram, n_below keys lie below it
     unsigned int n_below;
-    SelWindow near;           // near.on: S.list holds the n_listed values whose keys lie in the narrow window (if n_listed <= kListCap:
-    unsigned int n_near_below;//   all of them), n_near_below keys lie below it
-    unsigned int n_listed;
 };
 
 // Per-wave partials of the gathering pass -> LDS -> (one barrier) -> every thread folds the sixteen entries.
@@ -159,7 +137,7 @@ __device__ __forceinline__ SelPass0 fold_pass0(SelShared& S, unsigned int n, con
         S.w_plain[wv] = ordered_bits(plain);
     }
     lds_barrier();                           // also: the LDS set-up of the caller is complete
-    SelPass0 p{0u, true, 0xffffffffu, 0u, 0u, false, win, 0u, SelWindow{false, 0u, 0u, 0u}, 0u, 0u};
+    SelPass0 p{0u, true, 0xffffffffu, 0u, 0u, false, win, 0u};
     unsigned int any_bad_u = 0u;
     if (win.on) {
 #pragma unroll
@@ -260,14 +238,9 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         const unsigned int k_lo = static_cast<unsigned int>(rlo);
         const unsigned int k_hi = static_cast<unsigned int>(ceilf(rank));
         const float w = rank - rlo;
-        // the narrow window's list serves directly if the lower wanted rank lies inside it (the upper one may lie just behind:
-        // the smallest key above the list is then found as for any listed bin)
-        const bool prelisted = p0.near.on && p0.n_listed <= static_cast<unsigned int>(kListCap) && p0.n_near_below <= k_lo &&
-                               k_lo - p0.n_near_below < p0.n_listed;
-        if (p0.near.on && !prelisted && tid == 0) S.s_fill = 0u;     // the appends of the gathering pass are void (barriers follow before the list is filled again)
         // a window histogrammed during the gathering pass serves as level 0 if the wanted rank lies inside it
-        bool prehist = !prelisted && p0.win.on && p0.n_below <= k_lo;
-        if (!prehist && !prelisted && !have_range) {
+        bool prehist = p0.win.on && p0.n_below <= k_lo;
+        if (!prehist && !have_range) {
             range_from_registers<R, PERIOD, MAINS>(v, n_tail, S, &kmin, &kmax, &plain_o);
             have_range = true;
         }
@@ -277,10 +250,7 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         // histogram when that was not built during the gathering pass.
         unsigned int sel_lo, sel_width, sel_rank, sel_shift, sel_le, sel_count = N;
         bool sel_done = false;
-        if (prelisted) {
-            sel_lo = p0.near.lo; sel_width = p0.near.wd; sel_rank = k_lo - p0.n_near_below; sel_shift = 0u; sel_le = p0.n_near_below;
-            sel_count = p0.n_listed;
-        } else if (prehist) {
+        if (prehist) {
             sel_lo = p0.win.lo; sel_width = p0.win.wd; sel_rank = k_lo - p0.n_below; sel_shift = p0.win.sh; sel_le = p0.n_below;
         } else {
             sel_lo = kmin; sel_width = kmax - kmin + 1u; sel_rank = k_lo; sel_shift = level_shift(sel_width); sel_le = 0u;
@@ -291,9 +261,9 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
         }
         OSQ_SSTAMP(7);
         // ---- histogram levels: level 0 always; 1-2 only while the chosen bin is too crowded for the S.list
-        bool listed = prelisted;
+        bool listed = false;
         for (int level = 0; level < 3; ++level) {
-            if (sel_done || prelisted) break;
+            if (sel_done) break;
             if (level > 0) {
                 if (sel_count <= kListCap) { listed = true; break; }
                 for (int k = tid; k < kSelBins; k += kSelThreads) S.hist[k] = 0u;      // everybody read its bins before the last barrier
@@ -313,20 +283,25 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                 }
                 lds_barrier();
             }
-            // block-wide scan over the 2048 bins (2 per thread); the thread whose bins straddle the rank reports
-            const uint2 hh = *reinterpret_cast<const uint2*>(&S.hist[2 * tid]);
-            const unsigned int h0 = hh.x, h1 = hh.y;
-            const unsigned int incl_w = wave_inclusive_scan_u32(h0 + h1);
-            if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
-            lds_barrier();
-            unsigned int base = 0u, inside = 0u;
-#pragma unroll
-            for (int k = 0; k < kSelWaves; k += 4) {
-                const uint4 t4 = *reinterpret_cast<const uint4*>(&S.s_wtot[k]);
-                const unsigned int t[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { base += (k + e < wv) ? t[e] : 0u; inside += t[e]; }
+            // Scan over the 2048 bins by FOUR waves, 8 bins per thread; the thread whose bins straddle the rank reports.  Every
+            // instruction of a 16-wave workgroup costs its SIMD ~16 clocks whether 64 threads have work or 1024: with all
+            // sixteen waves on 2 bins each the two halves of this scan took 1.4 + 0.8 us; the other twelve waves now go
+            // straight to the barriers and leave each SIMD to one wave (round 6; the counters of the stand-alone kernel,
+            // profiles/r06_token_select_pmc.txt: the SIMDs of the selecting CU issue 81 % of the time).
+            constexpr int kScanWaves = 4, kScanBins = kSelBins / (kScanWaves * OSQ_WAVE);      // 8
+            unsigned int hb[kScanBins], hsum = 0u, incl_w = 0u;
+            if (wv < kScanWaves) {
+                const uint4 ha = *reinterpret_cast<const uint4*>(&S.hist[kScanBins * tid]);
+                const uint4 hc = *reinterpret_cast<const uint4*>(&S.hist[kScanBins * tid + 4]);
+                hb[0] = ha.x; hb[1] = ha.y; hb[2] = ha.z; hb[3] = ha.w; hb[4] = hc.x; hb[5] = hc.y; hb[6] = hc.z; hb[7] = hc.w;
+                hsum = ((hb[0] + hb[1]) + (hb[2] + hb[3])) + ((hb[4] + hb[5]) + (hb[6] + hb[7]));
+                incl_w = wave_inclusive_scan_u32(hsum);
+                if (lane == OSQ_WAVE - 1) S.s_wtot[wv] = incl_w;
             }
+            lds_barrier();
+            const uint4 t4 = *reinterpret_cast<const uint4*>(&S.s_wtot[0]);
+            const unsigned int inside = uniform(t4.x + t4.y + t4.z + t4.w);
+            const unsigned int base = wv == 0 ? 0u : (wv == 1 ? t4.x : (wv == 2 ? t4.x + t4.y : t4.x + t4.y + t4.z));
             if (level == 0) OSQ_SSTAMP(8);
             if (level == 0 && prehist && sel_rank >= inside) {
                 // the rank lies above the window (uniform: every thread sees the same sum): the full-range level after all
@@ -341,15 +316,24 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
                 --level;
                 continue;
             }
-            const unsigned int incl = base + incl_w, excl = incl - (h0 + h1);
-            if (sel_rank >= excl && sel_rank < incl) {     // exactly one thread
-                const bool second = sel_rank >= excl + h0;
-                uint4 pk;
-                pk.x = 2u * static_cast<unsigned int>(tid) + (second ? 1u : 0u);      // the bin
-                pk.y = second ? excl + h0 : excl;                                      // keys of the range below it
-                pk.z = second ? h1 : h0;                                               // keys in it
-                pk.w = 0u;
-                *reinterpret_cast<uint4*>(&S.pick[0]) = pk;
+            if (wv < kScanWaves) {
+                const unsigned int incl = base + incl_w, excl = incl - hsum;
+                if (sel_rank >= excl && sel_rank < incl) {     // exactly one thread: which of its 8 bins
+                    unsigned int bel = excl, bin_k = 0u, cnt_k = hb[0];
+#pragma unroll
+                    for (int k = 1; k < kScanBins; ++k) {
+                        const bool beyond = sel_rank >= bel + cnt_k;      // the rank lies behind bin bin_k: move on to bin k
+                        bel = beyond ? bel + cnt_k : bel;
+                        bin_k = beyond ? static_cast<unsigned int>(k) : bin_k;
+                        cnt_k = beyond ? hb[k] : cnt_k;
+                    }
+                    uint4 pk;
+                    pk.x = static_cast<unsigned int>(kScanBins) * static_cast<unsigned int>(tid) + bin_k;      // the bin
+                    pk.y = bel;                                                                // keys of the range below it
+                    pk.z = cnt_k;                                                              // keys in it
+                    pk.w = 0u;
+                    *reinterpret_cast<uint4*>(&S.pick[0]) = pk;
+                }
             }
             lds_barrier();
             {
@@ -381,13 +365,11 @@ __device__ __forceinline__ SideResult select_from_registers(const float (&v)[R],
             // ---- compact the chosen bin's keys; the smallest key above the bin only if rank+1 leaves the bin
             const unsigned int lo = sel_lo, wd = sel_width;
             const bool need_next = (k_hi != k_lo) && (sel_rank + 1u >= sel_count);
-            if (!prelisted) {                      // pre-listed: the gathering pass has filled the list
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    if (sel_used<PERIOD, MAINS>(i, n_tail)) {
-                        const unsigned int key = abs_key(v[i]);
-                        if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
-                    }
+            for (int i = 0; i < R; ++i) {
+                if (sel_used<PERIOD, MAINS>(i, n_tail)) {
+                    const unsigned int key = abs_key(v[i]);
+                    if (key - lo < wd) S.list[atomicAdd(&S.s_fill, 1u)] = __float_as_uint(v[i]);    // sign kept: see the shortcut below
                 }
             }
             if (need_next) {

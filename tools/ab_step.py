@@ -18,8 +18,15 @@ def child(lib_name, full):
     label = lib_name
     lib_name, _, knobs = lib_name.partition(":")          # libosq_hip.so:fused_deal=2,fused_gate=1
     _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), lib_name)
-    from tools.fused_check import mk, dev, status
+    from benchlib.common import make_quantizer
+    dev = torch.device("cuda:0")
+    mk = lambda: make_quantizer(dev)
     lib = _hip.load()
+
+    def status():
+        st = ctypes.c_int(-1)
+        _hip.check(lib.osq_fused_step_status(_hip.ptr(_hip.workspace(dev)), ctypes.byref(st), _hip.stream_ptr(dev)), "status")
+        return st.value
     for kv in filter(None, knobs.split(",")):
         key, _, val = kv.partition("=")
         assert lib.osq_set_tuning(key.encode(), int(val)) == 0, kv

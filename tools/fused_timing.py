@@ -7,7 +7,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from outlier_suppression_amd import _hip, ops
 _hip.LIB_PATH = _hip.LIB_PATH.replace("libosq_hip.so", "libosq_hip_dbg.so")
-from tools.fused_check import mk, dev
+from benchlib.common import make_quantizer
+dev = torch.device("cuda:0")
+mk = lambda: make_quantizer(dev)
 lib = _hip.load()
 lib.osq_debug_buffer.argtypes = [ctypes.c_void_p]
 shape = (256, 128, 768)
@@ -39,6 +41,17 @@ us = lambda v: (v.double() - t0) / 100.0
 print("selectors (us since first start): ", [[round(float(x), 2) for x in us(d[b, :4])] for b in range(2)])
 for side in range(2):
     print(f"select side {side}: prehist/n_below/k_lo/bin count/window", sel[side, 11:16].tolist())
+# the same sequence of calls through the three-launch path: must leave the same statistics
+ops.set_tuning("fused_step", 0)
+q3 = mk()
+with torch.no_grad():
+    for i in range(10):
+        q3(xs[i % 4], lengths, 1)
+    q3(xs[2], lengths, 1)
+torch.cuda.synchronize()
+ops.set_tuning("fused_step", 1)
+print("one launch  min/max:", q.observer.min_val.item(), q.observer.max_val.item(), "| three launches:", q3.observer.min_val.item(), q3.observer.max_val.item(),
+      "| EQUAL" if (q.observer.min_val.item(), q.observer.max_val.item()) == (q3.observer.min_val.item(), q3.observer.max_val.item()) else "| DIFFERENT")
 for side in range(2):
     names = [(0, "start"), (1, "LDS ready"), (2, "gathered+folded"), (7, "level set up"), (8, "level-0 scan done"), (3, "levels done"), (9, "list compacted"), (4, "ranked"), (5, "threshold"), (6, "granule out")]
     print(f"side {side} selection (LDS stamps):", ", ".join(f"{n} {float(us(sel[side, k])):.2f}" for k, n in names))

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--lengths", default="bench", choices=["bench", "full"])
     ap.add_argument("--events", action="store_true")
+    ap.add_argument("--state", action="store_true", help="an averaging observer's call from its second batch on: the running statistic predicts the threshold (pre-listed selection)")
     a = ap.parse_args()
     from outlier_suppression_amd import _hip, ops
     dev = torch.device("cuda:0")
@@ -27,13 +28,18 @@ def main():
     lengths = lengths.to(dev) if a.lengths == "bench" else torch.full((SHAPE[0],), SHAPE[1], device=dev)
     tok = ops.token_minmax(xs[0], 1, lengths)
     cur = torch.empty(2, device=dev)
+    rule, cnt, mn, mx = ops.UPDATE_NONE, 0, None, None
+    if a.state:
+        rule, mn, mx = ops.UPDATE_AVERAGE, torch.tensor(float("inf"), device=dev), torch.tensor(float("-inf"), device=dev)
+        ops.token_range_finalize(tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, rule, 0, mn, mx, 0, 63, False, None, cur)   # first batch
+        cnt = 3
     us_all = []
     for i in range(a.n):
         if a.events:
             ea, eb = ctypes.c_void_p(), ctypes.c_void_p()
             _hip.check(lib.osq_timing_events_create(ctypes.byref(ea), ctypes.byref(eb)), "events")
             lib.osq_time_next_launch(_hip.TIME_TOKEN_SELECT, ea, eb)
-        ops.token_range_finalize(tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, ops.UPDATE_NONE, 0, None, None, 0, 63, False, None, cur)
+        ops.token_range_finalize(tok[0], tok[1], tok[2], tok[3], tok[4], True, PERCENTILE, rule, cnt, mn, mx, 0, 63, False, None, cur)
         if a.events:
             us = ctypes.c_float()
             _hip.check(lib.osq_timing_elapsed_us(ea, eb, ctypes.byref(us)), "elapsed")
@@ -42,7 +48,7 @@ def main():
     torch.cuda.synchronize()
     if us_all:
         us_all.sort()
-        print(f"token_select_kernel, {a.lengths} lengths, {SHAPE[0] * SHAPE[1]} slots: median {us_all[len(us_all) // 2]:.2f} us, min {us_all[0]:.2f}, max {us_all[-1]:.2f} over {len(us_all)}")
+        print(f"token_select_kernel, {a.lengths} lengths{', running state (hint)' if a.state else ''}, {SHAPE[0] * SHAPE[1]} slots: median {us_all[len(us_all) // 2]:.2f} us, min {us_all[0]:.2f}, max {us_all[-1]:.2f} over {len(us_all)}")
     print("cur (min, max):", cur.tolist())
 
 

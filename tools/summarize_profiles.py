@@ -52,8 +52,17 @@ def pmc_rows(db, counter):
 
 def main(out, tag):
     stats, avg_us = kernel_table(find_db(os.path.join(out, "trace")))
+    phases = ""
+    ph = os.path.join(out, f"{tag}_bench_trace_phases.md")
+    if os.path.exists(ph):
+        txt = open(ph).read()
+        tail = txt[txt.find("| run length |"):] if "| run length |" in txt else ""
+        phases = ("\nThe step's kernel by how it was launched (tools/trace_phases.py on the same database; full table: "
+                  f"{tag}_bench_trace_phases.md): runs of 50 = graph replays of the K = 50 steps, longer runs = eager loops (settle, warm-up, "
+                  "pre-roll), the run of 1000 = the launches that carry dispatch events (`roofline.isolated_launch_us`).  `roofline.avg_launch_us` "
+                  "of the bench line is the back-to-back figure:\n\n" + tail)
     open(os.path.join(out, f"{tag}_bench_kernel_stats.md"), "w").write(
-        f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --settle 0 --no-cpu-baseline --no-calib --no-kernel-table\n\n" + stats)
+        f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --settle 0 --no-cpu-baseline --no-calib --no-kernel-table\n\n" + stats + phases)
     fetch = pmc_rows(find_db(os.path.join(out, "pmc_fetch")), "FETCH_SIZE")
     write = pmc_rows(find_db(os.path.join(out, "pmc_write")), "WRITE_SIZE")
     lines = [f"# {tag} PMC counters (rocprofv3 --pmc, separate passes), bench.py [256,128,768]", "",

@@ -35,7 +35,7 @@ typedef void* osq_stream;
 /* Bumped whenever a signature or the workspace layout changes; the Python host refuses a library whose
  * osq_abi_version() differs from the number it was written against (a stale libosq_hip.so must be rebuilt).
  * 5: the LSQ / LSQ+ backward takes its summation order as an argument (`lanes` / `sum_lanes`). */
-#define OSQ_ABI_VERSION 6
+#define OSQ_ABI_VERSION 7
 
 typedef enum osq_status {
     OSQ_OK = 0,
@@ -514,6 +514,17 @@ int osq_msefast_tensor_search_multi(void* const* states, const float* const* xs,
                                     const osq_token_view* views, const int64_t* const* lengths, int n_sites,
                                     void* workspace, osq_stream stream);
 int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq_stream stream);
+/* The LOSS MEMO of the per-tensor searches (ABI 7).  loss_fx (observer.py:423-432) is a pure function of the tensor and of the
+ * pair it hands to the fake-quant -- scale.item(), int(zero_point.item()) -- and scipy's bounded search asks for the same pair
+ * many times (the inner search of observer.py:434-446 moves the shift of a fixed range: the scale stays, the integer zero point
+ * changes once per quantisation step; the final inner search of observer.py:469-475 repeats an earlier one entirely).  A search
+ * keeps the pairs it has streamed (up to 512) in its state; the step after an evaluation advances the state machine for as long
+ * as the next candidate's pair is known.  Results, iterates and nfev are those of the search without it, bit for bit; on
+ * two-sided data 3/4 of the passes over the tensor go.  osq_set_tuning("mse_memo", 0) switches it off (tests, A/B).
+ * The _evals_flat / _evals_tokens / _evals_ordered / _ordered_multi_evals entry points use it; the persistent searches
+ * (osq_msefast_tensor_search*: the tensor is in registers, an evaluation costs microseconds) do not.
+ * stats_out: 4 device int32 -- nfev so far, pairs kept, evaluations answered from the memo, converged flag. */
+int osq_msefast_tensor_stats(const void* state, int32_t* stats_out, osq_stream stream);
 /* ObserverBase.calculate_qparams (observer.py:101-119) on float64 statistics -- what a per-tensor MSEFast observer holds:
  * torch computes in the statistics' (promoted) dtype; scale / zero_point are rounded to their fp32 / int32 storage once. */
 int osq_calculate_qparams_f64(const double* min_val, const double* max_val, int64_t n, int quant_min, int quant_max,

@@ -25,7 +25,7 @@ TIME_FAKE_QUANT_STRIDED, TIME_FAKE_QUANT_CHANNEL, TIME_OBSERVE_CHANNELS, TIME_TO
 TIME_OBSERVE_TOKENS = 13
 UPDATE_NONE, UPDATE_RUNNING, UPDATE_AVERAGE = 0, 1, 2
 ERR_UNSUPPORTED = -3          # OSQ_ERR_UNSUPPORTED: nothing was launched, the caller takes its other path
-ABI_VERSION = 6               # OSQ_ABI_VERSION of include/osq_hip.h this file was written against
+ABI_VERSION = 7               # OSQ_ABI_VERSION of include/osq_hip.h this file was written against
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -115,6 +115,7 @@ SIGNATURES = {
     "osq_msefast_tensor_search_multi": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_L), ctypes.POINTER(TokenView),
                                              ctypes.POINTER(_P), _I, _P, _P]),
     "osq_msefast_tensor_done": (_I, [_P, _P, _P]),
+    "osq_msefast_tensor_stats": (_I, [_P, _P, _P]),
     "osq_calculate_qparams_f64": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _I, _P]),
     "osq_msefast_tensor_commit": (_I, [_P, _I, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "osq_observe_moments": (_I, [_P, _L, _L, _L, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -405,13 +405,30 @@ __global__ __launch_bounds__(kThreads) void msefast_rows_kernel(const float* __r
 
 // ---------------------------------------------------------------- per-tensor: state in device memory
 
+// LOSS MEMO (round 6).  loss_fx (observer.py:423-432) is a pure function of the tensor and of the fake-quant parameters it is
+// handed -- scale.item() and int(zero_point.item()) -- and scipy's bounded search asks for the same pair again and again: the
+// inner search of the nested form (observer.py:434-446) moves the shift of a FIXED range, so the scale stays and the integer
+// zero point changes once per quantisation step; after ~8 evaluations the bracket is narrower than a step and the remaining
+// ~15 (xatol = 1e-5) repeat one pair, and the final inner search (observer.py:469-475) repeats the best range's from its first
+// evaluation to its last.  On two-sided data ~100 of a search's ~450 evaluations are distinct.  Every per-tensor search keeps
+// the (scale word, zero point) -> loss pairs of the evaluations it has streamed; the step that follows an evaluation keeps
+// advancing the state machine for as long as the next candidate's pair is in the table.  Same function value, bit for bit
+// (it IS the earlier evaluation's), same iterates, same nfev -- the pass over the tensor is what is skipped.
+// osq_set_tuning("mse_memo", 0): every evaluation streams (tests: equal results; A/B).
+constexpr int kMemoCap = 512;                    // pairs a search keeps (more distinct pairs than that: the rest stream as before)
 struct TensorSearch {
     Search S;
     float scale, zp;          // fake-quant parameters of the pending candidate
     int evals_launched;
     int pad;
     double scale_d;           // the same scale before its fp32 rounding (float64 arithmetic, Search::f64)
+    int memo_count, memo_hits;
+    unsigned long long memo_scale[kMemoCap];     // the scale as the evaluation uses it: the float64 word (Search::f64) or the fp32 one
+    double memo_loss[kMemoCap];                  // what the evaluation handed to tell()
+    unsigned int memo_zp[kMemoCap];
 };
+static_assert(sizeof(Search) % 8 == 0 && sizeof(Search) <= 1024, "the staged copy of the state: 8-byte words, at most 1 KiB");
+constexpr int kMemoLdsBytes = 1024 + kMemoCap * 20;          // the state's copy + the table, staged by the advancing wave
 
 __global__ void msefast_tensor_init_kernel(TensorSearch* __restrict__ ts, const float* __restrict__ cur_minmax,
                                            int quant_min, int quant_max, int symmetric, int side, int two_d, int f64) {
@@ -419,15 +436,82 @@ __global__ void msefast_tensor_init_kernel(TensorSearch* __restrict__ ts, const 
     ts->S.init(cur_minmax[0], cur_minmax[1], quant_min, quant_max, symmetric, side, two_d, f64);
     loss_qparams(ts->S.cand_min, ts->S.cand_max, quant_min, quant_max, symmetric, &ts->scale, &ts->zp, &ts->scale_d);
     ts->evals_launched = 0;
+    ts->memo_count = 0;
+    ts->memo_hits = 0;
 }
 
-// last workgroup: loss -> state machine -> next candidate
-__device__ __forceinline__ void tensor_search_advance(TensorSearch* ts, double total, double count) {
-    const double mean = total / count;
-    ts->S.tell(ts->S.f64 ? mean : static_cast<double>(static_cast<float>(mean)));
-    if (!ts->S.done)
-        loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
-                     &ts->scale_d);
+// The step after a streamed evaluation: loss -> state machine -> next candidate, repeated while the memo knows the candidate.
+// Called by ONE WHOLE WAVE (64 converged lanes) of the workgroup that finished the evaluation; `loss` (what the reference's
+// objective returns: an fp32 value unless Search::f64) is lane 0's.  lds: kMemoLdsBytes the wave may overwrite.  The state and
+// the table are staged in LDS for the walk -- a hit then costs the serial Brent step on LDS operands (~0.3 us) instead of a
+// memory round trip per field -- and written back once.
+__device__ __forceinline__ void tensor_search_advance(TensorSearch* ts, double loss, unsigned char* lds, const bool memo_on) {
+    const int lane = threadIdx.x & (OSQ_WAVE - 1);
+    constexpr int kWords = static_cast<int>(sizeof(Search) / 8);
+    Search* const S = reinterpret_cast<Search*>(lds);
+    unsigned long long* const mk = reinterpret_cast<unsigned long long*>(lds + 1024);
+    double* const ml = reinterpret_cast<double*>(mk + kMemoCap);
+    unsigned int* const mz = reinterpret_cast<unsigned int*>(ml + kMemoCap);
+    int count = memo_on ? __builtin_amdgcn_readfirstlane(ts->memo_count) : 0;
+    if (count > kMemoCap) count = kMemoCap;
+    float sc = ts->scale, zp = ts->zp;                     // the pair the streamed evaluation used
+    double scd = ts->scale_d;
+    {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ts->S);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(S);
+        for (int i = lane; i < kWords; i += OSQ_WAVE) dst[i] = src[i];
+        for (int i = lane; i < count; i += OSQ_WAVE) { mk[i] = ts->memo_scale[i]; ml[i] = ts->memo_loss[i]; mz[i] = ts->memo_zp[i]; }
+    }
+    cascade_wave_sync();                                      // lane 0 reads what the other lanes staged
+    const bool f64 = __builtin_amdgcn_readfirstlane(S->f64) != 0;
+    auto key_of = [&](unsigned long long& ks, unsigned int& kz) {
+        const unsigned long long w = f64 ? static_cast<unsigned long long>(__double_as_longlong(scd)) : static_cast<unsigned long long>(__float_as_uint(sc));
+        ks = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(w >> 32))) << 32) |
+             static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(w & 0xffffffffull)));
+        kz = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(zp))));
+    };
+    unsigned long long ks;
+    unsigned int kz;
+    key_of(ks, kz);
+    int n = count, hits = 0, done = 0;
+    const bool inserted = memo_on && n < kMemoCap;
+    if (inserted) {
+        if (lane == 0) { mk[n] = ks; mz[n] = kz; ml[n] = loss; }
+        ++n;
+    }
+    for (;;) {
+        cascade_wave_sync();
+        if (lane == 0) {
+            S->tell(loss);
+            if (!S->done) loss_qparams(S->cand_min, S->cand_max, S->quant_min, S->quant_max, S->symmetric, &sc, &zp, &scd);
+        }
+        cascade_wave_sync();
+        done = __builtin_amdgcn_readfirstlane(S->done);
+        if (done || !memo_on || hits >= 65536) break;
+        key_of(ks, kz);
+        int found = -1;
+        for (int i = lane; i < n; i += OSQ_WAVE)
+            if (mk[i] == ks && mz[i] == kz) found = i;
+        const unsigned long long hit = __ballot(found >= 0);
+        if (!hit) break;
+        const int idx = __shfl(found, __ffsll(static_cast<long long>(hit)) - 1);
+        loss = ml[idx];
+        ++hits;
+    }
+    cascade_wave_sync();
+    {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&ts->S);
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(S);
+        for (int i = lane; i < kWords; i += OSQ_WAVE) dst[i] = src[i];
+    }
+    if (lane == 0) {
+        if (!done) { ts->scale = sc; ts->zp = zp; ts->scale_d = scd; }
+        if (inserted) {
+            ts->memo_scale[count] = mk[count]; ts->memo_loss[count] = ml[count]; ts->memo_zp[count] = mz[count];
+            ts->memo_count = n;
+        }
+        if (hits) ts->memo_hits += hits;
+    }
 }
 
 // ---- test mode osq_set_tuning("mse_sum_order", 64): the loss summed as a double-double (error ~1e-32 relative), so that
@@ -463,8 +547,9 @@ __device__ __forceinline__ DD dd_wave_sum(DD v) {
 constexpr int kDdLoOffset = kMaxBlocks + 8;                  // low words of the published partials (behind the count of the token form)
 
 __device__ __forceinline__ void block_sum_publish_finish_exact(DD part, double* partials, unsigned int* counters,
-                                                               TensorSearch* ts, double count) {
+                                                               TensorSearch* ts, double count, const bool memo_on) {
     __shared__ double sh_hi[kWavesPerBlock], sh_lo[kWavesPerBlock];
+    __shared__ double memo_lds[kMemoLdsBytes / 8];
     part = dd_wave_sum(part);
     const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
     if (lane == 0) { sh_hi[wv] = part.hi; sh_lo[wv] = part.lo; }
@@ -486,18 +571,21 @@ __device__ __forceinline__ void block_sum_publish_finish_exact(DD part, double* 
         __syncthreads();
         if (lane == 0) { sh_hi[wv] = a.hi; sh_lo[wv] = a.lo; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wv == 0) {                                  // the first wave: lane 0 folds, the wave advances the search (memo walk)
             DD tot{0.0, 0.0};
-            for (int k = 0; k < kWavesPerBlock; ++k) tot = dd_join(tot, DD{sh_hi[k], sh_lo[k]});
-            tensor_search_advance(ts, tot.hi + tot.lo, count);
-            grid_reset(counters, gridDim.x);
+            if (lane == 0)
+                for (int k = 0; k < kWavesPerBlock; ++k) tot = dd_join(tot, DD{sh_hi[k], sh_lo[k]});
+            const double mean = (tot.hi + tot.lo) / count;
+            tensor_search_advance(ts, ts->S.f64 ? mean : static_cast<double>(static_cast<float>(mean)), reinterpret_cast<unsigned char*>(memo_lds), memo_on);
+            if (lane == 0) grid_reset(counters, gridDim.x);
         }
     }
 }
 
 __device__ __forceinline__ void block_sum_publish_finish(double part, double* partials, unsigned int* counters,
-                                                         TensorSearch* ts, double count) {
+                                                         TensorSearch* ts, double count, const bool memo_on) {
     __shared__ double sh[kWavesPerBlock];
+    __shared__ double memo_lds[kMemoLdsBytes / 8];
     part = wave_sum(part);
     const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = threadIdx.x / OSQ_WAVE;
     if (lane == 0) sh[wv] = part;
@@ -524,11 +612,13 @@ __device__ __forceinline__ void block_sum_publish_finish(double part, double* pa
         __syncthreads();
         if (lane == 0) sh[wv] = a;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (wv == 0) {
             double tot = 0.0;
-            for (int k = 0; k < kWavesPerBlock; ++k) tot += sh[k];
-            tensor_search_advance(ts, tot, count);
-            grid_reset(counters, gridDim.x);
+            if (lane == 0)
+                for (int k = 0; k < kWavesPerBlock; ++k) tot += sh[k];
+            const double mean = tot / count;
+            tensor_search_advance(ts, ts->S.f64 ? mean : static_cast<double>(static_cast<float>(mean)), reinterpret_cast<unsigned char*>(memo_lds), memo_on);
+            if (lane == 0) grid_reset(counters, gridDim.x);
         }
     }
 }
@@ -544,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
     const bool f64 = ts->S.f64 != 0;
     const float qmin = static_cast<float>(ts->S.quant_min), qmax = static_cast<float>(ts->S.quant_max);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
-    if (exact) {                                  // test mode: every squared error joins a double-double on its own
+    if (exact & 1) {                              // test mode: every squared error joins a double-double on its own
         DD dd{0.0, 0.0};
         for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n4; i += stride) {
             const float4 a = x[i];
@@ -554,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
         }
         if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail)
             dd_add(dd, f64 ? sq_err_f64(xt[threadIdx.x], sd, z, qmin, qmax) : static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax)));
-        block_sum_publish_finish_exact(dd, partials, counters, ts, static_cast<double>(n));
+        block_sum_publish_finish_exact(dd, partials, counters, ts, static_cast<double>(n), (exact & 2) != 0);
         return;
     }
     double acc = 0.0;
@@ -572,7 +662,7 @@ __global__ __launch_bounds__(kThreads) void msefast_flat_loss_kernel(const float
     }
     if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail)
         acc += f64 ? sq_err_f64(xt[threadIdx.x], sd, z, qmin, qmax) : static_cast<double>(sq_err(xt[threadIdx.x], s, z, qmin, qmax));
-    block_sum_publish_finish(acc, partials, counters, ts, static_cast<double>(n));
+    block_sum_publish_finish(acc, partials, counters, ts, static_cast<double>(n), (exact & 2) != 0);
 }
 
 // masked / strided activations: one wave per token (valid tokens only), any strides
@@ -592,7 +682,7 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
     const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) / OSQ_WAVE;
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     const int64_t F = v.feat_outer * v.feat_inner;
-    if (exact) {                                  // test mode: every squared error joins a double-double on its own
+    if (exact & 1) {                              // test mode: every squared error joins a double-double on its own
         DD dd{0.0, 0.0};
         for (int64_t tok = wave0; tok < ntok; tok += nwaves) {
             const int64_t b = tok / v.tokens, t = tok - b * v.tokens;
@@ -604,7 +694,7 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
                 dd_add(dd, f64 ? sq_err_f64(xv, sd, z, qmin, qmax) : static_cast<double>(sq_err(xv, s, z, qmin, qmax)));
             }
         }
-        block_sum_publish_finish_exact(dd, partials, counters, ts, valid_count[0]);
+        block_sum_publish_finish_exact(dd, partials, counters, ts, valid_count[0], (exact & 2) != 0);
         return;
     }
     double acc = 0.0;
@@ -630,7 +720,7 @@ __global__ __launch_bounds__(kThreads) void msefast_token_loss_kernel(const floa
         }
         acc += p;
     }
-    block_sum_publish_finish(acc, partials, counters, ts, valid_count[0]);
+    block_sum_publish_finish(acc, partials, counters, ts, valid_count[0], (exact & 2) != 0);
 }
 
 // osq_set_tuning("mse_sum_order", 8 | 16) for the PER-TENSOR searches -- the strict switch of the package
@@ -652,9 +742,12 @@ __device__ unsigned long long g_mse_phase[8];
 #define OSQ_MSE_STAMP(var) do { } while (0)
 #define OSQ_MSE_PHASE(slot, d) do { } while (0)
 #endif
-constexpr int kOrdThreads = 512;
+constexpr int kOrdThreads = 256;                              // WAVE form: four waves, each with its own chunks (cascade_chunks_wave)
+constexpr int kOrdThreadsPipe = 512;                          // pipelined form: two chunks per group of eight waves (cascade_chunks_pipelined)
+static_assert(kMemoLdsBytes <= 16 * 1024, "the memo walk of a strict evaluation's finisher reuses its 16 KiB of LDS");
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
 // one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
+template <int THREADS, bool WAVE>
 __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_generic, const int64_t n, TensorSearch* __restrict__ ts,
                                                    void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W_and_flags,
                                                    const unsigned int bid, const unsigned int nblk, double* lds_raw) {
@@ -665,6 +758,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
     OSQ_MSE_STAMP(t_entry);
     const int W = W_and_flags & 0xff;                             // 8 | 16; bit 8: the lean float64 term (osq_set_tuning("mse_lean"))
     const bool lean_ok = (W_and_flags >> 8) & 1;
+    const bool memo_on = (W_and_flags >> 12) & 1;                  // bit 12: the loss memo (tensor_search_advance)
     // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
@@ -690,7 +784,70 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
         };
         double* part = static_cast<double*>(scratch);
         double* lds = lds_raw;
-        if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
+        if (WAVE ? (fast && g.chunks > 0 && (g.NC == 16 || g.NC == 32) && g.P <= kCascadeMaxP) : ((g.S * g.NC) <= THREADS && g.chunks > 0)) {
+          if constexpr (WAVE) {
+            // full chunks, a wave per chunk: its next rows in flight under the arithmetic of the current ones (aten_order.h); the open unit below.
+            // (Data or scales beyond rcp_division_exact -- NaN / inf extrema, a scale outside [1e-9, 1e38] -- take the generic form below.)
+#ifdef OSQ_MSE_DBG
+            const bool dbg_noload = (W_and_flags >> 9) & 1, dbg_trivial = (W_and_flags >> 10) & 1;
+            auto load4 = [=](int64_t e) {
+                if (dbg_noload) { const float v = __int_as_float(0x3f000000 + static_cast<int>(e & 0xfffff)); return cascade_v4f32{v, v, v, v}; }
+                return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e);
+            };
+#else
+            constexpr bool dbg_trivial = false;
+            auto load4 = [=](int64_t e) { return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e); };
+#endif
+            static_assert(!WAVE || cascade_wave_lds_values<THREADS>() * 8 <= kOrdLdsBytes, "kOrdLdsBytes: 512 values per wave");
+#define OSQ_ORD_WAVE_F64(EVAL) do { \
+                if (g.NC == 16) { if (g.P == 4) cascade_chunks_wave<double, 4, 4, THREADS>(g, part, lds, load4, EVAL, bid, nblk); \
+                                  else cascade_chunks_wave<double, 5, 4, THREADS>(g, part, lds, load4, EVAL, bid, nblk); } \
+                else { if (g.P == 4) cascade_chunks_wave<double, 4, 5, THREADS>(g, part, lds, load4, EVAL, bid, nblk); \
+                       else cascade_chunks_wave<double, 5, 5, THREADS>(g, part, lds, load4, EVAL, bid, nblk); } } while (0)
+            if (lean) {
+                // the common case by far (a finite tensor, an integer zero point): the lean term, four elements of a row side by side;
+                // a row with an element within the tie guard (one row in ~1200) is redone in the exact chain -- one branch per row
+                auto eval4 = [=](cascade_v4f32 v, double (&t)[4]) {
+                    const float xs[4] = {v.x, v.y, v.z, v.w};
+                    if (dbg_trivial) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = static_cast<double>(xs[i]);
+                        return;
+                    }
+                    float r[4];
+                    bool tie[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float u = xs[i] * rcp32;
+                        r[i] = rintf(u);
+                        tie[i] = fabsf(u - r[i]) >= 0.4999f;                  // false for NaN (u = +-inf): saturates below
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float c = __builtin_amdgcn_fmed3f(r[i], lo32, hi32);
+                        const double d = static_cast<double>(c) * sd - static_cast<double>(xs[i]);
+                        t[i] = d * d;
+                    }
+                    if (tie[0] | tie[1] | tie[2] | tie[3]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double exact = sq_err_f64_rcp(xs[i], sd, rcp, z, qmin, qmax);
+                            t[i] = tie[i] ? exact : t[i];
+                        }
+                    }
+                };
+                OSQ_ORD_WAVE_F64(eval4);
+            } else {
+                auto eval4 = [=](cascade_v4f32 v, double (&t)[4]) {
+                    t[0] = sq_err_f64_rcp(v.x, sd, rcp, z, qmin, qmax);
+                    t[1] = sq_err_f64_rcp(v.y, sd, rcp, z, qmin, qmax);
+                    t[2] = sq_err_f64_rcp(v.z, sd, rcp, z, qmin, qmax);
+                    t[3] = sq_err_f64_rcp(v.w, sd, rcp, z, qmin, qmax);
+                };
+                OSQ_ORD_WAVE_F64(eval4);
+            }
+#undef OSQ_ORD_WAVE_F64
+          } else {
             // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
 #ifdef OSQ_MSE_DBG
             const bool dbg_noload = (W_and_flags >> 9) & 1, dbg_trivial = (W_and_flags >> 10) & 1;
@@ -702,39 +859,64 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
             if (lean && g.NC == 16) {
                 // the common case by far (a finite tensor, an integer zero point, the reference machine's W = 8): its own loop --
                 // the lean term alone, log2(NC) a constant (one address per thread and step, 16 immediate offsets)
-                auto eval = [=](float xf, int64_t, double (&t)[1]) {
-                    t[0] = dbg_trivial ? static_cast<double>(xf) : sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
+                // four of a thread's rows side by side; a four with an element within the tie guard (one in ~1200) is redone in the
+                // exact chain -- ONE branch per four elements (a diamond per element cost ~6 scalar instructions each)
+                auto eval = [=](const float (&xs)[4], double (&t)[4]) {
+                    if (dbg_trivial) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = static_cast<double>(xs[i]);
+                        return;
+                    }
+                    float r[4];
+                    bool tie[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float u = xs[i] * rcp32;
+                        r[i] = rintf(u);
+                        tie[i] = fabsf(u - r[i]) >= 0.4999f;                  // false for NaN (u = +-inf): saturates below
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float c = __builtin_amdgcn_fmed3f(r[i], lo32, hi32);
+                        const double d = static_cast<double>(c) * sd - static_cast<double>(xs[i]);
+                        t[i] = d * d;
+                    }
+                    if (tie[0] | tie[1] | tie[2] | tie[3]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double exact = sq_err_f64_rcp(xs[i], sd, rcp, z, qmin, qmax);
+                            t[i] = tie[i] ? exact : t[i];
+                        }
+                    }
                 };
-                static_assert(cascade_lds_fits<1, 4, kOrdThreads>(kOrdLdsBytes / 8) && cascade_lds_fits<1, 4, kOrdThreads>(kOrdLdsBytes / 4), "kOrdLdsBytes: two tiles + one group's block sums");
-                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
-                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float, decltype(load), decltype(eval), 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                static_assert(cascade_lds_fits<1, 4, THREADS>(kOrdLdsBytes / 8) && cascade_lds_fits<1, 4, THREADS>(kOrdLdsBytes / 4), "kOrdLdsBytes: two tiles + one group's block sums");
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, THREADS, float, decltype(load), decltype(eval), 4, 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                else cascade_chunks_pipelined<double, 1, 5, THREADS, float, decltype(load), decltype(eval), 4, 4>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             } else {
                 auto eval = [=](float xf, int64_t, double (&t)[1]) {
                     if (lean) t[0] = sq_err_f64_lean(xf, sd, rcp, rcp32, lo32, hi32, z, qmin, qmax);
                     else t[0] = fast ? sq_err_f64_rcp(xf, sd, rcp, z, qmin, qmax) : sq_err_f64_outofline(xf, sd, z, qmin, qmax);
                 };
-                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
-                else cascade_chunks_pipelined<double, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
+                else cascade_chunks_pipelined<double, 1, 5, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             }
+          }
             OSQ_MSE_STAMP(t_groups);
-            if (bid == nblk - 1) cascade_units<double, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
+            if (bid == nblk - 1) cascade_units<double, 1, THREADS>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
             OSQ_MSE_PHASE(0, t_state - t_entry); OSQ_MSE_PHASE(1, t_groups - t_state); OSQ_MSE_PHASE(4, 1);
         } else {
-            cascade_units<double, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
+            cascade_units<double, 1, THREADS>(g, part, lds, term, bid, nblk);
         }
         OSQ_MSE_STAMP(t_before_ticket);
         const bool last_wg = grid_last_block(counters, nblk, bid);
         OSQ_MSE_STAMP(t_after_ticket);
         OSQ_MSE_PHASE(2, t_after_ticket - t_before_ticket);
         if (last_wg) {
-            double sum[1];
-            cascade_finish<double, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 8, term, sum);
-            if (threadIdx.x == 0) {
-                ts->S.tell(sum[0] / static_cast<double>(n));
-                if (!ts->S.done)
-                    loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
-                                 &ts->scale_d);
-                grid_reset(counters, nblk);
+            double sum[1] = {0.0};
+            cascade_finish<double, 1, THREADS>(g, part, lds, kOrdLdsBytes / 8, term, sum);
+            if (threadIdx.x < OSQ_WAVE) {                         // thread 0 holds the sum; its wave walks the memo (the LDS is free now)
+                tensor_search_advance(ts, sum[0] / static_cast<double>(n), reinterpret_cast<unsigned char*>(lds_raw), memo_on);
+                if (threadIdx.x == 0) grid_reset(counters, nblk);
             }
             OSQ_MSE_STAMP(t_finished);
             OSQ_MSE_PHASE(3, t_finished - t_after_ticket); OSQ_MSE_PHASE(5, 1);
@@ -744,37 +926,48 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
         auto term = [=](int64_t e, float (&t)[1]) { t[0] = sq_err(x[e], s, z, qmin, qmax); };
         float* part = static_cast<float*>(scratch);
         float* lds = reinterpret_cast<float*>(lds_raw);
-        if ((g.S * g.NC) <= kOrdThreads && g.chunks > 0) {
+        if (WAVE ? (g.chunks > 0 && (g.NC == 32 || g.NC == 64) && g.P <= kCascadeMaxP) : ((g.S * g.NC) <= THREADS && g.chunks > 0)) {
+          if constexpr (WAVE) {
+            auto load4 = [=](int64_t e) { return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e); };
+            auto eval4 = [=](cascade_v4f32 v, float (&t)[4]) {
+                t[0] = sq_err(v.x, s, z, qmin, qmax);
+                t[1] = sq_err(v.y, s, z, qmin, qmax);
+                t[2] = sq_err(v.z, s, z, qmin, qmax);
+                t[3] = sq_err(v.w, s, z, qmin, qmax);
+            };
+            if (g.NC == 32) { if (g.P == 4) cascade_chunks_wave<float, 4, 5, THREADS>(g, part, lds, load4, eval4, bid, nblk);
+                              else cascade_chunks_wave<float, 5, 5, THREADS>(g, part, lds, load4, eval4, bid, nblk); }
+            else { if (g.P == 4) cascade_chunks_wave<float, 4, 6, THREADS>(g, part, lds, load4, eval4, bid, nblk);
+                   else cascade_chunks_wave<float, 5, 6, THREADS>(g, part, lds, load4, eval4, bid, nblk); }
+          } else {
             auto load = [=](int64_t e) { return x[e]; };
             auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
             if (g.NC == 32 && g.P == 4)                         // the reference machine's W = 8 (S * NC <= 512 leaves P = 4 only): log2(NC) a constant, as above
-                cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
-            else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
-            else cascade_chunks_pipelined<float, 1, 5, kOrdThreads, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
-            if (bid == nblk - 1) cascade_units<float, 1, kOrdThreads>(g, part, lds, term, 0u, 1u, g.chunks);
+                cascade_chunks_pipelined<float, 1, 4, THREADS, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
+            else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
+            else cascade_chunks_pipelined<float, 1, 5, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
+          }
+            if (bid == nblk - 1) cascade_units<float, 1, THREADS>(g, part, lds, term, 0u, 1u, g.chunks);
         } else {
-            cascade_units<float, 1, kOrdThreads>(g, part, lds, term, bid, nblk);
+            cascade_units<float, 1, THREADS>(g, part, lds, term, bid, nblk);
         }
         if (grid_last_block(counters, nblk, bid)) {
-            float sum[1];
-            cascade_finish<float, 1, kOrdThreads>(g, part, lds, kOrdLdsBytes / 4, term, sum);
-            if (threadIdx.x == 0) {
-                ts->S.tell(static_cast<double>(sum[0] / static_cast<float>(n)));
-                if (!ts->S.done)
-                    loss_qparams(ts->S.cand_min, ts->S.cand_max, ts->S.quant_min, ts->S.quant_max, ts->S.symmetric, &ts->scale, &ts->zp,
-                                 &ts->scale_d);
-                grid_reset(counters, nblk);
+            float sum[1] = {0.0f};
+            cascade_finish<float, 1, THREADS>(g, part, lds, kOrdLdsBytes / 4, term, sum);
+            if (threadIdx.x < OSQ_WAVE) {
+                tensor_search_advance(ts, static_cast<double>(sum[0] / static_cast<float>(n)), reinterpret_cast<unsigned char*>(lds_raw), memo_on);
+                if (threadIdx.x == 0) grid_reset(counters, nblk);
             }
         }
     }
 }
 
-__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
+__global__ __launch_bounds__(kOrdThreadsPipe) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
                                                                             const int64_t* __restrict__ n_dev,
                                                                             TensorSearch* __restrict__ ts, void* __restrict__ scratch,
                                                                             unsigned int* __restrict__ counters, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
-    ordered_evaluation(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
+    ordered_evaluation<kOrdThreadsPipe, false>(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
 }
 
 // The strict form of the searches of a whole forward (the observers of an observer pass are independent): ONE launch per
@@ -799,11 +992,20 @@ constexpr size_t kOrderedCounterBytes = (1 + kTicketShards) * kTicketStride * si
 // A workgroup's first loads are a dependent chain -- which site, its table entry, the search's state, only then the data --
 // and a round has thousands of short-lived workgroups: the chain is kept at three round trips (block -> site map, entry,
 // state; the element count of a masked site is copied into its entry once, by ordered_sites_counts_kernel).
-__global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites,
-                                                                                      const unsigned char* __restrict__ block_site, int n_sites, int W) {
+#ifndef OSQ_ORD_MIN_WAVES
+#define OSQ_ORD_MIN_WAVES 4                                   // waves per SIMD the WAVE form's registers are budgeted for (A/B builds: -DOSQ_ORD_MIN_WAVES=5)
+#endif
+template <int THREADS, bool WAVE>
+__global__ __launch_bounds__(THREADS, WAVE ? OSQ_ORD_MIN_WAVES : 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites,
+                                                                                   const unsigned char* __restrict__ block_site, int n_sites, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
-    const OrderedSite s = sites[block_site[blockIdx.x]];
-    ordered_evaluation(s.x, s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
+    // PING-PONG (round 6): a round streams every open site once (~0.3-0.6 GB), more than the 256 MB memory-side cache holds, so a
+    // round that walks the sites in the same direction as its predecessor finds none of its bytes there.  Every other round walks
+    // the grid backwards: what the last round read last is read first.  Which workgroup adds which chunk does not touch a sum
+    // (the chunks' block sums have their own slots; the finisher folds them in position order).
+    const unsigned int b = ((W >> 11) & 1) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const OrderedSite s = sites[block_site[b]];
+    ordered_evaluation<THREADS, WAVE>(s.x, s.n_host, s.ts, s.scratch, s.counters, W, b - s.block_begin, s.blocks, lds_raw);
 }
 
 // after the gathers of a group: n_host <- the device-side count of valid elements (same stream, once per group)
@@ -1008,6 +1210,7 @@ OSQ_SWITCH(int, g_mse_rows_order, 8);                     // osq_set_tuning("mse
 OSQ_AB_KNOB(int, g_mse_dbg, 0);                            // -DOSQ_MSE_DBG builds only (tools/mse_dbg_probe.py): 1 = generated values instead of data loads, 2 = a conversion instead of the term; WRONG results, timing probes
 OSQ_AB_KNOB(int, g_mse_lean, 1);                           // osq_set_tuning("mse_lean", 0): the float64 terms of the reference-order evaluations without the guarded fp32 quotient (sq_err_f64_lean; tests, A/B)
 OSQ_SWITCH(int, g_mse_sum_order, 0);                      // osq_set_tuning("mse_sum_order", 0 | 8 | 16 | 64): 8 / 16 = per-row losses summed in ATen's CPU order, 64 = per-tensor losses summed as double-doubles (test modes)
+OSQ_SWITCH(int, g_mse_memo, 1);                           // osq_set_tuning("mse_memo", 0): every loss evaluation of a per-tensor search streams its tensor, also a pair the search has seen (tests: equal results; A/B)
 OSQ_SWITCH(unsigned int, g_res_spin_limit, 0u);            // osq_set_tuning("mse_spin_limit", n): 0 = kResSpinLimit, n > 0 = n - 1 polls (tests: 1 forces the time-out path)
 
 struct ResidentState {                                   // workspace slice, all-zero before the first launch
@@ -1586,7 +1789,7 @@ extern "C" int osq_msefast_tensor_evals_flat(void* state, const float* x, int64_
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_flat_loss_kernel, dim3(grid), dim3(kThreads), 0, st, reinterpret_cast<const float4*>(x),
                            n4, x + n4 * 4, static_cast<int>(n - n4 * 4), n, static_cast<TensorSearch*>(state),
-                           ws.doubles(kFamMseFlat), ws.counter(kFamMseFlat), g_mse_sum_order == 64 ? 1 : 0);
+                           ws.doubles(kFamMseFlat), ws.counter(kFamMseFlat), (g_mse_sum_order == 64 ? 1 : 0) | (g_mse_memo ? 2 : 0));
     return check_launch("msefast_tensor_evals_flat");
 }
 
@@ -1607,7 +1810,7 @@ extern "C" int osq_msefast_tensor_evals_tokens(void* state, const float* x, cons
     for (int e = 0; e < n_evals; ++e)
         hipLaunchKernelGGL(msefast_token_loss_kernel, dim3(grid), dim3(kThreads), 0, st, x, v, lengths, vec,
                            static_cast<TensorSearch*>(state), ws.doubles(kFamMseTokens), ws.counter(kFamMseTokens), count,
-                           g_mse_sum_order == 64 ? 1 : 0);
+                           (g_mse_sum_order == 64 ? 1 : 0) | (g_mse_memo ? 2 : 0));
     return check_launch("msefast_tensor_evals_tokens");
 }
 
@@ -1644,14 +1847,18 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace ws(workspace);
     // one workgroup per level-1 chunk of the cascade in its finest form (float64: 256 rows x W / 2 x 4 columns), at most 2048
+    OSQ_REQUIRE(aligned16(x_flat), "msefast_tensor_evals_ordered: x_flat must be 16-byte aligned");
     const CascadeGeom g = cascade_geom(n, g_mse_sum_order / 2);
     const int grid = static_cast<int>(std::min<int64_t>(g.chunks + 1, kMaxBlocks));
     for (int e = 0; e < n_evals; ++e)
-        hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreads), 0, st, x_flat, n, n_device,
-                           static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order | (g_mse_lean ? 256 : 0));
+        hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreadsPipe), 0, st, x_flat, n, n_device,
+                           static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_memo ? 4096 : 0));
     return check_launch("msefast_tensor_evals_ordered");
 }
 
+OSQ_AB_KNOB(int, g_mse_pingpong, 1);   // osq_set_tuning("mse_pingpong", 0): every round walks the grid forwards (A/B)
+OSQ_AB_KNOB(int, g_mse_wave, 0);            // osq_set_tuning("mse_wave", 0): the rounds by cascade_chunks_pipelined (512-thread workgroups, a row per thread) instead of a wave per chunk
+OSQ_AB_KNOB(int, g_ord_slots, 0);           // osq_set_tuning("mse_round_slots", n): workgroups of a round, dealt to the sites by size (0: a workgroup per mse_round_groups)
 OSQ_AB_KNOB(int, g_ord_groups, 8);          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
@@ -1668,10 +1875,13 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
     OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
                 "msefast_ordered_multi_prepare: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
     std::vector<OrderedSite> host(static_cast<size_t>(n_sites));
+    int64_t total_elems = 0;
+    for (int i = 0; i < n_sites; ++i) total_elems += n[i] > 0 ? n[i] : 0;
     char* const counters0 = static_cast<char*>(table) + static_cast<size_t>(n_sites) * sizeof(OrderedSite);
     int64_t total = 0;
     for (int i = 0; i < n_sites; ++i) {
         OSQ_REQUIRE(states[i] && x_flat[i] && n[i] > 0 && scratch[i], "msefast_ordered_multi_prepare: bad site");
+        OSQ_REQUIRE(aligned16(x_flat[i]), "msefast_ordered_multi_prepare: x_flat must be 16-byte aligned");
         OSQ_REQUIRE(scratch_bytes[i] >= osq_ordered_sum_scratch_bytes(n[i], 1), "msefast_ordered_multi_prepare: scratch smaller than osq_ordered_sum_scratch_bytes(n, 1)");
         const CascadeGeom g = cascade_geom(n[i], g_mse_sum_order / 2);
         OSQ_REQUIRE(g.P <= kCascadeMaxP, "msefast_ordered_multi_prepare: tensor too large");
@@ -1687,7 +1897,14 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
         // the default) so that the loads of its next group travel under the arithmetic of the current one (aten_order.h,
         // cascade_chunks_pipelined); S = 32 (beyond 8.4 M elements): chunks of 16384 elements, 8 to a workgroup (measured best)
         const int64_t chunk_elems = static_cast<int64_t>(g.S) * g.S * g.NC;
-        const int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
+        int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
+        if (g_ord_slots > 0) {
+            // a round's workgroups are as many as the chip holds at once (g_ord_slots), dealt to the sites in proportion to their
+            // elements: every workgroup starts with the launch and they end together -- one start-up chain (table -> state -> first
+            // rows) per round and slot instead of one per 16 chunks, no last partial wave of workgroups
+            const int64_t share = std::max<int64_t>((n[i] * g_ord_slots + total_elems - 1) / total_elems, 1);
+            per_wg = std::max<int64_t>((g.chunks + share - 1) / share, 1);
+        }
         const int64_t groups = (g.chunks + per_wg - 1) / per_wg + 1;
         s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>(groups, 1), kMaxBlocks));
         s.pad[0] = s.pad[1] = 0u;
@@ -1718,8 +1935,13 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
     const OrderedSite* sites = static_cast<const OrderedSite*>(table);
     const unsigned char* block_site = static_cast<const unsigned char*>(table) + static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
     for (int e = 0; e < n_evals; ++e)
-        hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites,
-                           g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_dbg << 9));
+    {
+        const int flags = g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_dbg << 9) | ((g_mse_pingpong && (e & 1)) ? 2048 : 0) | (g_mse_memo ? 4096 : 0);
+        if (g_mse_wave)
+            hipLaunchKernelGGL((msefast_tensor_ordered_multi_kernel<kOrdThreads, true>), dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites, flags);
+        else
+            hipLaunchKernelGGL((msefast_tensor_ordered_multi_kernel<kOrdThreadsPipe, false>), dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreadsPipe), 0, st, sites, block_site, n_sites, flags);
+    }
     if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
     return check_launch("msefast_ordered_multi_evals");
 }
@@ -1729,11 +1951,15 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
 static std::atomic<int> g_mse_resident{[] { const char* e = getenv("OSQ_FUSED_STEP"); return (e && e[0] == '0') ? 0 : 1; }()};
 namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_resident") { g_mse_resident = value != 0; return true; }
+    if (std::string(key) == "mse_memo") { g_mse_memo = value != 0; return true; }
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
 #ifdef OSQ_TUNABLE
+    if (std::string(key) == "mse_wave") { g_mse_wave = value != 0; return true; }
+    if (std::string(key) == "mse_round_slots") { if (value < 0 || value > 65536) return false; g_ord_slots = value; return true; }
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
+    if (std::string(key) == "mse_pingpong") { g_mse_pingpong = value != 0; return true; }
 #ifdef OSQ_MSE_DBG
     if (std::string(key) == "mse_dbg") { g_mse_dbg = value & 3; return true; }
 #endif
@@ -1872,6 +2098,16 @@ extern "C" int osq_msefast_tensor_done(const void* state, int32_t* done_out, osq
     hipLaunchKernelGGL(msefast_done_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const TensorSearch*>(state), done_out);
     return check_launch("msefast_tensor_done");
+}
+
+__global__ void msefast_stats_kernel(const TensorSearch* __restrict__ ts, int32_t* __restrict__ out) {
+    if (threadIdx.x == 0) { out[0] = ts->S.nfev; out[1] = ts->memo_count; out[2] = ts->memo_hits; out[3] = ts->S.done; }
+}
+extern "C" int osq_msefast_tensor_stats(const void* state, int32_t* stats_out, osq_stream stream) {
+    OSQ_REQUIRE(state && stats_out, "msefast_tensor_stats: null pointer");
+    hipLaunchKernelGGL(msefast_stats_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const TensorSearch*>(state), stats_out);
+    return check_launch("msefast_tensor_stats");
 }
 
 extern "C" int osq_calculate_qparams_f64(const double* min_val, const double* max_val, int64_t n, int quant_min, int quant_max,

@@ -745,6 +745,7 @@ ORDERED_GROUP_SITES = 128     # searches one table of osq_msefast_ordered_multi_
 ORDERED_GROUP_BYTES = int(os.environ.get("OSQ_MSE_GROUP_MIB", "2048")) << 20
 
 
+ORDERED_CHUNK = max(1, int(os.environ.get("OSQ_MSE_CHUNK", "64")))          # rounds enqueued between two looks at a group's all-done flag
 ORDERED_STREAMS = max(1, int(os.environ.get("OSQ_MSE_STREAMS", "2")))     # concurrent groups of nested searches (see msefast_ordered_groups)
 
 
@@ -858,11 +859,12 @@ def _ordered_group_rounds(ctx, chunk):
     ctx["launched"] += chunk
 
 
-def msefast_tensor_run_ordered_group(group, chunk=64):
+def msefast_tensor_run_ordered_group(group, chunk=None):
     """The strict form of several searches (MseSearch records of one device, e.g. the MSEFast observers of one forward):
     rounds of ONE launch = one loss evaluation of every unfinished search, each sum in the order of torch.sum on a
     one-thread host (csrc/aten_order.h, osq_msefast_ordered_multi_*).  Same numbers as _msefast_tensor_run_ordered
     search by search (tests/test_gpu_strict_order.py)."""
+    chunk = chunk or ORDERED_CHUNK
     ctx = _ordered_group_prepare(group)
     while True:
         _ordered_group_rounds(ctx, chunk)
@@ -874,7 +876,7 @@ def msefast_tensor_run_ordered_group(group, chunk=64):
 _side_streams = {}
 
 
-def msefast_tensor_run_ordered_groups(groups, chunk=64):
+def msefast_tensor_run_ordered_groups(groups, chunk=None):
     """Several groups of strict searches CONCURRENTLY (see msefast_ordered_groups for why), at most ORDERED_STREAMS + 1 at a
     time: a group is prepared -- its gathered copies of masked sites, scratch and table allocated -- only when a stream is
     free, and dropped as soon as its searches have converged, so ORDERED_GROUP_BYTES bounds the memory of
@@ -883,6 +885,7 @@ def msefast_tensor_run_ordered_groups(groups, chunk=64):
     continues behind all of them -- ALSO when a launch, a prepare or a read-back raises: the records' tensors must not be
     freed under rounds that are still queued.  The records of `groups` must stay referenced by the caller until then (they
     are: the flush commits them afterwards)."""
+    chunk = chunk or ORDERED_CHUNK
     groups = [g for g in groups if g]
     if not groups:
         return 0
@@ -979,6 +982,14 @@ def msefast_tensor_commit(r, rule, cnt, min_val, max_val, sink=None, ref_float64
                                              quant_min, quant_max, symmetric, s_ptr, z_ptr, z_type,
                                              _hip.ptr(nfev), _hip.ptr(ref_float64), _hip.stream_ptr(dev)), "msefast_commit")
     return nfev
+
+
+def msefast_tensor_stats(r):
+    """int32[4] on the device: evaluations so far (nfev), pairs the search's loss memo holds, evaluations it answered, converged
+    flag (osq_msefast_tensor_stats; the memo: include/osq_hip.h)."""
+    out = torch.empty(4, dtype=torch.int32, device=r.x.device)
+    _hip.check(_hip.load().osq_msefast_tensor_stats(_hip.ptr(r.state), _hip.ptr(out), _hip.stream_ptr(r.x.device)), "msefast_tensor_stats")
+    return out
 
 
 def msefast_tensor(x, cur, observation_mask, seq_pos, quant_min, quant_max, symmetric, one_side, two_d,

@@ -26,6 +26,11 @@ from .. import _hip, ops
 from . import observer as _observer
 
 
+# tools / bench: a list here receives, per flushed forward, [(elements, nested search?, int32[4] device tensor of
+# ops.msefast_tensor_stats: nfev, pairs kept, evaluations the loss memo answered, converged)] of its per-tensor searches
+MSE_STATS_SINK = None
+
+
 class DeferredSites:
     def __init__(self):
         self.sites = []
@@ -78,6 +83,8 @@ class DeferredSites:
         return self._commit_mse(pending)
 
     def _commit_mse(self, pending):
+        if MSE_STATS_SINK is not None:
+            MSE_STATS_SINK.append([(int(search.elems), bool(two_d), ops.msefast_tensor_stats(search)) for _, search, two_d, _, _, _ in pending])
         for obs, search, two_d, sink, cnt, rule in pending:
             obs.last_nfev = ops.msefast_tensor_commit(search, rule, cnt, obs.min_val, obs.max_val, sink,
                                                       obs._ref_flags(obs.min_val.device))

@@ -56,6 +56,7 @@ for rep in range(2):
     calibration.calibrate_owned_sites(model, batches[:1], lambda m, b: m(**b), select=lambda n: "weight_fake_quant" in n)
     enable_calibration_woquantization(model, quantizer_type="act_fake_quant")
     acc.clear()
+    stats = deferred.MSE_STATS_SINK = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     calibration.calibrate_owned_sites(model, batches, fwd)
@@ -64,3 +65,22 @@ for rep in range(2):
     print(f"run {rep}: {len(batches)} batches, {total * 1e3:.1f} ms = {total / len(batches) * 1e3:.1f} ms per batch")
     for k, v in acc.items():
         print(f"    {k:42s} {v / len(batches) * 1e3:7.2f} ms per batch")
+    if rep == 1 and stats:
+        # the loss memo, search by search: what streamed and what was answered (last run, all batches)
+        import collections
+        rows = collections.defaultdict(lambda: [0, 0, 0, 0, 0])
+        rounds_per_batch = []
+        for fwd_stats in stats:
+            most = 0
+            for elems, nested, t in fwd_stats:
+                nfev, pairs, hits, done = (int(v) for v in t.cpu())
+                r = rows[(elems, nested)]
+                r[0] += 1; r[1] += nfev; r[2] += nfev - hits; r[3] += hits; r[4] += elems * 4 * (nfev - hits)
+                most = max(most, nfev - hits)
+            rounds_per_batch.append(most)
+        print("    loss memo (elements of the site as recorded, nested search?): searches, nfev, streamed, answered, GB streamed")
+        tot_b, tot_all = 0, 0
+        for (elems, nested), r in sorted(rows.items()):
+            print(f"      {elems:9d} {str(nested):5s}  {r[0]:4d} searches  nfev {r[1] / r[0]:6.1f}  streamed {r[2] / r[0]:6.1f}  answered {r[3] / r[0]:6.1f}  {r[4] / 1e9:7.2f} GB")
+            tot_b += r[4]; tot_all += elems * 4 * r[1]
+        print(f"      bytes streamed {tot_b / 1e9:.1f} GB of {tot_all / 1e9:.1f} GB without the memo (slots, padding included); most streamed evaluations of a search per batch: {rounds_per_batch}")

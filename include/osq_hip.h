@@ -110,6 +110,9 @@ size_t      osq_workspace_bytes(void);
  *                        persistent resident form;
  *     "final_fast" 0     the token range finaliser without the two-workgroup kernel; "select_shortcut" 0: that kernel always
  *                        runs its register threshold pass;
+ *     "mse_memo" 0       every loss evaluation of a per-tensor MSEFast search streams its tensor, also one whose (scale, zero
+ *                        point) pair the search has evaluated before (default 1: answered from the search's memo, see
+ *                        osq_msefast_tensor_stats; same results, iterates and nfev either way);
  *   robustness:
  *     "fused_spin_limit" / "mse_spin_limit" n   bound of the cross-workgroup waits of the two persistent launch families
  *                        (0 = the default, ~2 s; n > 0 = n - 1 polls, so 1 makes every wait give up at once: tests force the

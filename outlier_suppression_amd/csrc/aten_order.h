@@ -316,112 +316,6 @@ __device__ __forceinline__ void cascade_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Stage 1 of ONE sum over the FULL level-1 chunks, a WAVE per chunk (round 6).  cascade_chunks_pipelined above keeps one row
-// per thread and 16 dword loads = 4 KB per wave in flight: with 4 waves per SIMD (128 VGPRs) that is 64 KB per CU, 16 MB on the
-// chip, and at the ~2.7 us a load takes under load Little's law gives the 4.8 TB/s the rounds ran at -- the kernel was bound by
-// its bytes in flight, not by HBM or by its arithmetic.  Here a chunk (S blocks x S rows x NC columns, contiguous in memory)
-// belongs to ONE wave: lane (block, column quad) reads its rows as 16-byte loads -- R = 8 rows = 8 KB per wave in flight behind
-// the 8 KB being added, twice the bytes per register spent on the way -- and adds four columns' block sums in row order;
-// the S block sums of a column meet in a wave-private LDS tile and are added in order by lane (column): no workgroup barrier
-// anywhere in the stream (the waves of a workgroup run free), one at its end in front of the ticket.  A chunk wider than a wave
-// (NC / 4 quads x S blocks > 64 lanes) is walked in passes of 64 / (NC / 4) blocks, the column chain carried across them.
-// Same additions in the same order as cascade_units.  The chunk sums of up to 256 / NC chunks wait in LDS and leave in one burst
-// (no store inside the stream: vmcnt counts loads and stores in one order, see above).
-// lds: THREADS / 64 * 512 values of T.  load4(e): the 4 elements e .. e + 3 (e a multiple of 4; the vector must be 16-byte
-// aligned); eval4(raw, t[4]): their four terms (one call per row and lane: a term with a rare slow form takes ONE branch per row --
-// a diamond per element left the compiler 32 of them per step and its block-local scheduler spilled every term).  Requires chunks > 0.  Wave w of workgroup bid takes the chunks (bid * WAVES + w) + k * nblk_grid * WAVES.
-typedef float cascade_v4f32 __attribute__((ext_vector_type(4)));
-template <int THREADS>
-constexpr int cascade_wave_lds_values() { return THREADS / OSQ_WAVE * 512; }
-template <typename T, int P, int NCS, int THREADS, typename Load4, typename Eval4>
-__device__ __forceinline__ void cascade_chunks_wave(const CascadeGeom& g, T* __restrict__ part, T* lds, Load4 load4, Eval4 eval4,
-                                                    const unsigned int bid, const unsigned int nblk_grid) {
-    constexpr int S = 1 << P, NC = 1 << NCS, Q = NC / 4, BP = OSQ_WAVE / Q, PASSES = S / BP, R = 8, STEPS = S / R;
-    constexpr int WAVES = THREADS / OSQ_WAVE, KMAX = 256 / NC;
-    static_assert(Q >= 1 && Q <= OSQ_WAVE && BP * Q == OSQ_WAVE && PASSES * BP == S && STEPS >= 1 && KMAX >= 1, "cascade_chunks_wave: geometry");
-    // the wave's index is the same in its 64 lanes: say so (a scalar; the loops over its chunks are then uniform branches, not exec masks)
-    const int lane = threadIdx.x & (OSQ_WAVE - 1), wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x / OSQ_WAVE));
-    const int bl = lane / Q, cq = lane % Q;
-    T* const tile = lds + wv * 512;                         // [BP][NC] block sums of a pass
-    T* const held = tile + 256;                             // [KMAX][NC] chunk sums of a batch
-    const int64_t stride = static_cast<int64_t>(nblk_grid) * WAVES;
-    const int64_t m0 = static_cast<int64_t>(bid) * WAVES + wv;
-    const int nk = m0 < g.chunks ? static_cast<int>((g.chunks - 1 - m0) / stride) + 1 : 0;
-    // The rows in flight are a RING of R registers quadruples: as soon as row k of the current step has been added, its registers
-    // take row k of the NEXT step -- R - 1 loads (7 KB per wave) stay in flight behind the row being added, for R quadruples of
-    // registers, not 2 R (a second buffer cost the kernel its occupancy: 128 VGPRs hold four waves per SIMD).
-    cascade_v4f32 A[R];
-    // first element of lane (block, quad)'s rows of step (m, p, h).  m < 0: nothing left to fetch -- the first rows of the vector
-    // instead (in bounds: chunks > 0; every wave the same lines), never used.  Branch-free: behind a condition the compiler loses
-    // count of the loads in flight (see above).
-    auto first = [&](const int64_t m, const int p, const int h) -> int64_t {
-        const int64_t row0 = ((((m << P) + p * BP + bl) << P) + h * R);
-        return m >= 0 ? (row0 << NCS) + 4 * cq : static_cast<int64_t>(4 * cq);
-    };
-    auto step = [&](T (&acc)[4], const int64_t e_next) {
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            T t[4];
-            eval4(A[k], t);
-            acc[0] = acc[0] + t[0];
-            acc[1] = acc[1] + t[1];
-            acc[2] = acc[2] + t[2];
-            acc[3] = acc[3] + t[3];
-            // the sums are pinned HERE: left alone, the optimizer sinks the whole chain of additions to the block that uses its end
-            // (the terms of a pass, 2 x 32 doubles per lane, then wait in scratch memory)
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-            A[k] = load4(e_next + (static_cast<int64_t>(k) << NCS));
-        }
-    };
-    {
-        const int64_t e0 = first(nk > 0 ? m0 : static_cast<int64_t>(-1), 0, 0);
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            A[k] = load4(e0 + (static_cast<int64_t>(k) << NCS));
-            __builtin_amdgcn_sched_barrier(0);              // in ring order: issued otherwise, the loop's first wait is for all of them (vmcnt(0) at its header)
-        }
-    }
-    T colacc = T(0);
-    for (int k0 = 0; k0 < nk; k0 += KMAX) {
-        const int nb = nk - k0 < KMAX ? nk - k0 : KMAX;
-        for (int kk = 0; kk < nb; ++kk) {
-            const int64_t m = m0 + static_cast<int64_t>(k0 + kk) * stride;
-            const int64_t m_next = (k0 + kk + 1 < nk) ? m + stride : static_cast<int64_t>(-1);
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                T acc[4] = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-                for (int h = 0; h < STEPS; ++h) {
-                    if (h + 1 < STEPS) step(acc, first(m, p, h + 1));
-                    else if (p + 1 < PASSES) step(acc, first(m, p + 1, 0));
-                    else step(acc, first(m_next, 0, 0));
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) tile[bl * NC + 4 * cq + c] = acc[c];
-                cascade_wave_sync();
-                if (lane < NC) {
-                    T v[BP];
-#pragma unroll
-                    for (int b = 0; b < BP; ++b) v[b] = tile[b * NC + lane];
-#pragma unroll
-                    for (int b = 0; b < BP; ++b) colacc = colacc + v[b];
-                }
-                cascade_wave_sync();                        // the next pass overwrites the tile
-            }
-            if (lane < NC) held[kk * NC + lane] = colacc;
-            colacc = T(0);
-        }
-        cascade_wave_sync();
-        for (int t = lane; t < nb * NC; t += OSQ_WAVE) {
-            const int kk = t >> NCS, c = t & (NC - 1);
-            cascade_publish<T>(&part[((m0 + static_cast<int64_t>(k0 + kk) * stride) << NCS) + c], held[t]);
-        }
-        cascade_wave_sync();                                // the next batch overwrites held[]
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's published sums have left before the workgroup's ticket
-    __syncthreads();
-}
-
 // ---- stage 2: the last workgroup; `lds` holds lds_values values of T (>= NS * NC + NC); the sums arrive in out[] of thread 0
 template <typename T, int NS, int THREADS, typename Term>
 __device__ __forceinline__ void cascade_finish(const CascadeGeom& g, const T* __restrict__ part, T* lds, int lds_values, Term term,

@@ -742,12 +742,11 @@ __device__ unsigned long long g_mse_phase[8];
 #define OSQ_MSE_STAMP(var) do { } while (0)
 #define OSQ_MSE_PHASE(slot, d) do { } while (0)
 #endif
-constexpr int kOrdThreads = 256;                              // WAVE form: four waves, each with its own chunks (cascade_chunks_wave)
-constexpr int kOrdThreadsPipe = 512;                          // pipelined form: two chunks per group of eight waves (cascade_chunks_pipelined)
+constexpr int kOrdThreads = 512;
 static_assert(kMemoLdsBytes <= 16 * 1024, "the memo walk of a strict evaluation's finisher reuses its 16 KiB of LDS");
 constexpr int kOrdLdsBytes = 16 * 1024;                       // stage 1: S * NC values (<= 32 x 64 x 4 B, 32 x 32 x 8 B); stage 2: columns + a tile of level-2 units
 // one loss evaluation of one search: workgroup `bid` of the `nblk` that serve it; `counters` are the search's own
-template <int THREADS, bool WAVE>
+template <int THREADS>
 __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_generic, const int64_t n, TensorSearch* __restrict__ ts,
                                                    void* __restrict__ scratch, unsigned int* __restrict__ counters, const int W_and_flags,
                                                    const unsigned int bid, const unsigned int nblk, double* lds_raw) {
@@ -758,7 +757,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
     OSQ_MSE_STAMP(t_entry);
     const int W = W_and_flags & 0xff;                             // 8 | 16; bit 8: the lean float64 term (osq_set_tuning("mse_lean"))
     const bool lean_ok = (W_and_flags >> 8) & 1;
-    const bool memo_on = (W_and_flags >> 12) & 1;                  // bit 12: the loss memo (tensor_search_advance)
+    const bool memo_on = (W_and_flags >> 12) & 1;                  // bit 12: the loss memo (tensor_search_advance); 9-10: probe modes of -DOSQ_MSE_DBG builds
     // the state's fields travel together with its `done` flag: one round trip, not two, before the first data load
     const float s = ts->scale, z = ts->zp;
     const double sd = ts->scale_d;
@@ -784,70 +783,7 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
         };
         double* part = static_cast<double*>(scratch);
         double* lds = lds_raw;
-        if (WAVE ? (fast && g.chunks > 0 && (g.NC == 16 || g.NC == 32) && g.P <= kCascadeMaxP) : ((g.S * g.NC) <= THREADS && g.chunks > 0)) {
-          if constexpr (WAVE) {
-            // full chunks, a wave per chunk: its next rows in flight under the arithmetic of the current ones (aten_order.h); the open unit below.
-            // (Data or scales beyond rcp_division_exact -- NaN / inf extrema, a scale outside [1e-9, 1e38] -- take the generic form below.)
-#ifdef OSQ_MSE_DBG
-            const bool dbg_noload = (W_and_flags >> 9) & 1, dbg_trivial = (W_and_flags >> 10) & 1;
-            auto load4 = [=](int64_t e) {
-                if (dbg_noload) { const float v = __int_as_float(0x3f000000 + static_cast<int>(e & 0xfffff)); return cascade_v4f32{v, v, v, v}; }
-                return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e);
-            };
-#else
-            constexpr bool dbg_trivial = false;
-            auto load4 = [=](int64_t e) { return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e); };
-#endif
-            static_assert(!WAVE || cascade_wave_lds_values<THREADS>() * 8 <= kOrdLdsBytes, "kOrdLdsBytes: 512 values per wave");
-#define OSQ_ORD_WAVE_F64(EVAL) do { \
-                if (g.NC == 16) { if (g.P == 4) cascade_chunks_wave<double, 4, 4, THREADS>(g, part, lds, load4, EVAL, bid, nblk); \
-                                  else cascade_chunks_wave<double, 5, 4, THREADS>(g, part, lds, load4, EVAL, bid, nblk); } \
-                else { if (g.P == 4) cascade_chunks_wave<double, 4, 5, THREADS>(g, part, lds, load4, EVAL, bid, nblk); \
-                       else cascade_chunks_wave<double, 5, 5, THREADS>(g, part, lds, load4, EVAL, bid, nblk); } } while (0)
-            if (lean) {
-                // the common case by far (a finite tensor, an integer zero point): the lean term, four elements of a row side by side;
-                // a row with an element within the tie guard (one row in ~1200) is redone in the exact chain -- one branch per row
-                auto eval4 = [=](cascade_v4f32 v, double (&t)[4]) {
-                    const float xs[4] = {v.x, v.y, v.z, v.w};
-                    if (dbg_trivial) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) t[i] = static_cast<double>(xs[i]);
-                        return;
-                    }
-                    float r[4];
-                    bool tie[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float u = xs[i] * rcp32;
-                        r[i] = rintf(u);
-                        tie[i] = fabsf(u - r[i]) >= 0.4999f;                  // false for NaN (u = +-inf): saturates below
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float c = __builtin_amdgcn_fmed3f(r[i], lo32, hi32);
-                        const double d = static_cast<double>(c) * sd - static_cast<double>(xs[i]);
-                        t[i] = d * d;
-                    }
-                    if (tie[0] | tie[1] | tie[2] | tie[3]) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const double exact = sq_err_f64_rcp(xs[i], sd, rcp, z, qmin, qmax);
-                            t[i] = tie[i] ? exact : t[i];
-                        }
-                    }
-                };
-                OSQ_ORD_WAVE_F64(eval4);
-            } else {
-                auto eval4 = [=](cascade_v4f32 v, double (&t)[4]) {
-                    t[0] = sq_err_f64_rcp(v.x, sd, rcp, z, qmin, qmax);
-                    t[1] = sq_err_f64_rcp(v.y, sd, rcp, z, qmin, qmax);
-                    t[2] = sq_err_f64_rcp(v.z, sd, rcp, z, qmin, qmax);
-                    t[3] = sq_err_f64_rcp(v.w, sd, rcp, z, qmin, qmax);
-                };
-                OSQ_ORD_WAVE_F64(eval4);
-            }
-#undef OSQ_ORD_WAVE_F64
-          } else {
+        if ((g.S * g.NC) <= THREADS && g.chunks > 0) {
             // full chunks: loads of the next chunk under the arithmetic of this one (aten_order.h); the open unit below
 #ifdef OSQ_MSE_DBG
             const bool dbg_noload = (W_and_flags >> 9) & 1, dbg_trivial = (W_and_flags >> 10) & 1;
@@ -900,7 +836,6 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
                 if (g.P == 4) cascade_chunks_pipelined<double, 1, 4, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
                 else cascade_chunks_pipelined<double, 1, 5, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 8);
             }
-          }
             OSQ_MSE_STAMP(t_groups);
             if (bid == nblk - 1) cascade_units<double, 1, THREADS>(g, part, lds, term, 0u, 1u, g.chunks);     // the open unit: the workgroup with the fewest chunks
             OSQ_MSE_PHASE(0, t_state - t_entry); OSQ_MSE_PHASE(1, t_groups - t_state); OSQ_MSE_PHASE(4, 1);
@@ -926,27 +861,13 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
         auto term = [=](int64_t e, float (&t)[1]) { t[0] = sq_err(x[e], s, z, qmin, qmax); };
         float* part = static_cast<float*>(scratch);
         float* lds = reinterpret_cast<float*>(lds_raw);
-        if (WAVE ? (g.chunks > 0 && (g.NC == 32 || g.NC == 64) && g.P <= kCascadeMaxP) : ((g.S * g.NC) <= THREADS && g.chunks > 0)) {
-          if constexpr (WAVE) {
-            auto load4 = [=](int64_t e) { return *reinterpret_cast<const cascade_v4f32 __attribute__((address_space(1)))*>(x + e); };
-            auto eval4 = [=](cascade_v4f32 v, float (&t)[4]) {
-                t[0] = sq_err(v.x, s, z, qmin, qmax);
-                t[1] = sq_err(v.y, s, z, qmin, qmax);
-                t[2] = sq_err(v.z, s, z, qmin, qmax);
-                t[3] = sq_err(v.w, s, z, qmin, qmax);
-            };
-            if (g.NC == 32) { if (g.P == 4) cascade_chunks_wave<float, 4, 5, THREADS>(g, part, lds, load4, eval4, bid, nblk);
-                              else cascade_chunks_wave<float, 5, 5, THREADS>(g, part, lds, load4, eval4, bid, nblk); }
-            else { if (g.P == 4) cascade_chunks_wave<float, 4, 6, THREADS>(g, part, lds, load4, eval4, bid, nblk);
-                   else cascade_chunks_wave<float, 5, 6, THREADS>(g, part, lds, load4, eval4, bid, nblk); }
-          } else {
+        if ((g.S * g.NC) <= THREADS && g.chunks > 0) {
             auto load = [=](int64_t e) { return x[e]; };
             auto eval = [=](float xf, int64_t, float (&t)[1]) { t[0] = sq_err(xf, s, z, qmin, qmax); };
             if (g.NC == 32 && g.P == 4)                         // the reference machine's W = 8 (S * NC <= 512 leaves P = 4 only): log2(NC) a constant, as above
                 cascade_chunks_pipelined<float, 1, 4, THREADS, float, decltype(load), decltype(eval), 5>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
             else if (g.P == 4) cascade_chunks_pipelined<float, 1, 4, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
             else cascade_chunks_pipelined<float, 1, 5, THREADS, float>(g, part, lds, load, eval, bid, nblk, kOrdLdsBytes / 4);
-          }
             if (bid == nblk - 1) cascade_units<float, 1, THREADS>(g, part, lds, term, 0u, 1u, g.chunks);
         } else {
             cascade_units<float, 1, THREADS>(g, part, lds, term, bid, nblk);
@@ -962,12 +883,12 @@ __device__ __forceinline__ void ordered_evaluation(const float* __restrict__ x_g
     }
 }
 
-__global__ __launch_bounds__(kOrdThreadsPipe) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
+__global__ __launch_bounds__(kOrdThreads) void msefast_tensor_ordered_kernel(const float* __restrict__ x, int64_t n_host,
                                                                             const int64_t* __restrict__ n_dev,
                                                                             TensorSearch* __restrict__ ts, void* __restrict__ scratch,
                                                                             unsigned int* __restrict__ counters, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
-    ordered_evaluation<kOrdThreadsPipe, false>(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
+    ordered_evaluation<kOrdThreads>(x, n_dev ? n_dev[0] : n_host, ts, scratch, counters, W, blockIdx.x, gridDim.x, lds_raw);
 }
 
 // The strict form of the searches of a whole forward (the observers of an observer pass are independent): ONE launch per
@@ -992,20 +913,11 @@ constexpr size_t kOrderedCounterBytes = (1 + kTicketShards) * kTicketStride * si
 // A workgroup's first loads are a dependent chain -- which site, its table entry, the search's state, only then the data --
 // and a round has thousands of short-lived workgroups: the chain is kept at three round trips (block -> site map, entry,
 // state; the element count of a masked site is copied into its entry once, by ordered_sites_counts_kernel).
-#ifndef OSQ_ORD_MIN_WAVES
-#define OSQ_ORD_MIN_WAVES 4                                   // waves per SIMD the WAVE form's registers are budgeted for (A/B builds: -DOSQ_ORD_MIN_WAVES=5)
-#endif
-template <int THREADS, bool WAVE>
-__global__ __launch_bounds__(THREADS, WAVE ? OSQ_ORD_MIN_WAVES : 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites,
-                                                                                   const unsigned char* __restrict__ block_site, int n_sites, int W) {
+__global__ __launch_bounds__(kOrdThreads, 4) void msefast_tensor_ordered_multi_kernel(const OrderedSite* __restrict__ sites,
+                                                                                      const unsigned char* __restrict__ block_site, int n_sites, int W) {
     __shared__ double lds_raw[kOrdLdsBytes / 8];
-    // PING-PONG (round 6): a round streams every open site once (~0.3-0.6 GB), more than the 256 MB memory-side cache holds, so a
-    // round that walks the sites in the same direction as its predecessor finds none of its bytes there.  Every other round walks
-    // the grid backwards: what the last round read last is read first.  Which workgroup adds which chunk does not touch a sum
-    // (the chunks' block sums have their own slots; the finisher folds them in position order).
-    const unsigned int b = ((W >> 11) & 1) ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    const OrderedSite s = sites[block_site[b]];
-    ordered_evaluation<THREADS, WAVE>(s.x, s.n_host, s.ts, s.scratch, s.counters, W, b - s.block_begin, s.blocks, lds_raw);
+    const OrderedSite s = sites[block_site[blockIdx.x]];
+    ordered_evaluation<kOrdThreads>(s.x, s.n_host, s.ts, s.scratch, s.counters, W, blockIdx.x - s.block_begin, s.blocks, lds_raw);
 }
 
 // after the gathers of a group: n_host <- the device-side count of valid elements (same stream, once per group)
@@ -1851,14 +1763,11 @@ extern "C" int osq_msefast_tensor_evals_ordered(void* state, const float* x_flat
     const CascadeGeom g = cascade_geom(n, g_mse_sum_order / 2);
     const int grid = static_cast<int>(std::min<int64_t>(g.chunks + 1, kMaxBlocks));
     for (int e = 0; e < n_evals; ++e)
-        hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreadsPipe), 0, st, x_flat, n, n_device,
+        hipLaunchKernelGGL(msefast_tensor_ordered_kernel, dim3(grid), dim3(kOrdThreads), 0, st, x_flat, n, n_device,
                            static_cast<TensorSearch*>(state), scratch, ws.counter(kFamMseFlat), g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_memo ? 4096 : 0));
     return check_launch("msefast_tensor_evals_ordered");
 }
 
-OSQ_AB_KNOB(int, g_mse_pingpong, 1);   // osq_set_tuning("mse_pingpong", 0): every round walks the grid forwards (A/B)
-OSQ_AB_KNOB(int, g_mse_wave, 0);            // osq_set_tuning("mse_wave", 0): the rounds by cascade_chunks_pipelined (512-thread workgroups, a row per thread) instead of a wave per chunk
-OSQ_AB_KNOB(int, g_ord_slots, 0);           // osq_set_tuning("mse_round_slots", n): workgroups of a round, dealt to the sites by size (0: a workgroup per mse_round_groups)
 OSQ_AB_KNOB(int, g_ord_groups, 8);          // osq_set_tuning("mse_round_groups", n): chunk groups per workgroup of a strict round
 extern "C" size_t osq_msefast_ordered_multi_bytes(int n_sites) {
     if (n_sites <= 0) return 0;
@@ -1875,8 +1784,6 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
     OSQ_REQUIRE(g_mse_sum_order == 8 || g_mse_sum_order == 16,
                 "msefast_ordered_multi_prepare: set \"mse_sum_order\" to the reference machine's SIMD width (8 or 16) first");
     std::vector<OrderedSite> host(static_cast<size_t>(n_sites));
-    int64_t total_elems = 0;
-    for (int i = 0; i < n_sites; ++i) total_elems += n[i] > 0 ? n[i] : 0;
     char* const counters0 = static_cast<char*>(table) + static_cast<size_t>(n_sites) * sizeof(OrderedSite);
     int64_t total = 0;
     for (int i = 0; i < n_sites; ++i) {
@@ -1897,14 +1804,7 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
         // the default) so that the loads of its next group travel under the arithmetic of the current one (aten_order.h,
         // cascade_chunks_pipelined); S = 32 (beyond 8.4 M elements): chunks of 16384 elements, 8 to a workgroup (measured best)
         const int64_t chunk_elems = static_cast<int64_t>(g.S) * g.S * g.NC;
-        int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
-        if (g_ord_slots > 0) {
-            // a round's workgroups are as many as the chip holds at once (g_ord_slots), dealt to the sites in proportion to their
-            // elements: every workgroup starts with the launch and they end together -- one start-up chain (table -> state -> first
-            // rows) per round and slot instead of one per 16 chunks, no last partial wave of workgroups
-            const int64_t share = std::max<int64_t>((n[i] * g_ord_slots + total_elems - 1) / total_elems, 1);
-            per_wg = std::max<int64_t>((g.chunks + share - 1) / share, 1);
-        }
+        const int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
         const int64_t groups = (g.chunks + per_wg - 1) / per_wg + 1;
         s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>(groups, 1), kMaxBlocks));
         s.pad[0] = s.pad[1] = 0u;
@@ -1935,13 +1835,8 @@ extern "C" int osq_msefast_ordered_multi_evals(const void* table, int n_sites, i
     const OrderedSite* sites = static_cast<const OrderedSite*>(table);
     const unsigned char* block_site = static_cast<const unsigned char*>(table) + static_cast<size_t>(n_sites) * (sizeof(OrderedSite) + kOrderedCounterBytes);
     for (int e = 0; e < n_evals; ++e)
-    {
-        const int flags = g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_dbg << 9) | ((g_mse_pingpong && (e & 1)) ? 2048 : 0) | (g_mse_memo ? 4096 : 0);
-        if (g_mse_wave)
-            hipLaunchKernelGGL((msefast_tensor_ordered_multi_kernel<kOrdThreads, true>), dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites, flags);
-        else
-            hipLaunchKernelGGL((msefast_tensor_ordered_multi_kernel<kOrdThreadsPipe, false>), dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreadsPipe), 0, st, sites, block_site, n_sites, flags);
-    }
+        hipLaunchKernelGGL(msefast_tensor_ordered_multi_kernel, dim3(static_cast<unsigned>(total_blocks)), dim3(kOrdThreads), 0, st, sites, block_site, n_sites,
+                           g_mse_sum_order | (g_mse_lean ? 256 : 0) | (g_mse_dbg << 9) | (g_mse_memo ? 4096 : 0));
     if (done_out) hipLaunchKernelGGL(msefast_done_multi_kernel, dim3(1), dim3(OSQ_WAVE), 0, st, sites, n_sites, done_out);
     return check_launch("msefast_ordered_multi_evals");
 }
@@ -1955,11 +1850,8 @@ namespace osq { bool set_msefast_tuning(const char* key, int value) {
     if (std::string(key) == "mse_rows_order") { if (value != 0 && value != 8 && value != 16) return false; g_mse_rows_order = value; return true; }
     if (std::string(key) == "mse_sum_order") { if (value != 0 && value != 8 && value != 16 && value != 64) return false; g_mse_sum_order = value; return true; }
 #ifdef OSQ_TUNABLE
-    if (std::string(key) == "mse_wave") { g_mse_wave = value != 0; return true; }
-    if (std::string(key) == "mse_round_slots") { if (value < 0 || value > 65536) return false; g_ord_slots = value; return true; }
     if (std::string(key) == "mse_round_groups") { if (value < 1 || value > 64) return false; g_ord_groups = value; return true; }
     if (std::string(key) == "mse_lean") { g_mse_lean = value != 0; return true; }
-    if (std::string(key) == "mse_pingpong") { g_mse_pingpong = value != 0; return true; }
 #ifdef OSQ_MSE_DBG
     if (std::string(key) == "mse_dbg") { g_mse_dbg = value & 3; return true; }
 #endif

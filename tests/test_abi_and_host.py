@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
 
 
 SHIPPED_SWITCHES = {"mse_sum_order": (0, 8), "mse_rows_order": (8, 8), "fused_step": (0, 1), "mse_resident": (0, 1), "final_fast": (0, 1),
-                    "select_shortcut": (0, 1), "fused_spin_limit": (5, 0), "mse_spin_limit": (5, 0)}
+                    "select_shortcut": (0, 1), "mse_memo": (0, 1), "fused_spin_limit": (5, 0), "mse_spin_limit": (5, 0)}
 AB_KNOBS = ("fq_unroll", "fq_max_blocks", "fq_nt", "fq_headsplit", "stream_wt", "bwd_blocks", "bwd_order_chunks", "ln_blocks",
             "obs_blocks", "tok_nt", "fused_gate", "fused_grid", "select_hint", "mse_round_groups", "mse_lean", "mse_grid_all", "mse_dbg")
 

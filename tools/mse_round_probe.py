@@ -17,8 +17,9 @@ ROUNDS = 12
 knobs = [int(a) for a in sys.argv[1:]] or [8]
 modes = [int(m) for m in os.environ.get("MSE_DBG_MODES", "0").split()]      # -DOSQ_MSE_DBG builds: 1 = no loads, 2 = trivial term, 3 = both
 ops.set_tuning("mse_memo", 0)
-if os.environ.get("MSE_WAVE"):
-    ops.set_tuning("mse_wave", int(os.environ["MSE_WAVE"]))
+for kv in os.environ.get("MSE_TUNING", "").split():
+    k, v = kv.split("=")
+    ops.set_tuning(k, int(v))
 CASES = (((32, 128, 768), 48), ((32, 128, 3072), 12), ((32, 128, 3072), 6), ((32, 128, 768), 8))
 if os.environ.get("MSE_PROBE_CASES"):
     CASES = tuple(CASES[int(i)] for i in os.environ["MSE_PROBE_CASES"].split())
@@ -26,11 +27,7 @@ for shape, k in CASES:
     xs = [(torch.randn(*shape, generator=g) * (1 + i % 3)).to(dev) for i in range(k)]
     for groups, mode in [(a, b) for a in knobs for b in modes]:
         try:
-            if groups >= 100:
-                ops.set_tuning("mse_round_slots", groups)
-            else:
-                ops.set_tuning("mse_round_slots", 0)
-                ops.set_tuning("mse_round_groups", groups)
+            ops.set_tuning("mse_round_groups", groups)
         except Exception:
             if groups != knobs[0]:
                 continue

@@ -1804,7 +1804,7 @@ extern "C" int osq_msefast_ordered_multi_prepare(void* table, size_t table_bytes
         // the default) so that the loads of its next group travel under the arithmetic of the current one (aten_order.h,
         // cascade_chunks_pipelined); S = 32 (beyond 8.4 M elements): chunks of 16384 elements, 8 to a workgroup (measured best)
         const int64_t chunk_elems = static_cast<int64_t>(g.S) * g.S * g.NC;
-        const int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192) / chunk_elems, 1);
+        const int64_t per_wg = std::max<int64_t>((static_cast<int64_t>(g_ord_groups) * 8192 * (g.P > 4 ? 2 : 1)) / chunk_elems, 1);
         const int64_t groups = (g.chunks + per_wg - 1) / per_wg + 1;
         s.blocks = static_cast<unsigned int>(std::min<int64_t>(std::max<int64_t>(groups, 1), kMaxBlocks));
         s.pad[0] = s.pad[1] = 0u;

@@ -24,7 +24,7 @@ def set_strict(on=True, simd_width=8, backward=None, _lib=None):
 
     ``on`` -- the MSEFast losses.  ON by default: min_val / max_val / scale / zero_point of every MSEFast observer equal
     that reference run bit for bit, and it is also the FASTER form of an observer pass (the searches of a forward run as
-    rounds, quantization/deferred.py: BASELINE configs[3] 1.09 s against 2.28 s).  A lone search pays one launch per
+    rounds, quantization/deferred.py: BASELINE configs[3] 0.47-0.50 s against 2.2 s since round 6).  A lone search pays one launch per
     evaluation (15-24 us against 6-9 for the resident order-free form).  Per-channel (row) searches follow the
     reference's order in either mode.
 

@@ -77,6 +77,12 @@ def test_memo_on_equals_memo_off(dev, tier):
                     assert pairs + hits == nfev, (tier, name, f64, a[3])          # every evaluation either streamed (and was kept) or was answered
                 if name != "clipped":
                     assert hits > nfev // 2, (tier, name, f64, a[3])              # two-sided data: most evaluations repeat a pair
+                else:
+                    # the range's lower end sits at the data's minimum: a new scale per shift, more distinct pairs than the table
+                    # holds (512) -- it fills, the rest stream without being kept, and the results still equal the memo-less run
+                    assert pairs > 400, (tier, name, f64, a[3])
+                    if tier.startswith("strict"):
+                        assert pairs == 512 and nfev - hits > 512, (tier, name, f64, a[3])
                 total_hits += hits
         assert total_hits > 0
     finally:
@@ -113,6 +119,34 @@ def test_memo_in_rounds_equals_memo_off(dev):
         b = run()
         for (amin, amax, an), (bmin, bmax, bn) in zip(a, b):
             assert bits_equal(amin, bmin) and bits_equal(amax, bmax) and bits_equal(an, bn)
+    finally:
+        ops.set_tuning("mse_memo", 1)
+        osq.reset_tier()
+
+
+def test_one_dimensional_searches_have_nothing_to_repeat(dev):
+    """The 1-D search (observer.py:483-494: one-sided data) changes the scale with every candidate: the memo keeps every pair, answers
+    none, and the result equals the memo-less run."""
+    import outlier_suppression_amd as osq
+    from outlier_suppression_amd import ops
+    osq.set_strict(True)
+    try:
+        g = torch.Generator().manual_seed(23)
+        x = torch.softmax(torch.randn(4, 6, 32, 32, generator=g) * 2, -1).to(dev)
+        out = []
+        for memo in (1, 0):
+            ops.set_tuning("mse_memo", memo)
+            cur = ops.batch_minmax(x, None, 2)
+            r = ops.msefast_tensor_begin(x, cur, None, 2, 0, 63, False, "pos", False, False)
+            ops.msefast_tensor_run(r, None, False)
+            stats = N(ops.msefast_tensor_stats(r))
+            mn = torch.full((1,), float("inf"), dtype=torch.float64, device=dev)
+            mx = torch.full((1,), float("-inf"), dtype=torch.float64, device=dev)
+            nfev = int(ops.msefast_tensor_commit(r, ops.UPDATE_RUNNING, 0, mn, mx).item())
+            out.append((N(mn), N(mx), nfev, stats))
+        (amin, amax, an, astats), (bmin, bmax, bn, bstats) = out
+        assert bits_equal(amin, bmin) and bits_equal(amax, bmax) and an == bn
+        assert int(astats[1]) == an and int(astats[2]) == 0 and tuple(int(v) for v in bstats[1:3]) == (0, 0)
     finally:
         ops.set_tuning("mse_memo", 1)
         osq.reset_tier()

@@ -150,3 +150,34 @@ def test_one_dimensional_searches_have_nothing_to_repeat(dev):
     finally:
         ops.set_tuning("mse_memo", 1)
         osq.reset_tier()
+
+
+def test_memo_at_baseline_size(dev):
+    """BASELINE's [256,128,768] activation, masked (lengths randint(8,129)), both calls of an AvgMSEFast observer (fp32 then float64
+    arithmetic): a size-independent property instead of an oracle pass -- the memo changes no bit of range, statistic or nfev."""
+    import outlier_suppression_amd as osq
+    from outlier_suppression_amd import ops
+    from outlier_suppression_amd.quantization.observer import AvgMSEFastObserver
+    osq.set_strict(True)
+    try:
+        gen = torch.Generator(device=dev).manual_seed(0)
+        xs = []
+        for _ in range(2):
+            x = torch.randn(256, 128, 768, device=dev, generator=gen)
+            x[..., [7, 300, 511]] *= 20
+            xs.append(x)
+        L = torch.randint(8, 129, (256,), device=dev, generator=gen)
+        out = []
+        for memo in (1, 0):
+            ops.set_tuning("mse_memo", memo)
+            ob = AvgMSEFastObserver(bit=6, symmetric=False).to(dev)
+            per_call = []
+            for x in xs:
+                ob(x, L, 1)
+                per_call.append((N(ob.min_val), N(ob.max_val), N(ob.last_nfev)))
+            out.append(per_call)
+        for (amin, amax, an), (bmin, bmax, bn) in zip(*out):
+            assert bits_equal(amin, bmin) and bits_equal(amax, bmax) and bits_equal(an, bn)
+    finally:
+        ops.set_tuning("mse_memo", 1)
+        osq.reset_tier()

@@ -218,6 +218,37 @@ def kernel_table(dev, xs, lengths, reps=20):
                 "wall_us": round(res[1][0], 1), "loss_evaluations": res[1][1], "us_per_evaluation": round(res[1][0] / max(res[1][1], 1), 2),
                 "one_launch_per_evaluation_us_per_evaluation": round(res[0][0] / max(res[0][1], 1), 2),
                 "bound": "per evaluation: fp64 VALU work on the resident tensor + one exchange through memory (~2 us) + the serial Brent step (~1.5 us)"}
+        # the ROUNDS kernel of an observer pass (msefast_tensor_ordered_multi_kernel): one loss evaluation of K open float64 searches per
+        # launch, 604 MB per round; the loss memo off so that every timed round streams every site (with it ~1 round in 4 streams a
+        # two-sided site: that is the flow's gain, not the kernel's)
+        if ops.reference_sum_order("mse"):
+            for tag, shp, k in (("48 x [32,128,768]", (32, 128, 768), 48), ("12 x [32,128,3072]", (32, 128, 3072), 12)):
+                sites = [torch.randn(*shp, device=dev) * (1 + i % 3) for i in range(k)]
+                ops.set_tuning("mse_memo", 0)
+                try:
+                    group = []
+                    for xm in sites:
+                        cur = torch.stack([xm.min(), xm.max()]).to(torch.float32)
+                        group.append(ops.msefast_tensor_begin(xm, cur, None, 1, 0, 63, False, "no", True, float64_input=True))
+                    ctx = ops._ordered_group_prepare(group)
+                    ops._ordered_group_rounds(ctx, 2)
+                    best = None
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        ops._ordered_group_rounds(ctx, 12)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us = e0.elapsed_time(e1) * 1e3 / 12
+                        best = us if best is None else min(best, us)
+                finally:
+                    ops.set_tuning("mse_memo", 1)
+                nbytes = 4 * sum(xm.numel() for xm in sites)
+                rows[f"MSEFast rounds kernel, {tag} open float64 searches (one loss evaluation of each per launch, reference summation order)"] = dict(
+                    hbm_row(best, nbytes, cycled=True), timer="stream events around 12 back-to-back rounds, best of 3 (kernel boundaries included)",
+                    note="a bare read of the same bytes takes 100-105 us (profiles/r06_stream_pattern.txt)")
+                del ctx, group, sites
         # Infinity Cache: the same 96 MiB tensor over and over (x + y = 192 MiB < 256 MiB) against the buffer cycle above
         warm_y = ev_timed(lambda i: ops.fake_quant_per_tensor(xs[0], s, zf, 0, 63, ops.PARAM_LSQPLUS, 1e-4))
         add_ev("fake_quant_forward, warm (same input every launch; Infinity Cache)", warm_y, 8 * n, resident=True)
